@@ -1,0 +1,153 @@
+/* libspegnet_hip.so -- C ABI of the MI355X-native SPEGNet hot path.
+ *
+ * The reference (Baber-Jan/SPEGNet) has no FFI / operator registry: its hot path is a chain of stock
+ * torch.nn calls inside SPEGNet.forward (models/spegnet.py:137-206), the sam2 Hiera trunk
+ * (models/feature_encoding.py:156-159,236), CODLoss (utils/loss_functions.py:242-295) and
+ * Trainer._process_batch (engine/trainer.py:308-427).  Each entry point below replaces the group of
+ * torch calls named in its comment.  See INTEGRATION.md for the ctypes binding.
+ *
+ * Conventions
+ *   - dtype: SPG_F32 (parity path, exact-f32 MFMA) or SPG_BF16 (fast path, bf16 MFMA, f32 accumulate).
+ *     "T" below means that storage type.  Parameters that stay fp32 in both modes are typed float*.
+ *   - activations are NHWC (channels-last); encoder tokens are [B,H,W,C] == [M,C] row-major.
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator); the library
+ *     never allocates, frees or retains device memory, never synchronises, and launches only on
+ *     `stream`, so every call is hipGraph-capturable and re-entrant (autograd thread safe).
+ *   - return 0 on success, negative SPG_ERR_* otherwise; spg_last_error() gives the text.
+ */
+#ifndef SPEGNET_HIP_H
+#define SPEGNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* spg_stream_t; /* hipStream_t */
+
+enum { SPG_F32 = 0, SPG_BF16 = 1 };
+enum { SPG_OK = 0, SPG_ERR_BAD_ARG = -1, SPG_ERR_LAUNCH = -2, SPG_ERR_UNSUPPORTED = -3 };
+enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2 };
+
+int spg_version(void);
+const char* spg_last_error(void);
+
+/* ---- GEMM family (MFMA) ---------------------------------------------------------------------
+ * spg_gemm_nt: C[M,N] = epi( X[M,K] . W[N,K]^T )      replaces F.linear / 1x1 conv / 3x3 conv fwd+dgrad
+ *   epilogue order: +bias[n] (f32) -> store pre-activation to C2 (optional) -> act -> *gelu'(gelu_h[m,n])
+ *   (optional) -> +residual[m,n] (optional) -> C.
+ *   conv3x3 != 0: X is NHWC [B,H,W,Ci], M=B*H*W, K=9*Ci, k = tap*Ci+ci (pad 1, stride 1), W packed [N][9*Ci].
+ * spg_gemm_tn: dW[N,K] += dY[M,N]^T . X[M,K]   (f32 atomic accumulation; same conv3x3 gather on X)
+ *   replaces the weight-gradient half of linear/conv backward (engine/trainer.py:402 .backward()).    */
+int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, void* C2, const float* bias,
+                const void* residual, const void* gelu_h, int M, int N, int K, int ldx, int ldc, int act,
+                int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream);
+int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx,
+                int ldw, int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream);
+
+/* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
+ * spg_pack_matrix: dst[r][c] = src[r][c] (transpose=0) or dst[c][r] = src[r][c] (transpose=1), src f32 [R,C].
+ * spg_pack_conv3x3: torch [Co,Ci,3,3] f32 -> fwd pack [Co][tap][Ci] and dgrad pack [Ci][tap'][Co] (tap' flipped).
+ * spg_unpack_conv3x3_grad: packed f32 grad [Co][tap][Ci] -> torch layout [Co,Ci,3,3] (+= if accumulate). */
+int spg_pack_matrix(int dtype, const float* src, void* dst, int R, int C, int transpose, spg_stream_t stream);
+int spg_pack_conv3x3(int dtype, const float* src, void* dst_fwd, void* dst_dgrad, int Co, int Ci, spg_stream_t stream);
+int spg_unpack_conv3x3_grad(const float* packed, float* dst, int Co, int Ci, spg_stream_t stream);
+
+/* ---- Hiera trunk pieces (sam2 Hiera MultiScaleBlock) --------------------------------
+ * layernorm: y = LN(x)*g+b over last dim C (eps), stats saved (mean,rstd f32 [M]) for backward.
+ * layernorm_bwd: dx = LN'(dy) (+ dres if non-null); dgamma/dbeta f32 atomically accumulated.            */
+int spg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, int M, int C, float eps, spg_stream_t stream);
+int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int M, int C,
+                      spg_stream_t stream);
+/* windowed multi-head attention straight from the fused qkv projection output [B,H,W,3,heads,hd].
+ * Windows of ws x ws over the HxW map (ws<=0: one global window); padded window slots act as keys equal to
+ * the qkv bias (what zero-padding after LN produces in the reference) with multiplicity folded in.
+ * q_pooled != NULL: queries come from a 2x2-max-pooled map [B,H/2,W/2,heads*hd] (stage-transition blocks),
+ * windows on the query side are ws/2.  lse f32 [B,Hq,Wq,heads] saved for backward.                        */
+int spg_attn_fwd(int dtype, const void* qkv, const void* q_pooled, const void* qkv_bias_t, void* out, float* lse,
+                 int B, int H, int W, int heads, int hd, int ws, spg_stream_t stream);
+/* dqkv [B,H,W,3,heads,hd] (q part written only when q_pooled==NULL, else dq_pooled [B,H/2,W/2,heads*hd]);
+ * dbias_pad f32 [3*heads*hd] accumulates the gradient reaching the bias through padded key slots.         */
+int spg_attn_bwd(int dtype, const void* qkv, const void* q_pooled, const void* qkv_bias_t, const void* out,
+                 const void* dout, const float* lse, void* dqkv, void* dq_pooled, float* dbias_pad, float* delta_ws,
+                 int B, int H, int W, int heads, int hd, int ws, spg_stream_t stream);
+/* 2x2 max pool on NHWC with channel window [c0, c0+C) of a row of ldc channels; idx u8 saved.
+ * bwd scatters dy into dx (dx rows of ldc channels; only [c0,c0+C) touched; accumulate=0 overwrites).      */
+int spg_maxpool2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int ldc, int c0,
+                     spg_stream_t stream);
+int spg_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int ldc,
+                     int c0, spg_stream_t stream);
+/* patch embedding input gather: image f32/T NCHW [B,3,S,S] -> im2col rows [B*(S/4)^2, Kpad] (k = c*49+ky*7+kx,
+ * zero padded to Kpad), so that patch-embed is a spg_gemm_nt; pos-embed add is the GEMM's residual.          */
+int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int S, int Kpad, spg_stream_t stream);
+
+/* ---- column reductions / elementwise (HBM-bound) -----------------------------------------------------------
+ * colsum: out[c] += sum_m x[m][c] (f32 atomics; bias gradients).  gap_sum / chan_prod_sum: the same per image. */
+int spg_colsum(int dtype, const void* x, float* out, int M, int C, int ldx, spg_stream_t stream);
+int spg_gap_sum(int dtype, const void* x, float* out, int B, long HW, int C, spg_stream_t stream);
+int spg_chan_prod_sum(int dtype, const void* a, const void* b, float* out, int B, long HW, int C, spg_stream_t stream);
+int spg_add(int dtype, const void* a, const void* b, void* out, long n, spg_stream_t stream);
+int spg_cast_bf16(const float* f32, void* bf16, long n, int to_f32, spg_stream_t stream);
+int spg_copy_channels(int dtype, const void* x, void* y, long M, int C, int ldx, int cx0, int ldy, int cy0,
+                      int accumulate, spg_stream_t stream);
+
+/* ---- BatchNorm2d on NHWC rows [M,C] (nn.BatchNorm2d eps 1e-5, momentum 0.1) ----------
+ * bn_stats: stats[c] += sum x, stats[C+c] += sum x^2 (caller zeroes stats f32 [2C]).
+ * bn_finalize: training: batch mean / biased var from stats, running stats updated with the unbiased var;
+ *   eval: running stats.  Writes scale_shift f32 [2C] (y = x*scale+shift) and mean_invstd f32 [2C].
+ * bn_apply: y = relu?(x*scale+shift).
+ * bn_bwd_reduce: sums[c] += sum dy', sums[C+c] += sum dy'*xhat, dy' = dy where the (recomputed) ReLU passed.
+ * bn_bwd_apply: dx = gamma*invstd*(dy' - sums0/M - xhat*sums1/M); dgamma += sums1, dbeta += sums0.          */
+int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, spg_stream_t stream);
+int spg_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* scale_shift, float* mean_invstd, long M, int C, float eps,
+                    float momentum, int training, spg_stream_t stream);
+int spg_bn_apply(int dtype, const void* x, const float* scale_shift, void* y, long M, int C, int relu,
+                 spg_stream_t stream);
+int spg_bn_bwd_reduce(int dtype, const void* dy, const void* x, const float* scale_shift, const float* mean_invstd,
+                      float* sums, long M, int C, int relu, spg_stream_t stream);
+int spg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* scale_shift, const float* mean_invstd,
+                     const float* gamma, const float* sums, void* dx, float* dgamma, float* dbeta, long M, int C,
+                     int relu, spg_stream_t stream);
+
+/* ---- CFI (models/feature_integration.py) -----------------------------------------------------------------
+ * upsample_bilinear (align_corners=False) writes into channels [c0,c0+C) of rows of ldy channels, i.e. it
+ *   places its result directly inside the 2016-channel fusion input / the 320-channel PED concat
+ *   (feature_integration.py:229-236, object_detection.py:219-227); _bwd is the exact adjoint (gather form).
+ * se_fc: hidden = relu(W1 gap), scale = sigmoid(W2 hidden) (feature_integration.py:121-126,147-151).
+ * dwconv3x3: dilated depth-wise 3x3, pad = dil (feature_integration.py:317-332); flip=1 gives the input grad.
+ * easpp_fuse: grouped 1x1 over the BRANCH-MAJOR concat of 4 branches + broadcast global branch: group g reads
+ *   concat channels 5g..5g+4 (feature_integration.py:348-360,411-412).                */
+int spg_upsample_bilinear(int dtype, const void* x, void* y, int B, int h, int w, int C, int H, int W, int ldy,
+                          int c0, spg_stream_t stream);
+int spg_upsample_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int h, int w, int C, int H, int W, int ldy,
+                              int c0, int accumulate, spg_stream_t stream);
+int spg_se_fc(const float* gap, const float* w1, const float* w2, float* hidden, float* scale, int B, int C, int R,
+              spg_stream_t stream);
+int spg_se_fc_bwd(const float* gap, const float* w1, const float* w2, const float* hidden, const float* scale,
+                  const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, spg_stream_t stream);
+int spg_chan_scale(int dtype, const void* x, const float* scale, void* y, int B, long HW, int C, spg_stream_t stream);
+int spg_chan_scale_bwd(int dtype, const void* dy, const float* scale, const float* dgap, void* dx, int B, long HW,
+                       int C, spg_stream_t stream);
+int spg_dwconv3x3(int dtype, const void* x, const float* w, void* y, int B, int H, int W, int C, int dil, int flip,
+                  spg_stream_t stream);
+int spg_dwconv3x3_wgrad(int dtype, const void* dy, const void* x, float* dw, int B, int H, int W, int C, int dil,
+                        spg_stream_t stream);
+int spg_easpp_fuse(int dtype, const void* br0, const void* br1, const void* br2, const void* br3, const float* glob,
+                   const float* w, void* y, int B, long HW, int C, spg_stream_t stream);
+int spg_easpp_fuse_bwd(int dtype, const void* dy, const void* br0, const void* br1, const void* br2, const void* br3,
+                       const float* glob, const float* w, void* d0, void* d1, void* d2, void* d3, float* dglob,
+                       float* dw, int B, long HW, int C, spg_stream_t stream);
+
+/* ---- EFE / PED heads (models/object_detection.py:126-130,155,306,339): 1x1 conv C->1 with bias ------------ */
+int spg_head1x1(int dtype, const void* x, const float* w, const float* b, void* y, long M, int C, spg_stream_t stream);
+int spg_head1x1_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, long M,
+                    int C, int accumulate, spg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

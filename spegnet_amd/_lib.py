@@ -1,0 +1,99 @@
+"""ctypes binding of libspegnet_hip.so (the C ABI declared in include/spegnet_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  The product path never
+imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspegnet_hip.so")
+
+SPG_F32, SPG_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+# name -> argument type string (p pointer, i int, l long, f float); every function returns int
+SIGNATURES = {
+    "spg_gemm_nt": "ipppppppiiiiiiiiiiip",
+    "spg_gemm_tn": "ipppiiiiiiiiiiip",
+    "spg_pack_matrix": "ippiiip",
+    "spg_pack_conv3x3": "ipppiip",
+    "spg_unpack_conv3x3_grad": "ppiip",
+    "spg_layernorm_fwd": "ipppppp" "iifp",
+    "spg_layernorm_bwd": "ippppppppp" "iip",
+    "spg_attn_fwd": "ippppp" "iiiiiip",
+    "spg_attn_bwd": "ippppppppp" "p" "iiiiiip",
+    "spg_maxpool2_fwd": "ippp" "iiiiiip",
+    "spg_maxpool2_bwd": "ippp" "iiiiiip",
+    "spg_patch_im2col": "ipp" "iiip",
+    "spg_colsum": "ipp" "iiip",
+    "spg_gap_sum": "ipp" "ilip",
+    "spg_chan_prod_sum": "ippp" "ilip",
+    "spg_add": "ippp" "lp",
+    "spg_cast_bf16": "pp" "lip",
+    "spg_copy_channels": "ipp" "liiiiiip",
+    "spg_bn_stats": "ipp" "lip",
+    "spg_bn_finalize": "ppppppp" "liffip",
+    "spg_bn_apply": "ippp" "liip",
+    "spg_bn_bwd_reduce": "ippppp" "liip",
+    "spg_bn_bwd_apply": "ippppppppp" "liip",
+    "spg_upsample_bilinear": "ipp" "iiiiiiiip",
+    "spg_upsample_bilinear_bwd": "ipp" "iiiiiiiiip",
+    "spg_se_fc": "ppppp" "iiip",
+    "spg_se_fc_bwd": "ppppppppp" "iiip",
+    "spg_chan_scale": "ippp" "ilip",
+    "spg_chan_scale_bwd": "ipppp" "ilip",
+    "spg_dwconv3x3": "ippp" "iiiiiip",
+    "spg_dwconv3x3_wgrad": "ippp" "iiiiip",
+    "spg_easpp_fuse": "ippppppp" "ilip",
+    "spg_easpp_fuse_bwd": "ipppppppppppp" "p" "ilip",
+    "spg_head1x1": "ipppp" "lip",
+    "spg_head1x1_bwd": "ipppppp" "liip",
+}
+_OPTIONAL = {
+    "spg_loss_weight_map": "ppp" "iifp",
+    "spg_loss_scale": "ipppppp" "iiiiffffip",
+    "spg_loss_finalize": "pp" "ifffffffp",
+    "spg_sumsq": "pp" "lp",
+    "spg_adamw": "ppppppp" "fffffilp",
+}
+_CT = {"p": _P, "i": _I, "l": _L, "f": _F}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads the shared library once; raises if it is absent (build with `python spegnet_amd/build.py`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the SPEGNet HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (needs hipcc). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.spg_last_error.restype = ctypes.c_char_p
+    lib.spg_version.restype = _I
+    for table, required in ((SIGNATURES, True), (_OPTIONAL, False)):
+        for name, sig in table.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                if required:
+                    raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild the extension")
+                continue
+            fn.restype = _I
+            fn.argtypes = [_CT[c] for c in sig]
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.spg_last_error().decode()}")

@@ -1,0 +1,566 @@
+// Windowed multi-head attention for the Hiera trunk on gfx950 MFMA (forward, dQ, dK/dV).
+//
+// Follows sam2 Hiera's MultiScaleAttention (reference call site models/feature_encoding.py:236; algorithm in
+// SURVEY.md §8 row E): the block's tokens are LayerNorm-ed, window-partitioned WITH zero padding, projected by
+// the qkv Linear, q optionally 2x2 max-pooled, softmax(q k^T / sqrt(hd)) v per window.  Here nothing is
+// partitioned or padded in memory: a workgroup enumerates the VALID tokens of its window's rectangle straight
+// from the [B,H,W,3,heads,hd] projection output; the padded slots of the reference (whose k and v equal the
+// qkv bias because LN output is zero there) become ONE virtual key of multiplicity n_pad, i.e. an additive
+// log(n_pad) on its score.  Masked tile slots get -1e30.  This is the same sum, re-ordered.
+//
+// One tile engine serves the three kernels.  A wave keeps 16 "stationary" rows (queries, or keys in the dK/dV
+// kernel) as MFMA B operands in registers; tiles of 64 "streamed" tokens sit in LDS as a row image [token][d]
+// (A operand of the score-type products) and as a transposed image [d][token] (A operand of the products that
+// sum over tokens).  Scores are computed transposed (streamed token on the accumulator row, stationary row on
+// the lane) so the softmax is lane-local and P / dS feed the next MFMA from registers with a permuted k order
+// (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
+#include <type_traits>
+#include "common.h"
+
+namespace spg {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr int AT = 256;  // threads
+
+struct AttnP {
+  const void* qkv; const void* qp; const void* bias;  // T
+  void* out; float* lse;
+  const void* dout; void* dqkv; void* dqp; float* dbias; float* delta;
+  int B, H, W, heads, ws, nwy, nwx, Hq, Wq, wsq, C;
+  float scale;
+};
+
+struct Win {
+  int b, y0, x0, hv, wv, nvalid, npad, y0q, x0q, wvq, nq;
+};
+
+__device__ __forceinline__ Win get_win(const AttnP& p, int widx) {
+  Win w;
+  const int per = p.nwy * p.nwx;
+  w.b = widx / per;
+  const int r = widx - w.b * per;
+  const int wy = r / p.nwx, wx = r - wy * p.nwx;
+  w.y0 = wy * p.ws; w.x0 = wx * p.ws;
+  w.hv = min(p.ws, p.H - w.y0); w.wv = min(p.ws, p.W - w.x0);
+  w.nvalid = w.hv * w.wv;
+  w.npad = p.ws * p.ws - w.nvalid;
+  if (p.qp) {
+    w.y0q = wy * p.wsq; w.x0q = wx * p.wsq;
+    w.wvq = w.wv >> 1;
+    w.nq = (w.hv >> 1) * w.wvq;
+  } else {
+    w.y0q = w.y0; w.x0q = w.x0; w.wvq = w.wv; w.nq = w.nvalid;
+  }
+  return w;
+}
+// global row index (into [B,H,W]) of key token c (< nvalid) / (into [B,Hq,Wq]) of query token i (< nq)
+__device__ __forceinline__ long key_row(const AttnP& p, const Win& w, int c) {
+  const int ly = c / w.wv, lx = c - ly * w.wv;
+  return ((long)w.b * p.H + w.y0 + ly) * p.W + w.x0 + lx;
+}
+__device__ __forceinline__ long q_row(const AttnP& p, const Win& w, int i) {
+  const int ly = i / w.wvq, lx = i - ly * w.wvq;
+  return ((long)w.b * p.Hq + w.y0q + ly) * p.Wq + w.x0q + lx;
+}
+
+template <typename T, int HD> struct AC {  // attention constants
+  static constexpr int VEC = ST<T>::VEC;
+  static constexpr int NCH = HD / VEC;                               // 16-byte chunks per head row
+  static constexpr int DB = (HD + 15) / 16;                          // 16-row d blocks
+  static constexpr int KS = sizeof(T) == 2 ? (HD + 31) / 32 : HD / 4;  // k-steps over d
+  static constexpr int DROW = sizeof(T) == 2 ? KS * 32 : HD;         // padded d per row image row
+  static constexpr int RS = DROW * (int)sizeof(T) + 16;              // row image stride (bytes)
+  static constexpr int TS = 64 * (int)sizeof(T) + 16;                // transposed image stride (bytes)
+  static constexpr int ROW_BYTES = 64 * RS;
+  static constexpr int TR_BYTES = DB * 16 * TS;
+  using Frag = typename std::conditional<sizeof(T) == 2, bf16x8_t, float>::type;
+};
+
+// ---- fragments ------------------------------------------------------------------------------------
+// B operand of a score-type product, straight from global: row pointer (or null), k-step s.
+template <typename T, int HD>
+__device__ __forceinline__ typename AC<T, HD>::Frag load_row_frag_global(const T* row, int s, int q) {
+  if constexpr (sizeof(T) == 2) {
+    const int ch = 4 * s + q;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row && ch < AC<T, HD>::NCH) v = ld16(row + ch * 8);
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    return row ? row[4 * s + q] : 0.f;
+  }
+}
+// A operand of a score-type product from a row image: token row `r`, k-step s.
+template <typename T, int HD>
+__device__ __forceinline__ typename AC<T, HD>::Frag load_row_frag_lds(const char* img, int r, int s, int q) {
+  if constexpr (sizeof(T) == 2) {
+    return *reinterpret_cast<const bf16x8_t*>(img + r * AC<T, HD>::RS + (32 * s + 8 * q) * 2);
+  } else {
+    return *reinterpret_cast<const float*>(img + r * AC<T, HD>::RS + (4 * s + q) * 4);
+  }
+}
+
+template <typename T> struct MM;
+template <> struct MM<bf16_t> {
+  __device__ static __forceinline__ f32x4 mma(bf16x8_t a, bf16x8_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MM<float> {
+  __device__ static __forceinline__ f32x4 mma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// acc[db] += Timg[d = 16db + lane&15][token] * vals[token][col = lane&15] summed over the 64 tile tokens,
+// vals given as accumulator-layout registers pv[nb][r] (token = 16nb + 4q + r).
+template <typename T, int HD>
+__device__ __forceinline__ void mma_over_tokens(const char* timg, const float (&pv)[4][4], int lane,
+                                                f32x4 (&acc)[AC<T, HD>::DB]) {
+  constexpr int DB = AC<T, HD>::DB, TS = AC<T, HD>::TS;
+  const int r15 = lane & 15, q = lane >> 4;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 b = {pack2bf(pv[2 * s][0], pv[2 * s][1]), pack2bf(pv[2 * s][2], pv[2 * s][3]),
+                 pack2bf(pv[2 * s + 1][0], pv[2 * s + 1][1]), pack2bf(pv[2 * s + 1][2], pv[2 * s + 1][3])};
+      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const char* row = timg + (db * 16 + r15) * TS + (32 * s + 4 * q) * 2;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(row);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(row + 32);
+        u32x4 a = {lo.x, lo.y, hi.x, hi.y};
+        acc[db] = MM<T>::mma(__builtin_bit_cast(bf16x8_t, a), bf, acc[db]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const float a = *reinterpret_cast<const float*>(timg + (db * 16 + r15) * TS + (16 * nb + 4 * q + r) * 4);
+          acc[db] = MM<T>::mma(a, pv[nb][r], acc[db]);
+        }
+  }
+}
+
+// score-type product for the whole tile: acc[nb] = sum_d Rimg[token 16nb + lane&15][d] * frag[d][col]
+template <typename T, int HD>
+__device__ __forceinline__ void mma_scores(const char* rimg, const typename AC<T, HD>::Frag (&bf)[AC<T, HD>::KS], int lane,
+                                           f32x4 (&acc)[4]) {
+  const int r15 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < AC<T, HD>::KS; ++s)
+      acc[nb] = MM<T>::mma(load_row_frag_lds<T, HD>(rimg, nb * 16 + r15, s, q), bf[s], acc[nb]);
+  }
+}
+
+// ---- staging: 64 token rows (pointers in LDS, null = zero row) -> row image and/or transposed image ----------
+template <typename T, int HD, bool ROW, bool TR>
+__device__ __forceinline__ void stage_tile(const T* const* ptrs, int off, char* rimg, char* timg) {
+  constexpr int VEC = AC<T, HD>::VEC, NCH = AC<T, HD>::NCH, RS = AC<T, HD>::RS, TS = AC<T, HD>::TS;
+  for (int p = threadIdx.x; p < 16 * NCH; p += AT) {
+    const int ch = p % NCH, g = p / NCH;
+    u32x4 rows[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T* s = ptrs[4 * g + i];
+      rows[i] = s ? ld16(s + off + ch * VEC) : u32x4{0u, 0u, 0u, 0u};
+    }
+    if constexpr (ROW) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(rimg + (4 * g + i) * RS + ch * 16) = rows[i];
+    }
+    if constexpr (TR) {
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          unsigned e[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned word = rows[i][j >> 1];
+            e[i] = (j & 1) ? (word >> 16) : (word & 0xffffu);
+          }
+          *reinterpret_cast<u32x2*>(timg + (ch * 8 + j) * TS + g * 8) = u32x2{e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<u32x4*>(timg + (ch * 4 + j) * TS + g * 16) = u32x4{rows[0][j], rows[1][j], rows[2][j], rows[3][j]};
+      }
+    }
+  }
+}
+
+// zero the parts of the images staging never writes (pad d columns / pad d rows)
+template <typename T, int HD>
+__device__ __forceinline__ void zero_images(char* base, int bytes) {
+  for (int i = threadIdx.x * 16; i < bytes; i += AT * 16) *reinterpret_cast<u32x4*>(base + i) = u32x4{0u, 0u, 0u, 0u};
+}
+
+// store accumulators acc[db] (rows d = 16db + 4q + r, col = lane&15) * mul into dst row (4 consecutive d per reg group)
+template <typename T, int HD>
+__device__ __forceinline__ void store_rows_T(T* row, const f32x4 (&acc)[AC<T, HD>::DB], float mul, int lane) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int db = 0; db < AC<T, HD>::DB; ++db) {
+    const int d = db * 16 + q * 4;
+    if (d < HD) {
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<u32x2*>(row + d) = u32x2{pack2bf(acc[db][0] * mul, acc[db][1] * mul), pack2bf(acc[db][2] * mul, acc[db][3] * mul)};
+      } else {
+        *reinterpret_cast<f32x4*>(row + d) = acc[db] * mul;
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+template <typename T, int HD>
+__global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
+  using A = AC<T, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kimg = smem;
+  char* vtimg = kimg + A::ROW_BYTES;
+  const T** kptr = reinterpret_cast<const T**>(vtimg + A::TR_BYTES);
+  float* kb = reinterpret_cast<float*>(kptr + 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
+  const int head = blockIdx.y;
+  const Win w = get_win(p, blockIdx.z);
+  const int qi = blockIdx.x * 64 + wave * 16 + r15;
+  if (blockIdx.x * 64 >= w.nq) return;  // uniform
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* qp = reinterpret_cast<const T*>(p.qp);
+  const bool qvalid = qi < w.nq;
+  const long qrow = q_row(p, w, qvalid ? qi : 0);
+  const T* qptr = qp ? qp + qrow * p.C + head * HD : qkv + qrow * 3 * p.C + head * HD;
+
+  zero_images<T, HD>(smem, A::ROW_BYTES + A::TR_BYTES);
+  typename A::Frag qf[A::KS];
+#pragma unroll
+  for (int s = 0; s < A::KS; ++s) qf[s] = load_row_frag_global<T, HD>(qptr, s, q);
+
+  f32x4 o[A::DB];
+#pragma unroll
+  for (int db = 0; db < A::DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = NEG_BIG, l = 0.f;
+  const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
+  const int ntiles = (nkeys + 63) >> 6;
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();  // previous tile's readers done (also covers zero_images)
+    if (tid < 64) {
+      const int c = t * 64 + tid;
+      const T* kp = nullptr;
+      float b = NEG_BIG;
+      if (c < w.nvalid) { kp = qkv + key_row(p, w, c) * 3 * p.C + p.C + head * HD; b = 0.f; }
+      else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; b = __logf((float)w.npad); }
+      kptr[tid] = kp; kb[tid] = b;
+    }
+    __syncthreads();
+    stage_tile<T, HD, true, false>(kptr, 0, kimg, nullptr);
+    stage_tile<T, HD, false, true>(kptr, p.C, nullptr, vtimg);
+    __syncthreads();
+    f32x4 sacc[4];
+    mma_scores<T, HD>(kimg, qf, lane, sacc);
+    float pv[4][4];
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + nb * 16 + q * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pv[nb][r] = sacc[nb][r] * p.scale + b4[r]; mx = fmaxf(mx, pv[nb][r]); }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pv[nb][r] = __expf(pv[nb][r] - mn); ps += pv[nb][r]; }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int db = 0; db < A::DB; ++db) o[db] *= alpha;
+    mma_over_tokens<T, HD>(vtimg, pv, lane, o);
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (qvalid) {
+    T* orow = reinterpret_cast<T*>(p.out) + qrow * p.C + head * HD;
+    store_rows_T<T, HD>(orow, o, 1.f / l, lane);
+    if (q == 0) p.lse[qrow * p.heads + head] = m + __logf(l);
+  }
+}
+
+// =====================================================================================================
+// backward, query side: dQ (+ delta = rowsum(dO*O) written for the dK/dV kernel)
+// =====================================================================================================
+template <typename T, int HD>
+__global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
+  using A = AC<T, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kimg = smem;
+  char* vimg = kimg + A::ROW_BYTES;
+  char* ktimg = vimg + A::ROW_BYTES;
+  const T** kptr = reinterpret_cast<const T**>(ktimg + A::TR_BYTES);
+  float* kb = reinterpret_cast<float*>(kptr + 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
+  const int head = blockIdx.y;
+  const Win w = get_win(p, blockIdx.z);
+  if (blockIdx.x * 64 >= w.nq) return;
+  const int qi = blockIdx.x * 64 + wave * 16 + r15;
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* qp = reinterpret_cast<const T*>(p.qp);
+  const bool qvalid = qi < w.nq;
+  const long qrow = q_row(p, w, qvalid ? qi : 0);
+  const T* qptr = qp ? qp + qrow * p.C + head * HD : qkv + qrow * 3 * p.C + head * HD;
+  const T* doptr = reinterpret_cast<const T*>(p.dout) + qrow * p.C + head * HD;
+  const T* optr = reinterpret_cast<const T*>(p.out) + qrow * p.C + head * HD;
+
+  zero_images<T, HD>(smem, 2 * A::ROW_BYTES + A::TR_BYTES);
+  typename A::Frag qf[A::KS], dof[A::KS];
+#pragma unroll
+  for (int s = 0; s < A::KS; ++s) {
+    qf[s] = load_row_frag_global<T, HD>(qptr, s, q);
+    dof[s] = load_row_frag_global<T, HD>(doptr, s, q);
+  }
+  // delta: each of the 4 lanes sharing a row sums a quarter of d
+  float delta = 0.f;
+  for (int d = q; d < HD; d += 4) delta += ST<T>::ld(doptr + d) * ST<T>::ld(optr + d);
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+  const float lse = qvalid ? p.lse[qrow * p.heads + head] : 0.f;
+  if (qvalid && q == 0) p.delta[qrow * p.heads + head] = delta;
+
+  f32x4 dq[A::DB];
+#pragma unroll
+  for (int db = 0; db < A::DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
+  const int ntiles = (nkeys + 63) >> 6;
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+    if (tid < 64) {
+      const int c = t * 64 + tid;
+      const T* kp = nullptr;
+      float b = NEG_BIG;
+      if (c < w.nvalid) { kp = qkv + key_row(p, w, c) * 3 * p.C + p.C + head * HD; b = 0.f; }
+      else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; b = __logf((float)w.npad); }
+      kptr[tid] = kp; kb[tid] = b;
+    }
+    __syncthreads();
+    stage_tile<T, HD, true, true>(kptr, 0, kimg, ktimg);
+    stage_tile<T, HD, true, false>(kptr, p.C, vimg, nullptr);
+    __syncthreads();
+    f32x4 sacc[4], pacc[4];
+    mma_scores<T, HD>(kimg, qf, lane, sacc);
+    mma_scores<T, HD>(vimg, dof, lane, pacc);
+    float ds[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + nb * 16 + q * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = __expf(sacc[nb][r] * p.scale + b4[r] - lse);
+        ds[nb][r] = pr * (pacc[nb][r] - delta);
+      }
+    }
+    mma_over_tokens<T, HD>(ktimg, ds, lane, dq);
+  }
+  if (qvalid) {
+    T* dst = p.qp ? reinterpret_cast<T*>(p.dqp) + qrow * p.C + head * HD
+                  : reinterpret_cast<T*>(p.dqkv) + qrow * 3 * p.C + head * HD;
+    store_rows_T<T, HD>(dst, dq, p.scale, lane);
+  }
+}
+
+// =====================================================================================================
+// backward, key side: dK, dV (keys stationary, queries streamed)
+// =====================================================================================================
+template <typename T, int HD>
+__global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
+  using A = AC<T, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qimg = smem;
+  char* doimg = qimg + A::ROW_BYTES;
+  char* qtimg = doimg + A::ROW_BYTES;
+  char* dotimg = qtimg + A::TR_BYTES;
+  const T** qptrs = reinterpret_cast<const T**>(dotimg + A::TR_BYTES);
+  const T** doptrs = qptrs + 64;
+  float* lse_s = reinterpret_cast<float*>(doptrs + 64);
+  float* delta_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
+  const int head = blockIdx.y;
+  const Win w = get_win(p, blockIdx.z);
+  const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
+  if (blockIdx.x * 64 >= nkeys) return;
+  const int c = blockIdx.x * 64 + wave * 16 + r15;  // this lane's key
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* qp = reinterpret_cast<const T*>(p.qp);
+  const T* kp = nullptr;
+  float kbias = NEG_BIG;
+  long krow = 0;
+  if (c < w.nvalid) { krow = key_row(p, w, c); kp = qkv + krow * 3 * p.C + p.C + head * HD; kbias = 0.f; }
+  else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; kbias = __logf((float)w.npad); }
+
+  zero_images<T, HD>(smem, 2 * A::ROW_BYTES + 2 * A::TR_BYTES);
+  typename A::Frag kf[A::KS], vf[A::KS];
+#pragma unroll
+  for (int s = 0; s < A::KS; ++s) {
+    kf[s] = load_row_frag_global<T, HD>(kp, s, q);
+    vf[s] = load_row_frag_global<T, HD>(kp ? kp + p.C : nullptr, s, q);
+  }
+  f32x4 dk[A::DB], dv[A::DB];
+#pragma unroll
+  for (int db = 0; db < A::DB; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int ntiles = (w.nq + 63) >> 6;
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+    if (tid < 64) {
+      const int i = t * 64 + tid;
+      const T* a = nullptr; const T* b = nullptr;
+      float ls = 1.0e30f, dl = 0.f;
+      if (i < w.nq) {
+        const long row = q_row(p, w, i);
+        a = qp ? qp + row * p.C + head * HD : qkv + row * 3 * p.C + head * HD;
+        b = reinterpret_cast<const T*>(p.dout) + row * p.C + head * HD;
+        ls = p.lse[row * p.heads + head];
+        dl = p.delta[row * p.heads + head];
+      }
+      qptrs[tid] = a; doptrs[tid] = b; lse_s[tid] = ls; delta_s[tid] = dl;
+    }
+    __syncthreads();
+    stage_tile<T, HD, true, true>(qptrs, 0, qimg, qtimg);
+    stage_tile<T, HD, true, true>(doptrs, 0, doimg, dotimg);
+    __syncthreads();
+    f32x4 sacc[4], pacc[4];
+    mma_scores<T, HD>(qimg, kf, lane, sacc);   // S[i][key]
+    mma_scores<T, HD>(doimg, vf, lane, pacc);  // dP[i][key]
+    float pr[4][4], ds[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + nb * 16 + q * 4);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + nb * 16 + q * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[nb][r] = __expf(sacc[nb][r] * p.scale + kbias - l4[r]);
+        ds[nb][r] = pr[nb][r] * (pacc[nb][r] - d4[r]);
+      }
+    }
+    mma_over_tokens<T, HD>(dotimg, pr, lane, dv);
+    mma_over_tokens<T, HD>(qtimg, ds, lane, dk);
+  }
+  if (c < w.nvalid) {
+    T* dst = reinterpret_cast<T*>(p.dqkv) + krow * 3 * p.C + p.C + head * HD;
+    store_rows_T<T, HD>(dst, dk, p.scale, lane);
+    store_rows_T<T, HD>(dst + p.C, dv, 1.f, lane);
+  } else if (c == w.nvalid && w.npad > 0) {
+    float* db_ = p.dbias + p.C + head * HD;
+#pragma unroll
+    for (int db = 0; db < A::DB; ++db) {
+      const int d = db * 16 + q * 4;
+      if (d < HD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(db_ + d + r, dk[db][r] * p.scale);
+          atomicAdd(db_ + p.C + d + r, dv[db][r]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int HD>
+static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
+  using A = AC<T, HD>;
+  const int nwin = p.B * p.nwy * p.nwx;
+  if (which == 0) {
+    const size_t lds = A::ROW_BYTES + A::TR_BYTES + 64 * 8 + 64 * 4;
+    hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
+    return check_launch("attn_fwd");
+  }
+  {
+    const size_t lds = 2 * A::ROW_BYTES + A::TR_BYTES + 64 * 8 + 64 * 4;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
+    int rc = check_launch("attn_bwd_dq");
+    if (rc) return rc;
+  }
+  {
+    const size_t lds = 2 * A::ROW_BYTES + 2 * A::TR_BYTES + 2 * 64 * 8 + 2 * 64 * 4;
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3(cdiv(maxk, 64), p.heads, nwin), dim3(AT), lds, s, p);
+    return check_launch("attn_bwd_dkv");
+  }
+}
+
+static int fill_geom(AttnP& p, int B, int H, int W, int heads, int hd, int ws, bool pooled, int* maxq, int* maxk) {
+  p.B = B; p.H = H; p.W = W; p.heads = heads; p.C = heads * hd;
+  if (ws <= 0) ws = H > W ? H : W;
+  p.ws = ws; p.nwy = cdiv(H, ws); p.nwx = cdiv(W, ws);
+  if (pooled) {
+    if ((H | W | ws) & 1) { set_error("attn: pooled queries need even H, W, window (H=%d W=%d ws=%d)", H, W, ws); return SPG_ERR_BAD_ARG; }
+    p.Hq = H / 2; p.Wq = W / 2; p.wsq = ws / 2;
+  } else { p.Hq = H; p.Wq = W; p.wsq = ws; }
+  p.scale = 1.0f / sqrtf((float)hd);
+  const int hv = ws < H ? ws : H, wv = ws < W ? ws : W;
+  *maxk = hv * wv + 1;
+  *maxq = pooled ? (hv / 2) * (wv / 2) : hv * wv;
+  return SPG_OK;
+}
+
+template <typename T>
+static int dispatch_hd(int which, AttnP p, int hd, int maxq, int maxk, hipStream_t s) {
+  switch (hd) {
+    case 72: return launch_attn<T, 72>(which, p, maxq, maxk, s);
+    case 16: return launch_attn<T, 16>(which, p, maxq, maxk, s);
+    case 32: return launch_attn<T, 32>(which, p, maxq, maxk, s);
+    default: set_error("attn: unsupported head_dim %d (built: 16, 32, 72)", hd); return SPG_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace spg
+
+using namespace spg;
+
+extern "C" int spg_attn_fwd(int dtype, const void* qkv, const void* q_pooled, const void* qkv_bias_t, void* out,
+                            float* lse, int B, int H, int W, int heads, int hd, int ws, spg_stream_t stream) {
+  SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "attn_fwd: bad dtype");
+  SPG_REQUIRE(B > 0 && H > 0 && W > 0 && heads > 0, "attn_fwd: empty problem");
+  AttnP p{};
+  p.qkv = qkv; p.qp = q_pooled; p.bias = qkv_bias_t; p.out = out; p.lse = lse;
+  int maxq, maxk;
+  int rc = fill_geom(p, B, H, W, heads, hd, ws, q_pooled != nullptr, &maxq, &maxk);
+  if (rc) return rc;
+  return dtype == SPG_BF16 ? dispatch_hd<bf16_t>(0, p, hd, maxq, maxk, (hipStream_t)stream)
+                           : dispatch_hd<float>(0, p, hd, maxq, maxk, (hipStream_t)stream);
+}
+
+extern "C" int spg_attn_bwd(int dtype, const void* qkv, const void* q_pooled, const void* qkv_bias_t, const void* out,
+                            const void* dout, const float* lse, void* dqkv, void* dq_pooled, float* dbias_pad,
+                            float* delta_ws, int B, int H, int W, int heads, int hd, int ws, spg_stream_t stream) {
+  SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "attn_bwd: bad dtype");
+  SPG_REQUIRE(B > 0 && H > 0 && W > 0 && heads > 0, "attn_bwd: empty problem");
+  SPG_REQUIRE((q_pooled == nullptr) == (dq_pooled == nullptr), "attn_bwd: q_pooled and dq_pooled must both be given or both be null");
+  AttnP p{};
+  p.qkv = qkv; p.qp = q_pooled; p.bias = qkv_bias_t; p.out = const_cast<void*>(out); p.lse = const_cast<float*>(lse);
+  p.dout = dout; p.dqkv = dqkv; p.dqp = dq_pooled; p.dbias = dbias_pad; p.delta = delta_ws;
+  int maxq, maxk;
+  int rc = fill_geom(p, B, H, W, heads, hd, ws, q_pooled != nullptr, &maxq, &maxk);
+  if (rc) return rc;
+  return dtype == SPG_BF16 ? dispatch_hd<bf16_t>(1, p, hd, maxq, maxk, (hipStream_t)stream)
+                           : dispatch_hd<float>(1, p, hd, maxq, maxk, (hipStream_t)stream);
+}

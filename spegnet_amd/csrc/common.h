@@ -1,0 +1,111 @@
+// Shared device/host helpers for the SPEGNet gfx950 kernels.
+// Storage type T is float (parity path, exact-f32 MFMA) or bf16 (fast path, bf16 MFMA, f32 accumulate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/spegnet_hip.h"
+
+namespace spg {
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int WAVE = 64;
+
+// ---- error plumbing (no exceptions across the C ABI) -------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+#define SPG_REQUIRE(cond, ...)                    \
+  do {                                            \
+    if (!(cond)) {                                \
+      spg::set_error(__VA_ARGS__);                \
+      return SPG_ERR_BAD_ARG;                     \
+    }                                             \
+  } while (0)
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, keeps NaN a NaN
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+template <typename T> struct ST;  // storage traits
+template <> struct ST<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ST<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte chunk <-> floats
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& c, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4& c, float* f) {
+  f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y); f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4& c, float* f) {
+  f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
+  f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
+  f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
+  f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* f);
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* f) {
+  u32x4 c; c.x = __float_as_uint(f[0]); c.y = __float_as_uint(f[1]); c.z = __float_as_uint(f[2]); c.w = __float_as_uint(f[3]);
+  return c;
+}
+template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
+  u32x4 c; c.x = pack2bf(f[0], f[1]); c.y = pack2bf(f[2], f[3]); c.z = pack2bf(f[4], f[5]); c.w = pack2bf(f[6], f[7]);
+  return c;
+}
+template <typename T> __device__ __forceinline__ u32x4 ld16(const T* p) { return *reinterpret_cast<const u32x4*>(p); }
+template <typename T> __device__ __forceinline__ void st16(T* p, const u32x4& c) { *reinterpret_cast<u32x4*>(p) = c; }
+
+// ---- wave / block reductions ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over a block of NT threads; result valid in every thread. smem: >= NT/64 floats
+template <int NT> __device__ __forceinline__ float block_sum(float v, float* smem) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) r += smem[i];
+  return r;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace spg

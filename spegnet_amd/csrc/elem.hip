@@ -1,0 +1,705 @@
+// HBM-bound element / gather kernels of the SPEGNet path (NHWC, 16-byte vectors over channels):
+// bilinear upsample (+concat placement) and its adjoint, 2x2 max-pool with argmax, patch-embed im2col,
+// SE excitation, dilated depth-wise 3x3, e-ASPP grouped fusion, 1x1 prediction heads, small utilities.
+#include "common.h"
+
+namespace spg {
+
+static inline int ew_grid(long n_items) {
+  long g = (n_items + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// PyTorch bilinear, align_corners=False: src = max(0,(dst+0.5)*in/out-0.5); i0=floor; i1=min(i0+1,in-1)
+__device__ __forceinline__ void bil_src(int dst, int in, int out, int& i0, int& i1, float& lam) {
+  float src = ((float)dst + 0.5f) * ((float)in / (float)out) - 0.5f;
+  src = fmaxf(src, 0.f);
+  i0 = min((int)src, in - 1);
+  i1 = min(i0 + 1, in - 1);
+  lam = src - (float)i0;
+}
+
+// y[b,Y,X,c0+c] = bilinear(x[b,:,:,c])  (y rows have ldy channels)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int h, int w,
+                                                       int C, int H, int W, int ldy, int c0) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const long total = (long)B * H * W * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    long p = i / nch;
+    const int X = (int)(p % W); p /= W;
+    const int Y = (int)(p % H);
+    const int b = (int)(p / H);
+    int y0, y1, x0, x1; float ly, lx;
+    bil_src(Y, h, H, y0, y1, ly);
+    bil_src(X, w, W, x0, x1, lx);
+    const T* base = x + (long)b * h * w * C + ch * VEC;
+    float a[VEC], bb[VEC], c[VEC], d[VEC], o[VEC];
+    unpack16<T>(ld16(base + ((long)y0 * w + x0) * C), a);
+    unpack16<T>(ld16(base + ((long)y0 * w + x1) * C), bb);
+    unpack16<T>(ld16(base + ((long)y1 * w + x0) * C), c);
+    unpack16<T>(ld16(base + ((long)y1 * w + x1) * C), d);
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = w00 * a[e] + w01 * bb[e] + w10 * c[e] + w11 * d[e];
+    st16(y + (((long)b * H + Y) * W + X) * ldy + c0 + ch * VEC, pack16<T>(o));
+  }
+}
+
+// adjoint as a gather: dx[b,y,x,c] (+)= sum over output pixels whose taps hit (y,x)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int h,
+                                                           int w, int C, int H, int W, int ldy, int c0, int accumulate) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const long total = (long)B * h * w * nch;
+  const int sy = (H + h - 1) / h, sx = (W + w - 1) / w;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    long p = i / nch;
+    const int xx = (int)(p % w); p /= w;
+    const int yy = (int)(p % h);
+    const int b = (int)(p / h);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    const int Y0 = max(0, (yy - 1) * sy), Y1 = min(H - 1, (yy + 2) * sy);
+    const int X0 = max(0, (xx - 1) * sx), X1 = min(W - 1, (xx + 2) * sx);
+    for (int Y = Y0; Y <= Y1; ++Y) {
+      int y0, y1; float ly;
+      bil_src(Y, h, H, y0, y1, ly);
+      const float wy = (y0 == yy ? 1.f - ly : 0.f) + (y1 == yy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int X = X0; X <= X1; ++X) {
+        int x0, x1; float lx;
+        bil_src(X, w, W, x0, x1, lx);
+        const float wx = (x0 == xx ? 1.f - lx : 0.f) + (x1 == xx ? lx : 0.f);
+        if (wx == 0.f) continue;
+        float v[VEC];
+        unpack16<T>(ld16(dy + (((long)b * H + Y) * W + X) * ldy + c0 + ch * VEC), v);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += wgt * v[e];
+      }
+    }
+    T* dst = dx + i * VEC;
+    if (accumulate) {
+      float o[VEC];
+      unpack16<T>(ld16(dst), o);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += o[e];
+    }
+    st16(dst, pack16<T>(acc));
+  }
+}
+
+// y[m][cy0 + c] (+)= x[m][cx0 + c]
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const T* __restrict__ x, T* __restrict__ y, long M, int C,
+                                                            int ldx, int cx0, int ldy, int cy0, int accumulate) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const long total = M * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    const long m = i / nch;
+    u32x4 v = ld16(x + m * ldx + cx0 + ch * VEC);
+    T* dst = y + m * ldy + cy0 + ch * VEC;
+    if (accumulate) {
+      float a[VEC], b[VEC];
+      unpack16<T>(v, a);
+      unpack16<T>(ld16(dst), b);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) a[e] += b[e];
+      v = pack16<T>(a);
+    }
+    st16(dst, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long nvec) {
+  constexpr int VEC = ST<T>::VEC;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    float x[VEC], y[VEC];
+    unpack16<T>(ld16(a + i * VEC), x);
+    unpack16<T>(ld16(b + i * VEC), y);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) x[e] += y[e];
+    st16(o + i * VEC, pack16<T>(x));
+  }
+}
+
+// f32 <-> T conversions (n multiple of 8)
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ f, bf16_t* __restrict__ h, long n8, int to_f32) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    if (to_f32) {
+      float v[8];
+      unpack16<bf16_t>(ld16(h + i * 8), v);
+      float* dst = const_cast<float*>(f) + i * 8;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(f + i * 8), b = *reinterpret_cast<const f32x4*>(f + i * 8 + 4);
+      float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      st16(h + i * 8, pack16<bf16_t>(v));
+    }
+  }
+}
+
+// 2x2 max pool over a channel window of an NHWC tensor; first max wins ties (torch semantics)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                           int B, int H, int W, int C, int ldc, int c0) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * Ho * Wo * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int X = (int)(p % Wo); p /= Wo;
+    const int Y = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const T* base = x + (((long)b * H + 2 * Y) * W + 2 * X) * ldc + c0 + c;
+    float best = ST<T>::ld(base);
+    int bi = 0;
+    const float v1 = ST<T>::ld(base + ldc), v2 = ST<T>::ld(base + (long)W * ldc), v3 = ST<T>::ld(base + (long)(W + 1) * ldc);
+    if (v1 > best) { best = v1; bi = 1; }
+    if (v2 > best) { best = v2; bi = 2; }
+    if (v3 > best) { best = v3; bi = 3; }
+    ST<T>::st(y + i, best);
+    idx[i] = (uint8_t)bi;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                           T* __restrict__ dx, int B, int H, int W, int C, int ldc, int c0) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * H * W * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int X = (int)(p % W); p /= W;
+    const int Y = (int)(p % H);
+    const int b = (int)(p / H);
+    const long o = (((long)b * Ho + (Y >> 1)) * Wo + (X >> 1)) * C + c;
+    const int me = ((Y & 1) << 1) | (X & 1);
+    const float v = (idx[o] == me) ? ST<T>::ld(dy + o) : 0.f;
+    ST<T>::st(dx + (((long)b * H + Y) * W + X) * ldc + c0 + c, v);
+  }
+}
+
+// patch-embed im2col: img f32 NCHW [B,3,S,S] -> cols T [B*(S/4)^2][Kpad], k = c*49 + ky*7 + kx (conv 7x7 s4 p3)
+template <typename T>
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int S, int Kpad) {
+  const int So = S / 4;
+  const long total = (long)B * So * So * Kpad;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % Kpad);
+    long p = i / Kpad;
+    const int ox = (int)(p % So); p /= So;
+    const int oy = (int)(p % So);
+    const int b = (int)(p / So);
+    float v = 0.f;
+    if (k < 147) {
+      const int c = k / 49, r = k - c * 49, ky = r / 7, kx = r - ky * 7;
+      const int iy = oy * 4 + ky - 3, ix = ox * 4 + kx - 3;
+      if ((unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S) v = img[(((long)b * 3 + c) * S + iy) * S + ix];
+    }
+    ST<T>::st(cols + i, v);
+  }
+}
+
+// ---- SE excitation (per image): hidden = relu(W1 gap), scale = sigmoid(W2 hidden) ---------------------------
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
+                                                    const float* __restrict__ w2, float* __restrict__ hidden,
+                                                    float* __restrict__ scale, int C, int R) {
+  extern __shared__ float sm[];  // gap[C] + hidden[R]
+  const int b = blockIdx.x;
+  float* g = sm; float* h = sm + C;
+  for (int c = threadIdx.x; c < C; c += 256) g[c] = gap[(long)b * C + c];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < R; r += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w1[(long)r * C + c] * g[c];
+    s = wave_sum(s);
+    if (lane == 0) { h[r] = fmaxf(s, 0.f); hidden[(long)b * R + r] = h[r]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += w2[(long)c * R + r] * h[r];
+    scale[(long)b * C + c] = sigmoid_f(s);
+  }
+}
+// given dscale -> dgap, dw1 +=, dw2 +=
+__global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
+                                                        const float* __restrict__ w2, const float* __restrict__ hidden,
+                                                        const float* __restrict__ scale, const float* __restrict__ dscale,
+                                                        float* __restrict__ dgap, float* __restrict__ dw1,
+                                                        float* __restrict__ dw2, int C, int R) {
+  extern __shared__ float sm[];  // dz[C] + dh[R] + g[C]
+  const int b = blockIdx.x;
+  float* dz = sm; float* dh = sm + C; float* g = dh + R;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float s = scale[(long)b * C + c];
+    dz[c] = dscale[(long)b * C + c] * s * (1.f - s);
+    g[c] = gap[(long)b * C + c];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < R; r += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w2[(long)c * R + r] * dz[c];
+    s = wave_sum(s);
+    const float hr = hidden[(long)b * R + r];
+    if (lane == 0) dh[r] = hr > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+      s += w1[(long)r * C + c] * dh[r];
+      atomicAdd(dw2 + (long)c * R + r, dz[c] * hidden[(long)b * R + r]);
+      atomicAdd(dw1 + (long)r * C + c, dh[r] * g[c]);
+    }
+    dgap[(long)b * C + c] = s;
+  }
+}
+
+// y = x * scale[b][c]
+template <typename T>
+__global__ __launch_bounds__(256) void chan_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                         T* __restrict__ y, long HW, int C, long total) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    const long b = (i / nch) / HW;
+    float v[VEC];
+    unpack16<T>(ld16(x + i * VEC), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] *= scale[b * C + ch * VEC + e];
+    st16(y + i * VEC, pack16<T>(v));
+  }
+}
+// dx = dy*scale[b][c] + dgap_over_hw[b][c]
+template <typename T>
+__global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ scale,
+                                                             const float* __restrict__ dgap, T* __restrict__ dx, long HW,
+                                                             int C, long total, float inv_hw) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    const long b = (i / nch) / HW;
+    float v[VEC];
+    unpack16<T>(ld16(dy + i * VEC), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = v[e] * scale[b * C + ch * VEC + e] + dgap[b * C + ch * VEC + e] * inv_hw;
+    st16(dx + i * VEC, pack16<T>(v));
+  }
+}
+
+// ---- dilated depth-wise 3x3 (pad = dil), NHWC, weights f32 [C][9] ------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                     int B, int H, int W, int C, int dil, int flip) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const long total = (long)B * H * W * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    long p = i / nch;
+    const int X = (int)(p % W); p /= W;
+    const int Y = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = (t / 3 - 1) * dil, dx = (t % 3 - 1) * dil;
+      const int yy = Y + dy, xx = X + dx;
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+        float v[VEC];
+        unpack16<T>(ld16(x + (((long)b * H + yy) * W + xx) * C + ch * VEC), v);
+        const int tw = flip ? 8 - t : t;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += w[(ch * VEC + e) * 9 + tw] * v[e];
+      }
+    }
+    st16(y + i * VEC, pack16<T>(acc));
+  }
+}
+// dw[c][t] += sum_pixels dy[p][c] * x[p + t][c]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           float* __restrict__ dw, int B, int H, int W, int C, int dil,
+                                                           long pix_per_block) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const int ppar = 256 / nch;
+  const int ch = threadIdx.x % nch, pl = threadIdx.x / nch;
+  const long npix = (long)B * H * W;
+  const long p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+  float acc[9][VEC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+  if (pl < ppar) {
+    for (long p = p0 + pl; p < p1; p += ppar) {
+      const int X = (int)(p % W);
+      const int Y = (int)((p / W) % H);
+      float d[VEC];
+      unpack16<T>(ld16(dy + p * C + ch * VEC), d);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = Y + (t / 3 - 1) * dil, xx = X + (t % 3 - 1) * dil;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          float v[VEC];
+          unpack16<T>(ld16(x + (p + (long)(t / 3 - 1) * dil * W + (t % 3 - 1) * dil) * C + ch * VEC), v);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[t][e] += d[e] * v[e];
+        }
+      }
+    }
+  }
+  __shared__ float red[256 * 8];
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = acc[t][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f;
+      for (int r = 0; r < ppar; ++r) s += red[r * nch * VEC + c];
+      atomicAdd(dw + (long)c * 9 + t, s);
+    }
+  }
+}
+
+// ---- e-ASPP grouped 1x1 over the branch-major concat: y[p][g] = sum_j w[g][j] * cat[p][5g+j] --------------
+template <typename T>
+__device__ __forceinline__ float cat_at(const T* const* br, const float* glob, long b, long p, int C, int cc) {
+  const int which = cc / C, ch = cc - which * C;
+  return which < 4 ? ST<T>::ld(br[which] + p * C + ch) : glob[b * C + ch];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void easpp_fuse_kernel(const T* b0, const T* b1, const T* b2, const T* b3,
+                                                         const float* __restrict__ glob, const float* __restrict__ w,
+                                                         T* __restrict__ y, long HW, int C, long total) {
+  const T* br[4] = {b0, b1, b2, b3};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int g = (int)(i % C);
+    const long p = i / C;
+    const long b = p / HW;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s += w[g * 5 + j] * cat_at<T>(br, glob, b, p, C, 5 * g + j);
+    ST<T>::st(y + i, s);
+  }
+}
+// d(cat)[p][cc] = w[cc/5][cc%5] * dy[p][cc/5]  -> written to the four branch grads; global part reduced per image
+template <typename T>
+__global__ __launch_bounds__(256) void easpp_fuse_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                             T* d0, T* d1, T* d2, T* d3, long HW, int C, long total) {
+  T* d[4] = {d0, d1, d2, d3};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {  // over p * 4C
+    const int cc = (int)(i % (4 * C));
+    const long p = i / (4 * C);
+    const int g = cc / 5, j = cc - g * 5;
+    const int which = cc / C, ch = cc - which * C;
+    ST<T>::st(d[which] + p * C + ch, w[g * 5 + j] * ST<T>::ld(dy + p * C + g));
+  }
+}
+// per image: dglob[b][ch] = sum_p w[g][j]*dy[p][g] for cc = 4C+ch;   dw[g][j] += sum_p dy[p][g]*cat[p][5g+j]
+template <typename T>
+__global__ __launch_bounds__(256) void easpp_fuse_bwd_reduce_kernel(const T* __restrict__ dy, const T* b0, const T* b1,
+                                                                    const T* b2, const T* b3, const float* __restrict__ glob,
+                                                                    const float* __restrict__ w, float* __restrict__ dglob,
+                                                                    float* __restrict__ dw, long HW, int C, long rows_per_block) {
+  const T* br[4] = {b0, b1, b2, b3};
+  const long b = blockIdx.y;
+  const long r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+  // thread -> (g, j) pairs: 5*C of them; loop
+  for (int gj = threadIdx.x; gj < 5 * C; gj += 256) {
+    const int g = gj / 5, j = gj - g * 5, cc = gj;  // cc == 5g + j
+    float sw = 0.f, sd = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const long p = b * HW + r;
+      const float d = ST<T>::ld(dy + p * C + g);
+      sw += d * cat_at<T>(br, glob, b, p, C, cc);
+      sd += d;
+    }
+    atomicAdd(dw + gj, sw);
+    if (cc >= 4 * C) atomicAdd(dglob + b * C + (cc - 4 * C), w[gj] * sd);
+  }
+}
+
+// ---- 1x1 prediction heads: y[m] = x[m,:].w + b --------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, T* __restrict__ y, long M, int C) {
+  constexpr int VEC = ST<T>::VEC;
+  const int lpp = C / VEC;  // lanes per pixel (power of two <= 64)
+  const int ppw = 64 / lpp;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % lpp, pin = lane / lpp;
+  const long wave_global = (blockIdx.x * 256L + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * 256) >> 6;
+  float wv[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) wv[e] = w[sub * VEC + e];
+  for (long m0 = wave_global * ppw; m0 < M; m0 += nwaves * ppw) {
+    const long m = m0 + pin;
+    float s = 0.f;
+    if (m < M) {
+      float v[VEC];
+      unpack16<T>(ld16(x + m * C + sub * VEC), v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s += v[e] * wv[e];
+    }
+    for (int o = lpp >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0 && m < M) ST<T>::st(y + m, s + bias[0]);
+  }
+}
+// dx[m,c] (+)= dy[m]*w[c]
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                          T* __restrict__ dx, long M, int C, int accumulate) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const long total = M * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    const long m = i / nch;
+    const float d = ST<T>::ld(dy + m);
+    float v[VEC];
+    if (accumulate) unpack16<T>(ld16(dx + i * VEC), v);
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] += d * w[ch * VEC + e];
+    st16(dx + i * VEC, pack16<T>(v));
+  }
+}
+// dw[c] += sum_m dy[m]*x[m,c];  db += sum_m dy[m]
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          float* __restrict__ dw, float* __restrict__ db, long M, int C,
+                                                          long rows_per_block) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const int rpar = 256 / nch;
+  const int ch = threadIdx.x % nch, rl = threadIdx.x / nch;
+  const long r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc[VEC], sb = 0.f;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if (rl < rpar) {
+    for (long r = r0 + rl; r < r1; r += rpar) {
+      const float d = ST<T>::ld(dy + r);
+      float v[VEC];
+      unpack16<T>(ld16(x + r * C + ch * VEC), v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += d * v[e];
+      if (ch == 0) sb += d;
+    }
+  }
+  __shared__ float red[256 * 8];
+  __shared__ float redb[256];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = acc[e];
+  redb[threadIdx.x] = sb;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int r = 0; r < rpar; ++r) s += red[r * nch * VEC + c];
+    atomicAdd(dw + c, s);
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int r = 0; r < 256; ++r) s += redb[r];
+    atomicAdd(db, s);
+  }
+}
+
+}  // namespace spg
+
+using namespace spg;
+
+#define LAUNCH_T(dtype, KERNEL, grid, lds, stream, ...)                                                      \
+  do {                                                                                                       \
+    if ((dtype) == SPG_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)(stream), __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<float>, dim3(grid), dim3(256), lds, (hipStream_t)(stream), __VA_ARGS__);  \
+  } while (0)
+#define TP(dtype, p) ((dtype) == SPG_BF16 ? (void*)(p) : (void*)(p))
+static inline int vec_of(int dtype) { return dtype == SPG_BF16 ? 8 : 4; }
+
+extern "C" int spg_upsample_bilinear(int dtype, const void* x, void* y, int B, int h, int w, int C, int H, int W, int ldy,
+                                     int c0, spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(C % v == 0 && ldy % v == 0 && c0 % v == 0, "upsample: C=%d ldy=%d c0=%d must be multiples of %d", C, ldy, c0, v);
+  const int grid = ew_grid((long)B * H * W * (C / v));
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(upsample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, h, w, C, H, W, ldy, c0);
+  else hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, h, w, C, H, W, ldy, c0);
+  return check_launch("upsample_bilinear");
+}
+extern "C" int spg_upsample_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int h, int w, int C, int H, int W,
+                                         int ldy, int c0, int accumulate, spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(C % v == 0 && ldy % v == 0 && c0 % v == 0, "upsample_bwd: alignment");
+  SPG_REQUIRE(H >= h && W >= w, "upsample_bwd: only upsampling is supported");
+  const int grid = ew_grid((long)B * h * w * (C / v));
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, B, h, w, C, H, W, ldy, c0, accumulate);
+  else hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, B, h, w, C, H, W, ldy, c0, accumulate);
+  return check_launch("upsample_bilinear_bwd");
+}
+extern "C" int spg_copy_channels(int dtype, const void* x, void* y, long M, int C, int ldx, int cx0, int ldy, int cy0,
+                                 int accumulate, spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(C % v == 0 && ldx % v == 0 && ldy % v == 0 && cx0 % v == 0 && cy0 % v == 0, "copy_channels: alignment");
+  const int grid = ew_grid(M * (C / v));
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, M, C, ldx, cx0, ldy, cy0, accumulate);
+  else hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, M, C, ldx, cx0, ldy, cy0, accumulate);
+  return check_launch("copy_channels");
+}
+extern "C" int spg_add(int dtype, const void* a, const void* b, void* out, long n, spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(n % v == 0, "add: n=%ld must be a multiple of %d", n, v);
+  const int grid = ew_grid(n / v);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / v);
+  else hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)out, n / v);
+  return check_launch("add");
+}
+extern "C" int spg_cast_bf16(const float* f32, void* bf16, long n, int to_f32, spg_stream_t stream) {
+  SPG_REQUIRE(n % 8 == 0, "cast: n=%ld must be a multiple of 8", n);
+  hipLaunchKernelGGL(cast_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, f32, (bf16_t*)bf16, n / 8, to_f32);
+  return check_launch("cast_bf16");
+}
+extern "C" int spg_maxpool2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int ldc, int c0,
+                                spg_stream_t stream) {
+  SPG_REQUIRE((H % 2 == 0) && (W % 2 == 0), "maxpool2: H=%d W=%d must be even", H, W);
+  const int grid = ew_grid((long)B * (H / 2) * (W / 2) * C);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, idx, B, H, W, C, ldc, c0);
+  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, idx, B, H, W, C, ldc, c0);
+  return check_launch("maxpool2_fwd");
+}
+extern "C" int spg_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int ldc,
+                                int c0, spg_stream_t stream) {
+  SPG_REQUIRE((H % 2 == 0) && (W % 2 == 0), "maxpool2_bwd: H=%d W=%d must be even", H, W);
+  const int grid = ew_grid((long)B * H * W * C);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, idx, (bf16_t*)dx, B, H, W, C, ldc, c0);
+  else hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, idx, (float*)dx, B, H, W, C, ldc, c0);
+  return check_launch("maxpool2_bwd");
+}
+extern "C" int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int S, int Kpad, spg_stream_t stream) {
+  SPG_REQUIRE(S % 4 == 0 && Kpad >= 147, "patch_im2col: S=%d Kpad=%d", S, Kpad);
+  const int grid = ew_grid((long)B * (S / 4) * (S / 4) * Kpad);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, S, Kpad);
+  else hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, S, Kpad);
+  return check_launch("patch_im2col");
+}
+extern "C" int spg_se_fc(const float* gap, const float* w1, const float* w2, float* hidden, float* scale, int B, int C, int R,
+                         spg_stream_t stream) {
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, C, R);
+  return check_launch("se_fc");
+}
+extern "C" int spg_se_fc_bwd(const float* gap, const float* w1, const float* w2, const float* hidden, const float* scale,
+                             const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, spg_stream_t stream) {
+  hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(256), (2 * C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, dscale, dgap, dw1, dw2, C, R);
+  return check_launch("se_fc_bwd");
+}
+extern "C" int spg_chan_scale(int dtype, const void* x, const float* scale, void* y, int B, long HW, int C, spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(C % v == 0, "chan_scale: C alignment");
+  const long total = (long)B * HW * (C / v);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(chan_scale_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, (bf16_t*)y, HW, C, total);
+  else hipLaunchKernelGGL(chan_scale_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, (float*)y, HW, C, total);
+  return check_launch("chan_scale");
+}
+extern "C" int spg_chan_scale_bwd(int dtype, const void* dy, const float* scale, const float* dgap, void* dx, int B, long HW,
+                                  int C, spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(C % v == 0, "chan_scale_bwd: C alignment");
+  const long total = (long)B * HW * (C / v);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(chan_scale_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, scale, dgap, (bf16_t*)dx, HW, C, total, 1.f / (float)HW);
+  else hipLaunchKernelGGL(chan_scale_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, scale, dgap, (float*)dx, HW, C, total, 1.f / (float)HW);
+  return check_launch("chan_scale_bwd");
+}
+extern "C" int spg_dwconv3x3(int dtype, const void* x, const float* w, void* y, int B, int H, int W, int C, int dil, int flip,
+                             spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(C % v == 0, "dwconv3x3: C alignment");
+  const int grid = ew_grid((long)B * H * W * (C / v));
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (bf16_t*)y, B, H, W, C, dil, flip);
+  else hipLaunchKernelGGL(dwconv_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, (float*)y, B, H, W, C, dil, flip);
+  return check_launch("dwconv3x3");
+}
+extern "C" int spg_dwconv3x3_wgrad(int dtype, const void* dy, const void* x, float* dw, int B, int H, int W, int C, int dil,
+                                   spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(C % v == 0 && C / v <= 256, "dwconv3x3_wgrad: C alignment");
+  const long npix = (long)B * H * W;
+  long ppb = cdiv(npix, 512);
+  if (ppb < 64) ppb = 64;
+  const int grid = cdiv(npix, ppb);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, dw, B, H, W, C, dil, ppb);
+  else hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, dw, B, H, W, C, dil, ppb);
+  return check_launch("dwconv3x3_wgrad");
+}
+extern "C" int spg_easpp_fuse(int dtype, const void* br0, const void* br1, const void* br2, const void* br3, const float* glob,
+                              const float* w, void* y, int B, long HW, int C, spg_stream_t stream) {
+  const long total = (long)B * HW * C;
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(easpp_fuse_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)br0, (const bf16_t*)br1, (const bf16_t*)br2, (const bf16_t*)br3, glob, w, (bf16_t*)y, HW, C, total);
+  else hipLaunchKernelGGL(easpp_fuse_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)br0, (const float*)br1, (const float*)br2, (const float*)br3, glob, w, (float*)y, HW, C, total);
+  return check_launch("easpp_fuse");
+}
+extern "C" int spg_easpp_fuse_bwd(int dtype, const void* dy, const void* br0, const void* br1, const void* br2, const void* br3,
+                                  const float* glob, const float* w, void* d0, void* d1, void* d2, void* d3, float* dglob,
+                                  float* dw, int B, long HW, int C, spg_stream_t stream) {
+  const long total = (long)B * HW * 4 * C;
+  long rpb = cdiv(HW, 32);
+  if (rpb < 8) rpb = 8;
+  dim3 g2(cdiv(HW, rpb), B);
+  if (dtype == SPG_BF16) {
+    hipLaunchKernelGGL(easpp_fuse_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, w, (bf16_t*)d0, (bf16_t*)d1, (bf16_t*)d2, (bf16_t*)d3, HW, C, total);
+    hipLaunchKernelGGL(easpp_fuse_bwd_reduce_kernel<bf16_t>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)br0, (const bf16_t*)br1, (const bf16_t*)br2, (const bf16_t*)br3, glob, w, dglob, dw, HW, C, rpb);
+  } else {
+    hipLaunchKernelGGL(easpp_fuse_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)d0, (float*)d1, (float*)d2, (float*)d3, HW, C, total);
+    hipLaunchKernelGGL(easpp_fuse_bwd_reduce_kernel<float>, g2, dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)br0, (const float*)br1, (const float*)br2, (const float*)br3, glob, w, dglob, dw, HW, C, rpb);
+  }
+  return check_launch("easpp_fuse_bwd");
+}
+extern "C" int spg_head1x1(int dtype, const void* x, const float* w, const float* b, void* y, long M, int C, spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  const int lpp = C / v;
+  SPG_REQUIRE(C % v == 0 && lpp >= 1 && lpp <= 64 && (lpp & (lpp - 1)) == 0, "head1x1: C=%d/%d must be a power of two <= 64", C, v);
+  const int ppw = 64 / lpp;
+  const int grid = ew_grid((M + ppw - 1) / ppw * 64);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b, (bf16_t*)y, M, C);
+  else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, b, (float*)y, M, C);
+  return check_launch("head1x1");
+}
+extern "C" int spg_head1x1_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, long M,
+                               int C, int accumulate, spg_stream_t stream) {
+  const int v = vec_of(dtype);
+  SPG_REQUIRE(C % v == 0 && C / v <= 256, "head1x1_bwd: C alignment");
+  const long rpar = 256 / (C / v);
+  long rpb = cdiv(M, 1024);
+  if (rpb < rpar * 8) rpb = rpar * 8;
+  if (dtype == SPG_BF16) {
+    hipLaunchKernelGGL(head_bwd_dx_kernel<bf16_t>, dim3(ew_grid(M * (C / v))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, w, (bf16_t*)dx, M, C, accumulate);
+    hipLaunchKernelGGL(head_bwd_dw_kernel<bf16_t>, dim3(cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, dw, db, M, C, rpb);
+  } else {
+    hipLaunchKernelGGL(head_bwd_dx_kernel<float>, dim3(ew_grid(M * (C / v))), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, M, C, accumulate);
+    hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, dw, db, M, C, rpb);
+  }
+  return check_launch("head1x1_bwd");
+}

@@ -1,0 +1,510 @@
+// MFMA GEMM family for gfx950.
+//
+//   gemm_nt : C[M,N] = epi(X[M,K] . W[N,K]^T)   forward + dgrad of every Linear / 1x1 conv, and (conv3x3
+//             gather on X) forward + dgrad of every 3x3 convolution as an implicit GEMM over NHWC.
+//   gemm_tn : dW[N,K] += dY[M,N]^T . X[M,K]     weight gradients (reduction over the M rows), operands are
+//             transposed through registers on their way into LDS; split over M with f32 atomics.
+//
+// Tile 128(m) x 128(n), 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 blocks, f32 accumulators.
+// LDS rows are 128 bytes (64 bf16 / 32 f32 of K), 16-byte chunks XOR-swizzled so the fragment reads
+// (ds_read_b128 for bf16, ds_read_b32 for f32) are bank-conflict free / 2-way.  Register-staged double
+// buffering: global loads for tile t+1 are issued before the MFMAs of tile t, written to the other LDS
+// buffer after them, one barrier per K-tile.
+//
+// MFMA operand roles: "A" = weight rows (n), "B" = activation rows (m)  =>  D[n][m]: a lane holds 4
+// consecutive n for one m, so the epilogue reads bias / writes C as 8- or 16-byte vectors.
+#include "common.h"
+
+namespace spg {
+
+constexpr int BM = 128, BN = 128, ROWB = 128;  // tile rows, LDS row bytes
+constexpr int NT_THREADS = 256;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int SUB = 2;  // MFMA k-steps per LDS row (2 x 32)
+  using Frag = bf16x8_t;
+  __device__ static __forceinline__ Frag load(const char* row, int sw, int s, int q) {
+    return *reinterpret_cast<const Frag*>(row + (((4 * s + q) ^ sw) << 4));
+  }
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int SUB = 8;  // 8 x 4
+  using Frag = float;
+  __device__ static __forceinline__ Frag load(const char* row, int sw, int s, int q) {
+    return *reinterpret_cast<const float*>(row + ((s ^ sw) << 4) + (q << 2));
+  }
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// XCD-aware bijective remap: blocks sharing blockIdx%8 (one XCD) get a contiguous range of tile ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+struct ConvGeom {
+  int B, H, W, Ci;  // NHWC input of a 3x3/pad1/stride1 convolution
+};
+
+// One 16-byte chunk of row m, K offset k0 of the (possibly gathered) X operand; zero outside.
+template <typename T, bool CONV>
+__device__ __forceinline__ u32x4 load_x_chunk(const T* __restrict__ X, int m, int k0, int M, int K, int ldx,
+                                              const ConvGeom& g, int py, int px, long pix_base) {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  if (m >= M || k0 >= K) return z;
+  if constexpr (!CONV) {
+    return ld16(X + (long)m * ldx + k0);
+  } else {
+    const int tap = k0 / g.Ci, ci = k0 - tap * g.Ci;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int yy = py + dy, xx = px + dx;
+    if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return z;
+    return ld16(X + (pix_base + (long)dy * g.W + dx) * g.Ci + ci);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_tile(const char* __restrict__ Ws, const char* __restrict__ Xs, int wn, int wm,
+                                         int lane, f32x4 (&acc)[4][4]) {
+  using M_ = Mma<T>;
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < M_::SUB; ++s) {
+    typename M_::Frag a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rowa = wn * 64 + i * 16 + r;
+      a[i] = M_::load(Ws + rowa * ROWB, rowa & 7, s, q);
+      const int rowb = wm * 64 + i * 16 + r;
+      b[i] = M_::load(Xs + rowb * ROWB, rowb & 7, s, q);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = M_::mma(a[ni], b[mi], acc[ni][mi]);
+  }
+}
+
+struct NtEpi {
+  const float* bias;
+  const void* residual;
+  const void* gelu_h;
+  void* C2;
+  int act;
+};
+
+template <typename T, bool CONV>
+__global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                             T* __restrict__ C, NtEpi epi, int M, int N, int K,
+                                                             int ldx, int ldc, ConvGeom g, int tiles_n, int nwg) {
+  constexpr int VEC = ST<T>::VEC;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem;                     // [2][BM][ROWB]
+  char* Ws = smem + 2 * BM * ROWB;     // [2][BN][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging assignment: chunk c = tid&7 of rows (tid>>3) + 32*i
+  const int sc = tid & 7, sr = tid >> 3;
+  int py[4], px[4];
+  long pbase[4];
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + sr + 32 * i;
+      const int hw = g.H * g.W;
+      const int b = m / hw, rem = m - b * hw;
+      py[i] = rem / g.W;
+      px[i] = rem - py[i] * g.W;
+      pbase[i] = (long)m;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { py[i] = px[i] = 0; pbase[i] = 0; }
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rx[4], rw[4];
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK + sc * VEC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rx[i] = load_x_chunk<T, CONV>(X, m0 + sr + 32 * i, k0, M, K, ldx, g, py[i], px[i], pbase[i]);
+      const int n = n0 + sr + 32 * i;
+      rw[i] = (n < N && k0 < K) ? ld16(W + (long)n * K + k0) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = sr + 32 * i;
+      const int off = row * ROWB + ((sc ^ (row & 7)) << 4);
+      *reinterpret_cast<u32x4*>(Xs + buf * BM * ROWB + off) = rx[i];
+      *reinterpret_cast<u32x4*>(Ws + buf * BN * ROWB + off) = rw[i];
+    }
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    mma_tile<T>(Ws + cur * BN * ROWB, Xs + cur * BM * ROWB, wn, wm, lane, acc);
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds n = nb + 4q + r (r = 0..3), m = mb + (lane&15)
+  const int r15 = lane & 15, q = lane >> 4;
+  const T* R = reinterpret_cast<const T*>(epi.residual);
+  const T* Hh = reinterpret_cast<const T*>(epi.gelu_h);
+  T* C2 = reinterpret_cast<T*>(epi.C2);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + r15;
+    if (m >= M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + q * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+      const long o = (long)m * ldc + n;
+      const bool full = (n + 3 < N);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!full && n + e >= N) break;
+        float x = v[e];
+        if (epi.bias) x += epi.bias[n + e];
+        if (C2) ST<T>::st(C2 + o + e, x);
+        if (epi.act == SPG_ACT_GELU) x = gelu_f(x);
+        else if (epi.act == SPG_ACT_RELU) x = fmaxf(x, 0.f);
+        if (Hh) x *= gelu_grad_f(ST<T>::ld(Hh + o + e));
+        if (R) x += ST<T>::ld(R + o + e);
+        v[e] = x;
+      }
+      if (full) {
+        if constexpr (sizeof(T) == 2) {
+          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(C + o) = pk;
+        } else {
+          *reinterpret_cast<f32x4*>(C + o) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+      } else {
+        for (int e = 0; e < 4 && n + e < N; ++e) ST<T>::st(C + o + e, v[e]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: dW[n][k] += sum_m dY[m][n] * X[m][k].  LDS rows are output features (n for the dY operand, k for the
+// X operand), 128 bytes of consecutive m per row; register transpose of 4(m) x 16-byte patches.
+// swizzle for these images: sw(f) = (f ^ (f >> 4)) & 7 -> fragment reads conflict free, patch writes 2-way.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_sw(int f) { return (f ^ (f >> 4)) & 7; }
+
+template <typename T>
+__device__ __forceinline__ void mma_tile_tn(const char* __restrict__ As, const char* __restrict__ Bs, int wn, int wk,
+                                            int lane, f32x4 (&acc)[4][4]) {
+  using M_ = Mma<T>;
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < M_::SUB; ++s) {
+    typename M_::Frag a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rowa = wn * 64 + i * 16 + r;
+      a[i] = M_::load(As + rowa * ROWB, tn_sw(rowa), s, q);
+      const int rowb = wk * 64 + i * 16 + r;
+      b[i] = M_::load(Bs + rowb * ROWB, tn_sw(rowb), s, q);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int ki = 0; ki < 4; ++ki) acc[ni][ki] = M_::mma(a[ni], b[ki], acc[ni][ki]);
+  }
+}
+
+// write a 4(m) x VEC(features) patch transposed into the LDS image. rows[4] = the four 16-byte loads.
+template <typename T>
+__device__ __forceinline__ void store_patch(char* img, const u32x4 (&rows)[4], int f0, int mg) {
+  if constexpr (sizeof(T) == 2) {
+    // 8 features; feature j gets the 4 bf16 (m = 4mg..4mg+3) = 8 bytes at chunk mg>>1, half mg&1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = f0 + j;
+      unsigned e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned word = rows[i][j >> 1];
+        e[i] = (j & 1) ? (word >> 16) : (word & 0xffffu);
+      }
+      u32x2 v = {e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+      *reinterpret_cast<u32x2*>(img + f * ROWB + ((((mg >> 1) ^ tn_sw(f))) << 4) + ((mg & 1) << 3)) = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = f0 + j;
+      u32x4 v = {rows[0][j], rows[1][j], rows[2][j], rows[3][j]};
+      *reinterpret_cast<u32x4*>(img + f * ROWB + ((mg ^ tn_sw(f)) << 4)) = v;
+    }
+  }
+}
+
+template <typename T, bool CONV>
+__global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict__ dY, const T* __restrict__ X,
+                                                             float* __restrict__ dW, int M, int N, int K, int ldy,
+                                                             int ldx, int ldw, ConvGeom g, int tiles_k, int m_per_split) {
+  constexpr int VEC = ST<T>::VEC;
+  constexpr int MSTEP = ROWB / (int)sizeof(T);  // m rows per LDS tile: 64 (bf16) / 32 (f32)
+  constexpr int NCH = 128 / VEC;                // feature chunks per tile row: 16 / 32
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                   // [2][128 n][ROWB]   (dY^T)
+  char* Bs = smem + 2 * 128 * ROWB;  // [2][128 k][ROWB]   (X^T)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int tk = blockIdx.x % tiles_k, tn = blockIdx.x / tiles_k;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int m_begin = blockIdx.y * m_per_split;
+  const int m_end = min(M, m_begin + m_per_split);
+
+  const int fc = tid % NCH, mg = tid / NCH;  // feature chunk, m-group (4 rows each)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int mt) {
+    const int mb = m_begin + mt * MSTEP + mg * 4;
+    const int n = n0 + fc * VEC, k = k0 + fc * VEC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + i;
+      const bool mv = m < m_end;
+      ra[i] = (mv && n < N) ? ld16(dY + (long)m * ldy + n) : u32x4{0u, 0u, 0u, 0u};
+      if constexpr (!CONV) {
+        rb[i] = (mv && k < K) ? ld16(X + (long)m * ldx + k) : u32x4{0u, 0u, 0u, 0u};
+      } else {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        if (mv && k < K) {
+          const int hw = g.H * g.W;
+          const int b = m / hw, rem = m - b * hw;
+          const int y = rem / g.W, x = rem - y * g.W;
+          const int tap = k / g.Ci, ci = k - tap * g.Ci;
+          const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+          if ((unsigned)(y + dy) < (unsigned)g.H && (unsigned)(x + dx) < (unsigned)g.W)
+            z = ld16(X + ((long)m + (long)dy * g.W + dx) * g.Ci + ci);
+        }
+        rb[i] = z;
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+    store_patch<T>(As + buf * 128 * ROWB, ra, fc * VEC, mg);
+    store_patch<T>(Bs + buf * 128 * ROWB, rb, fc * VEC, mg);
+  };
+
+  const int nm = (m_end - m_begin + MSTEP - 1) / MSTEP;
+  if (nm <= 0) return;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int mt = 0; mt < nm; ++mt) {
+    const int cur = mt & 1;
+    if (mt + 1 < nm) gload(mt + 1);
+    mma_tile_tn<T>(As + cur * 128 * ROWB, Bs + cur * 128 * ROWB, wn, wk, lane, acc);
+    if (mt + 1 < nm) sstore(cur ^ 1);
+    __syncthreads();
+  }
+  // lane holds n = nb + 4q + r, k = kb + (lane&15)
+  const int r15 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki) {
+      const int k = k0 + wk * 64 + ki * 16 + r15;
+      if (k >= K) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wn * 64 + ni * 16 + q * 4 + e;
+        if (n < N) atomicAdd(dW + (long)n * ldw + k, acc[ni][ki][e]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_matrix_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C, int transpose) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  if (!transpose) {
+    for (int j = ty; j < 32; j += 8) {
+      const int r = by + j, c = bx + tx;
+      if (r < R && c < C) ST<T>::st(dst + (long)r * C + c, src[(long)r * C + c]);
+    }
+    return;
+  }
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;  // dst[c][r]
+    if (r < R && c < C) ST<T>::st(dst + (long)c * R + r, tile[tx][j]);
+  }
+}
+
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* __restrict__ dgr, int Co,
+                                    int Ci) {
+  const long n = (long)Co * Ci * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const long t = i / 9;
+    const int ci = (int)(t % Ci), co = (int)(t / Ci);
+    const float v = src[i];
+    if (fwd) ST<T>::st(fwd + ((long)co * 9 + tap) * Ci + ci, v);
+    if (dgr) ST<T>::st(dgr + ((long)ci * 9 + (8 - tap)) * Co + co, v);
+  }
+}
+
+__global__ void unpack_conv3x3_grad_kernel(const float* __restrict__ packed, float* __restrict__ dst, int Co, int Ci) {
+  const long n = (long)Co * Ci * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const long t = i / 9;
+    const int ci = (int)(t % Ci), co = (int)(t / Ci);
+    dst[i] = packed[((long)co * 9 + tap) * Ci + ci];
+  }
+}
+
+template <typename T>
+static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, int N, int K, int ldx, int ldc, int conv,
+                     ConvGeom g, hipStream_t s) {
+  const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, BM);
+  const int nwg = tiles_n * tiles_m;
+  const size_t lds = 4 * 128 * ROWB;
+  if (conv)
+    hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(nwg), dim3(NT_THREADS), lds, s, (const T*)X, (const T*)W, (T*)C,
+                       epi, M, N, K, ldx, ldc, g, tiles_n, nwg);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(nwg), dim3(NT_THREADS), lds, s, (const T*)X, (const T*)W,
+                       (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg);
+  return check_launch("gemm_nt");
+}
+
+template <typename T>
+static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx, int ldw, int conv,
+                     ConvGeom g, hipStream_t s) {
+  constexpr int MSTEP = ROWB / (int)sizeof(T);
+  const int tiles_n = cdiv(N, 128), tiles_k = cdiv(K, 128);
+  const int tiles = tiles_n * tiles_k;
+  int splits = cdiv(768, tiles);  // aim for >= 3 blocks per CU
+  const int max_splits = cdiv(M, 4 * MSTEP);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int m_per_split = cdiv(cdiv(M, splits), MSTEP) * MSTEP;
+  splits = cdiv(M, m_per_split);
+  const size_t lds = 4 * 128 * ROWB;
+  if (conv)
+    hipLaunchKernelGGL((gemm_tn_kernel<T, true>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
+                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<T, false>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
+                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split);
+  return check_launch("gemm_tn");
+}
+
+}  // namespace spg
+
+using namespace spg;
+
+extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, void* C2, const float* bias,
+                           const void* residual, const void* gelu_h, int M, int N, int K, int ldx, int ldc, int act,
+                           int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream) {
+  const int vec = dtype == SPG_BF16 ? 8 : 4;
+  SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "gemm_nt: bad dtype %d", dtype);
+  SPG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  SPG_REQUIRE(K % vec == 0, "gemm_nt: K=%d must be a multiple of %d", K, vec);
+  SPG_REQUIRE(ldc % 4 == 0 && ldc >= N, "gemm_nt: ldc=%d must be >=N and a multiple of 4", ldc);
+  ConvGeom g{B, H, Wd, Ci};
+  if (conv3x3) {
+    SPG_REQUIRE((long)B * H * Wd == M && K == 9 * Ci && Ci % vec == 0, "gemm_nt: conv geometry mismatch (M=%d K=%d B=%d H=%d W=%d Ci=%d)", M, K, B, H, Wd, Ci);
+  } else {
+    SPG_REQUIRE(ldx % vec == 0 && ldx >= K, "gemm_nt: ldx=%d must be >=K and a multiple of %d", ldx, vec);
+  }
+  NtEpi epi{bias, residual, gelu_h, C2, act};
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == SPG_BF16 ? launch_nt<bf16_t>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s)
+                           : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s);
+}
+
+extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx,
+                           int ldw, int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream) {
+  const int vec = dtype == SPG_BF16 ? 8 : 4;
+  SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "gemm_tn: bad dtype %d", dtype);
+  SPG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem");
+  SPG_REQUIRE(N % vec == 0 && ldy % vec == 0 && K % vec == 0, "gemm_tn: N=%d ldy=%d K=%d must be multiples of %d", N, ldy, K, vec);
+  ConvGeom g{B, H, Wd, Ci};
+  if (conv3x3) {
+    SPG_REQUIRE((long)B * H * Wd == M && K == 9 * Ci && Ci % vec == 0, "gemm_tn: conv geometry mismatch");
+  } else {
+    SPG_REQUIRE(ldx % vec == 0 && ldx >= K, "gemm_tn: bad ldx=%d", ldx);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == SPG_BF16 ? launch_tn<bf16_t>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s)
+                           : launch_tn<float>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s);
+}
+
+extern "C" int spg_pack_matrix(int dtype, const float* src, void* dst, int R, int C, int transpose, spg_stream_t stream) {
+  SPG_REQUIRE(R > 0 && C > 0, "pack_matrix: empty");
+  dim3 grid(cdiv(C, 32), cdiv(R, 32));
+  if (dtype == SPG_BF16)
+    hipLaunchKernelGGL(pack_matrix_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, C, transpose);
+  else
+    hipLaunchKernelGGL(pack_matrix_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, R, C, transpose);
+  return check_launch("pack_matrix");
+}
+
+extern "C" int spg_pack_conv3x3(int dtype, const float* src, void* dst_fwd, void* dst_dgrad, int Co, int Ci,
+                                spg_stream_t stream) {
+  const long n = (long)Co * Ci * 9;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (dtype == SPG_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst_fwd, (bf16_t*)dst_dgrad, Co, Ci);
+  else
+    hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst_fwd, (float*)dst_dgrad, Co, Ci);
+  return check_launch("pack_conv3x3");
+}
+
+extern "C" int spg_unpack_conv3x3_grad(const float* packed, float* dst, int Co, int Ci, spg_stream_t stream) {
+  const long n = (long)Co * Ci * 9;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(unpack_conv3x3_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, packed, dst, Co, Ci);
+  return check_launch("unpack_conv3x3_grad");
+}

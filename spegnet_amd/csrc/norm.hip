@@ -1,0 +1,425 @@
+// LayerNorm (Hiera trunk, eps 1e-6) and BatchNorm2d-on-NHWC (head, eps 1e-5, momentum 0.1) kernels.
+// All are HBM-bound: 16-byte vector accesses, one pass over the data per kernel, f32 statistics,
+// wave shuffles for the row/channel reductions.
+#include "common.h"
+
+namespace spg {
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row cached in registers (<= MAXCH 16-byte chunks per lane).
+// ---------------------------------------------------------------------------------------------------
+constexpr int LN_MAXCH = 5;
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                            int C, float eps) {
+  constexpr int VEC = ST<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C / VEC;
+  float v[LN_MAXCH][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      unpack16<T>(ld16(x + (long)row * C + ch * VEC), v[i]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s += v[i][e];
+    }
+  }
+  const float mu = wave_sum(s) / C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = v[i][e] - mu; ss += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(ss) / C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = (v[i][e] - mu) * rs * gamma[ch * VEC + e] + beta[ch * VEC + e];
+      st16(y + (long)row * C + ch * VEC, pack16<T>(o));
+    }
+  }
+}
+
+// dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) (+dres); dgamma += sum dy*xhat; dbeta += sum dy.
+// A wave walks rows with a grid stride and keeps per-lane channel partials in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                            T* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int M, int C) {
+  constexpr int VEC = ST<T>::VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C / VEC;
+  float g[LN_MAXCH][VEC], dg[LN_MAXCH][VEC], db[LN_MAXCH][VEC];
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      g[i][e] = (ch < nch) ? gamma[ch * VEC + e] : 0.f;
+      dg[i][e] = 0.f; db[i][e] = 0.f;
+    }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAXCH][VEC], gd[LN_MAXCH][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float xv[VEC], dv[VEC];
+        unpack16<T>(ld16(x + (long)row * C + ch * VEC), xv);
+        unpack16<T>(ld16(dy + (long)row * C + ch * VEC), dv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          gd[i][e] = dv[e] * g[i][e];
+          s1 += gd[i][e];
+          s2 += gd[i][e] * xh[i][e];
+          dg[i][e] += dv[e] * xh[i][e];
+          db[i][e] += dv[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[VEC];
+        if (dres) unpack16<T>(ld16(dres + (long)row * C + ch * VEC), o);
+        else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] += rs * (gd[i][e] - s1 - xh[i][e] * s2);
+        st16(dx + (long)row * C + ch * VEC, pack16<T>(o));
+      }
+    }
+  }
+  // cross-wave reduce through LDS, then one atomic per channel per block
+  __shared__ float red[4][64 * VEC + 1];
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      if (64 * i >= nch) break;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) red[wave][lane * VEC + e] = pass ? db[i][e] : dg[i][e];
+      __syncthreads();
+      for (int j = threadIdx.x; j < 64 * VEC; j += 256) {
+        const int c = 64 * i * VEC + j;
+        if (c < C) {
+          const float t = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+          atomicAdd((pass ? dbeta : dgamma) + c, t);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Column reductions over [M, C] rows (channels fastest): sum (and optionally sum of squares, or sum of
+// dy'*(1, xhat) for BN backward).  A thread owns one 16-byte channel chunk and strides over rows.
+// ---------------------------------------------------------------------------------------------------
+enum { RED_SUM = 0, RED_SUM_SQ = 1, RED_BN_BWD = 2, RED_PROD = 3 };
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                        const float* __restrict__ p0, const float* __restrict__ p1,
+                                                        float* __restrict__ out, long M, int C, int lda, long rows_per_block,
+                                                        long img_rows, int relu) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const int rpar = 256 / nch;  // rows handled in parallel by a block
+  const int ch = threadIdx.x % nch, rl = threadIdx.x / nch;
+  // blockIdx.y = image index for per-image reductions (img_rows > 0), else 0
+  const long base = (long)blockIdx.y * img_rows;
+  const long rows_total = img_rows > 0 ? img_rows : M;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows_total, r0 + rows_per_block);
+  float s0[VEC], s1[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+  if constexpr (MODE == RED_BN_BWD) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = ch * VEC + e;
+      mu[e] = p0[c]; is[e] = p0[C + c]; sc[e] = p1[c]; sh[e] = p1[C + c];
+    }
+  }
+  if (rl < rpar) {
+    for (long r = r0 + rl; r < r1; r += rpar) {
+      float av[VEC];
+      unpack16<T>(ld16(a + (base + r) * lda + ch * VEC), av);
+      if constexpr (MODE == RED_SUM) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s0[e] += av[e];
+      } else if constexpr (MODE == RED_SUM_SQ) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s0[e] += av[e]; s1[e] += av[e] * av[e]; }
+      } else if constexpr (MODE == RED_PROD) {
+        float bv[VEC];
+        unpack16<T>(ld16(b + (base + r) * lda + ch * VEC), bv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s0[e] += av[e] * bv[e];
+      } else {  // a = dy, b = x (pre-BN)
+        float xv[VEC];
+        unpack16<T>(ld16(b + (base + r) * lda + ch * VEC), xv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = (relu && (xv[e] * sc[e] + sh[e] <= 0.f)) ? 0.f : av[e];
+          s0[e] += d;
+          s1[e] += d * (xv[e] - mu[e]) * is[e];
+        }
+      }
+    }
+  }
+  __shared__ float red[2][256 * 8];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x * VEC + e] = s0[e]; red[1][threadIdx.x * VEC + e] = s1[e]; }
+  __syncthreads();
+  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int r = 0; r < rpar; ++r) {
+      t0 += red[0][r * nch * VEC + c];
+      if (TWO) t1 += red[1][r * nch * VEC + c];
+    }
+    float* o = out + (long)blockIdx.y * C * (TWO ? 2 : 1);
+    atomicAdd(o + c, t0);
+    if (TWO) atomicAdd(o + C + c, t1);
+  }
+}
+
+template <typename T, int MODE>
+static int launch_colreduce(const void* a, const void* b, const float* p0, const float* p1, float* out, long M, int C,
+                            int lda, int nimg, long img_rows, int relu, hipStream_t s, const char* what) {
+  constexpr int VEC = ST<T>::VEC;
+  if (C % VEC != 0 || C / VEC > 256 || lda % VEC != 0) {
+    set_error("%s: C=%d (lda=%d) must be a multiple of %d and C/%d <= 256", what, C, lda, VEC, VEC);
+    return SPG_ERR_BAD_ARG;
+  }
+  const long rows = img_rows > 0 ? img_rows : M;
+  const int rpar = 256 / (C / VEC);
+  long want = 2048 / (nimg > 0 ? nimg : 1);
+  if (want < 1) want = 1;
+  long rpb = cdiv(rows, want);
+  const long min_rpb = (long)rpar * 8;
+  if (rpb < min_rpb) rpb = min_rpb;
+  const int gx = cdiv(rows, rpb);
+  hipLaunchKernelGGL((colreduce_kernel<T, MODE>), dim3(gx, nimg > 0 ? nimg : 1), dim3(256), 0, s, (const T*)a, (const T*)b,
+                     p0, p1, out, M, C, lda, rpb, img_rows, relu);
+  return check_launch(what);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BN finalize / apply / backward-apply
+// ---------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float* __restrict__ scale_shift, float* __restrict__ mean_invstd, long M, int C,
+                                   float eps, float momentum, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mu, var;
+  if (training) {
+    mu = stats[c] / (float)M;
+    var = fmaxf(stats[C + c] / (float)M - mu * mu, 0.f);
+    if (rmean) {
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+      const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+  } else {
+    mu = rmean[c]; var = rvar[c];
+  }
+  const float is = rsqrtf(var + eps);
+  const float sc = gamma[c] * is;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - mu * sc;
+  if (mean_invstd) { mean_invstd[c] = mu; mean_invstd[C + c] = is; }
+}
+
+// y = act(x*scale+shift) [* chan_mul[b][c]]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ ss,
+                                                       T* __restrict__ y, long M, int C, int relu) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const long total = M * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    float v[VEC];
+    unpack16<T>(ld16(x + i * VEC), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = ch * VEC + e;
+      float o = v[e] * ss[c] + ss[C + c];
+      v[e] = relu ? fmaxf(o, 0.f) : o;
+    }
+    st16(y + i * VEC, pack16<T>(v));
+  }
+}
+
+// dx = gamma*invstd*(dy' - s1/M - xhat*s2/M);  block 0 also does dgamma += s2, dbeta += s1
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ ss, const float* __restrict__ mi,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                           T* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, long M, int C, int relu) {
+  constexpr int VEC = ST<T>::VEC;
+  const int nch = C / VEC;
+  const long total = M * nch;
+  const float invM = 1.f / (float)M;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (dbeta) atomicAdd(dbeta + c, sums[c]);
+      if (dgamma) atomicAdd(dgamma + c, sums[C + c]);
+    }
+  }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    float dv[VEC], xv[VEC];
+    unpack16<T>(ld16(dy + i * VEC), dv);
+    unpack16<T>(ld16(x + i * VEC), xv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = ch * VEC + e;
+      const float d = (relu && (xv[e] * ss[c] + ss[C + c] <= 0.f)) ? 0.f : dv[e];
+      const float xh = (xv[e] - mi[c]) * mi[C + c];
+      dv[e] = gamma[c] * mi[C + c] * (d - sums[c] * invM - xh * sums[C + c] * invM);
+    }
+    st16(dx + i * VEC, pack16<T>(dv));
+  }
+}
+
+static inline int ew_grid(long n_items) {
+  long g = (n_items + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace spg
+
+using namespace spg;
+
+#define DISPATCH_T(dtype, CALL_BF, CALL_F32) ((dtype) == SPG_BF16 ? (CALL_BF) : (CALL_F32))
+
+extern "C" int spg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int M, int C, float eps, spg_stream_t stream) {
+  const int vec = dtype == SPG_BF16 ? 8 : 4;
+  SPG_REQUIRE(M > 0 && C > 0 && C % vec == 0 && C / vec <= 64 * LN_MAXCH, "layernorm_fwd: C=%d must be a multiple of %d and <= %d", C, vec, 64 * LN_MAXCH * vec);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SPG_BF16)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(cdiv(M, 4)), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(cdiv(M, 4)), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, C, eps);
+  return check_launch("layernorm_fwd");
+}
+
+extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int M, int C,
+                                 spg_stream_t stream) {
+  const int vec = dtype == SPG_BF16 ? 8 : 4;
+  SPG_REQUIRE(M > 0 && C > 0 && C % vec == 0 && C / vec <= 64 * LN_MAXCH, "layernorm_bwd: bad C=%d", C);
+  hipStream_t s = (hipStream_t)stream;
+  int grid = cdiv(M, 4 * 8);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  if (dtype == SPG_BF16)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, M, C);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, M, C);
+  return check_launch("layernorm_bwd");
+}
+
+extern "C" int spg_colsum(int dtype, const void* x, float* out, int M, int C, int ldx, spg_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM>(x, nullptr, nullptr, nullptr, out, M, C, ldx, 0, 0, 0, s, "colsum")),
+                    (launch_colreduce<float, RED_SUM>(x, nullptr, nullptr, nullptr, out, M, C, ldx, 0, 0, 0, s, "colsum")));
+}
+
+extern "C" int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, spg_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, s, "bn_stats")),
+                    (launch_colreduce<float, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, s, "bn_stats")));
+}
+
+extern "C" int spg_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float* scale_shift, float* mean_invstd, long M, int C, float eps,
+                               float momentum, int training, spg_stream_t stream) {
+  SPG_REQUIRE(C > 0 && M > 0, "bn_finalize: empty");
+  SPG_REQUIRE(training || (running_mean && running_var), "bn_finalize: eval mode needs running stats");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, gamma, beta,
+                     running_mean, running_var, scale_shift, mean_invstd, M, C, eps, momentum, training);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int spg_bn_apply(int dtype, const void* x, const float* scale_shift, void* y, long M, int C, int relu,
+                            spg_stream_t stream) {
+  const int vec = dtype == SPG_BF16 ? 8 : 4;
+  SPG_REQUIRE(C % vec == 0, "bn_apply: C=%d must be a multiple of %d", C, vec);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(M * (C / vec));
+  if (dtype == SPG_BF16)
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, scale_shift, (bf16_t*)y, M, C, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, scale_shift, (float*)y, M, C, relu);
+  return check_launch("bn_apply");
+}
+
+extern "C" int spg_bn_bwd_reduce(int dtype, const void* dy, const void* x, const float* scale_shift,
+                                 const float* mean_invstd, float* sums, long M, int C, int relu, spg_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_BN_BWD>(dy, x, mean_invstd, scale_shift, sums, M, C, C, 0, 0, relu, s, "bn_bwd_reduce")),
+                    (launch_colreduce<float, RED_BN_BWD>(dy, x, mean_invstd, scale_shift, sums, M, C, C, 0, 0, relu, s, "bn_bwd_reduce")));
+}
+
+extern "C" int spg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* scale_shift,
+                                const float* mean_invstd, const float* gamma, const float* sums, void* dx, float* dgamma,
+                                float* dbeta, long M, int C, int relu, spg_stream_t stream) {
+  const int vec = dtype == SPG_BF16 ? 8 : 4;
+  SPG_REQUIRE(C % vec == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, vec);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(M * (C / vec));
+  if (dtype == SPG_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, scale_shift, mean_invstd, gamma, sums, (bf16_t*)dx, dgamma, dbeta, M, C, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, scale_shift, mean_invstd, gamma, sums, (float*)dx, dgamma, dbeta, M, C, relu);
+  return check_launch("bn_bwd_apply");
+}
+
+// per-image column mean numerators: out[b][c] += sum_hw x[b][hw][c]   (caller divides / zeroes)
+extern "C" int spg_gap_sum(int dtype, const void* x, float* out, int B, long HW, int C, spg_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM>(x, nullptr, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, s, "gap_sum")),
+                    (launch_colreduce<float, RED_SUM>(x, nullptr, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, s, "gap_sum")));
+}
+// per-image channel products: out[b][c] += sum_hw a[b][hw][c]*b[b][hw][c]   (SE scale gradient)
+extern "C" int spg_chan_prod_sum(int dtype, const void* a, const void* b, float* out, int B, long HW, int C,
+                                 spg_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_PROD>(a, b, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, s, "chan_prod_sum")),
+                    (launch_colreduce<float, RED_PROD>(a, b, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, s, "chan_prod_sum")));
+}

@@ -1,0 +1,310 @@
+"""Thin tensor-level wrappers over the C ABI (spegnet_amd/_lib.py).  Every function launches hand-written
+HIP kernels on torch's current stream; tensors only provide device memory.  No CPU path exists."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, SPG_BF16, SPG_F32  # noqa: F401
+
+Tensor = torch.Tensor
+
+
+def dcode(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return SPG_F32
+    if t.dtype == torch.bfloat16:
+        return SPG_BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _p(t: Optional[Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("spegnet_amd ops need CUDA/HIP tensors: there is no CPU fallback")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _c(t: Tensor) -> Tensor:
+    if not t.is_contiguous():
+        raise RuntimeError(f"expected a contiguous tensor, got strides {t.stride()} for shape {tuple(t.shape)}")
+    return t
+
+
+def f32(t: Tensor) -> Tensor:
+    assert t.dtype == torch.float32, t.dtype
+    return _c(t)
+
+
+# ---- GEMM family ---------------------------------------------------------------------------------------
+def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = ACT_NONE, residual: Optional[Tensor] = None,
+            gelu_h: Optional[Tensor] = None, out: Optional[Tensor] = None, preact_out: Optional[Tensor] = None,
+            conv: Optional[tuple] = None) -> Tensor:
+    """out[M,N] = epi(x[M,K] @ w[N,K]^T).  conv=(B,H,W,Ci): x is NHWC and the product is a 3x3/pad-1 convolution
+    with w packed [N, 9*Ci]."""
+    N, K = w.shape
+    if conv is None:
+        M = x.numel() // x.shape[-1]
+        assert x.shape[-1] == K, (x.shape, w.shape)
+        ldx = K
+        B = H = W = Ci = 0
+    else:
+        B, H, W, Ci = conv
+        M = B * H * W
+        assert x.numel() == M * Ci and K == 9 * Ci, (x.shape, conv, w.shape)
+        ldx = Ci
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    assert out.numel() == M * N and w.dtype == x.dtype
+    _lib.call("spg_gemm_nt", dcode(x), _p(_c(x)), _p(_c(w)), _p(_c(out)), _p(preact_out), _p(bias), _p(residual),
+              _p(gelu_h), M, N, K, ldx, N, act, 1 if conv else 0, B, H, W, Ci, _stream())
+    return out
+
+
+def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None) -> None:
+    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]  (conv: x NHWC gathered as in gemm_nt)."""
+    N = dy.shape[-1]
+    M = dy.numel() // N
+    if conv is None:
+        K = x.shape[-1]
+        assert x.numel() == M * K
+        B = H = W = Ci = 0
+        ldx = K
+    else:
+        B, H, W, Ci = conv
+        K = 9 * Ci
+        assert B * H * W == M and x.numel() == M * Ci
+        ldx = Ci
+    assert dw.dtype == torch.float32 and dw.numel() == N * K, (dw.shape, N, K)
+    _lib.call("spg_gemm_tn", dcode(x), _p(_c(dy)), _p(_c(x)), _p(_c(dw)), M, N, K, N, ldx, K, 1 if conv else 0, B, H, W, Ci,
+              _stream())
+
+
+def pack_matrix(src: Tensor, dtype: torch.dtype, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    R, C = src.shape
+    if out is None:
+        out = torch.empty((C, R) if transpose else (R, C), dtype=dtype, device=src.device)
+    _lib.call("spg_pack_matrix", dcode(out), _p(f32(src)), _p(out), R, C, 1 if transpose else 0, _stream())
+    return out
+
+
+def pack_conv3x3(src: Tensor, dtype: torch.dtype, fwd: Optional[Tensor] = None, dgrad: Optional[Tensor] = None):
+    Co, Ci = src.shape[0], src.shape[1]
+    if fwd is None:
+        fwd = torch.empty((Co, 9 * Ci), dtype=dtype, device=src.device)
+    if dgrad is None:
+        dgrad = torch.empty((Ci, 9 * Co), dtype=dtype, device=src.device)
+    _lib.call("spg_pack_conv3x3", dcode(fwd), _p(f32(src)), _p(fwd), _p(dgrad), Co, Ci, _stream())
+    return fwd, dgrad
+
+
+def unpack_conv3x3_grad(packed: Tensor, dst: Tensor) -> None:
+    Co, Ci = dst.shape[0], dst.shape[1]
+    _lib.call("spg_unpack_conv3x3_grad", _p(f32(packed)), _p(f32(dst)), Co, Ci, _stream())
+
+
+# ---- trunk pieces --------------------------------------------------------------------------------------
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.call("spg_layernorm_fwd", dcode(x), _p(_c(x)), _p(f32(gamma)), _p(f32(beta)), _p(y), _p(mean), _p(rstd), M, C, eps,
+              _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,
+                  dres: Optional[Tensor] = None) -> Tensor:
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    _lib.call("spg_layernorm_bwd", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(gamma)), _p(mean), _p(rstd), _p(dres), _p(dx),
+              _p(f32(dgamma)), _p(f32(dbeta)), M, C, _stream())
+    return dx
+
+
+def attn_fwd(qkv: Tensor, bias_t: Tensor, B: int, H: int, W: int, heads: int, hd: int, ws: int,
+             q_pooled: Optional[Tensor] = None):
+    """qkv [B,H,W,3*heads*hd]; returns out [B,Hq,Wq,heads*hd], lse [B,Hq,Wq,heads]."""
+    Hq, Wq = (H // 2, W // 2) if q_pooled is not None else (H, W)
+    out = torch.empty((B, Hq, Wq, heads * hd), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, Hq, Wq, heads), dtype=torch.float32, device=qkv.device)
+    _lib.call("spg_attn_fwd", dcode(qkv), _p(_c(qkv)), _p(q_pooled), _p(_c(bias_t)), _p(out), _p(lse), B, H, W, heads, hd, ws,
+              _stream())
+    return out, lse
+
+
+def attn_bwd(qkv: Tensor, bias_t: Tensor, out: Tensor, dout: Tensor, lse: Tensor, dbias_pad: Tensor, B: int, H: int, W: int,
+             heads: int, hd: int, ws: int, q_pooled: Optional[Tensor] = None):
+    """returns dqkv (q part left untouched when q_pooled is given) and dq_pooled (or None)."""
+    dqkv = torch.empty_like(qkv)
+    dqp = torch.empty_like(q_pooled) if q_pooled is not None else None
+    delta = torch.empty_like(lse)
+    _lib.call("spg_attn_bwd", dcode(qkv), _p(_c(qkv)), _p(q_pooled), _p(_c(bias_t)), _p(_c(out)), _p(_c(dout)), _p(lse),
+              _p(dqkv), _p(dqp), _p(f32(dbias_pad)), _p(delta), B, H, W, heads, hd, ws, _stream())
+    return dqkv, dqp
+
+
+def maxpool2_fwd(x: Tensor, B: int, H: int, W: int, C: int, ldc: int, c0: int):
+    y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    idx = torch.empty((B, H // 2, W // 2, C), dtype=torch.uint8, device=x.device)
+    _lib.call("spg_maxpool2_fwd", dcode(x), _p(_c(x)), _p(y), _p(idx), B, H, W, C, ldc, c0, _stream())
+    return y, idx
+
+
+def maxpool2_bwd(dy: Tensor, idx: Tensor, dx: Tensor, B: int, H: int, W: int, C: int, ldc: int, c0: int) -> None:
+    _lib.call("spg_maxpool2_bwd", dcode(dy), _p(_c(dy)), _p(idx), _p(dx), B, H, W, C, ldc, c0, _stream())
+
+
+def patch_im2col(img: Tensor, dtype: torch.dtype, kpad: int) -> Tensor:
+    B, _, S, _ = img.shape
+    cols = torch.empty((B * (S // 4) ** 2, kpad), dtype=dtype, device=img.device)
+    _lib.call("spg_patch_im2col", dcode(cols), _p(f32(img)), _p(cols), B, S, kpad, _stream())
+    return cols
+
+
+# ---- reductions / elementwise ---------------------------------------------------------------------------
+def colsum(x: Tensor, out: Tensor) -> None:
+    C = x.shape[-1]
+    _lib.call("spg_colsum", dcode(x), _p(_c(x)), _p(f32(out)), x.numel() // C, C, C, _stream())
+
+
+def gap_sum(x: Tensor, B: int, HW: int, C: int) -> Tensor:
+    out = torch.zeros((B, C), dtype=torch.float32, device=x.device)
+    _lib.call("spg_gap_sum", dcode(x), _p(_c(x)), _p(out), B, HW, C, _stream())
+    return out
+
+
+def chan_prod_sum(a: Tensor, b: Tensor, B: int, HW: int, C: int) -> Tensor:
+    out = torch.zeros((B, C), dtype=torch.float32, device=a.device)
+    _lib.call("spg_chan_prod_sum", dcode(a), _p(_c(a)), _p(_c(b)), _p(out), B, HW, C, _stream())
+    return out
+
+
+def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.call("spg_add", dcode(a), _p(_c(a)), _p(_c(b)), _p(out), a.numel(), _stream())
+    return out
+
+
+def copy_channels(x: Tensor, y: Tensor, M: int, C: int, ldx: int, cx0: int, ldy: int, cy0: int, accumulate: bool = False):
+    _lib.call("spg_copy_channels", dcode(x), _p(x), _p(y), M, C, ldx, cx0, ldy, cy0, 1 if accumulate else 0, _stream())
+
+
+# ---- BatchNorm ------------------------------------------------------------------------------------------
+def bn_stats(x: Tensor, C: int) -> Tensor:
+    stats = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+    _lib.call("spg_bn_stats", dcode(x), _p(_c(x)), _p(stats), x.numel() // C, C, _stream())
+    return stats
+
+
+def bn_finalize(stats: Optional[Tensor], gamma: Tensor, beta: Tensor, rmean: Optional[Tensor], rvar: Optional[Tensor], M: int,
+                training: bool, eps: float = 1e-5, momentum: float = 0.1):
+    C = gamma.numel()
+    ss = torch.empty(2 * C, dtype=torch.float32, device=gamma.device)
+    mi = torch.empty(2 * C, dtype=torch.float32, device=gamma.device)
+    _lib.call("spg_bn_finalize", _p(stats), _p(f32(gamma)), _p(f32(beta)), _p(rmean), _p(rvar), _p(ss), _p(mi), M, C, eps, momentum,
+              1 if training else 0, _stream())
+    return ss, mi
+
+
+def bn_apply(x: Tensor, ss: Tensor, C: int, relu: bool, out: Optional[Tensor] = None) -> Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("spg_bn_apply", dcode(x), _p(_c(x)), _p(ss), _p(out), x.numel() // C, C, 1 if relu else 0, _stream())
+    return out
+
+
+def bn_bwd(dy: Tensor, x: Tensor, ss: Tensor, mi: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor, C: int, relu: bool) -> Tensor:
+    M = x.numel() // C
+    sums = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+    _lib.call("spg_bn_bwd_reduce", dcode(x), _p(_c(dy)), _p(_c(x)), _p(ss), _p(mi), _p(sums), M, C, 1 if relu else 0, _stream())
+    dx = torch.empty_like(x)
+    _lib.call("spg_bn_bwd_apply", dcode(x), _p(dy), _p(x), _p(ss), _p(mi), _p(f32(gamma)), _p(sums), _p(dx), _p(f32(dgamma)),
+              _p(f32(dbeta)), M, C, 1 if relu else 0, _stream())
+    return dx
+
+
+# ---- CFI / PED pieces -------------------------------------------------------------------------------------
+def upsample_into(x: Tensor, y: Tensor, B: int, h: int, w: int, C: int, H: int, W: int, ldy: int, c0: int) -> None:
+    _lib.call("spg_upsample_bilinear", dcode(x), _p(_c(x)), _p(y), B, h, w, C, H, W, ldy, c0, _stream())
+
+
+def upsample_bwd(dy: Tensor, dx: Tensor, B: int, h: int, w: int, C: int, H: int, W: int, ldy: int, c0: int, accumulate: bool = False):
+    _lib.call("spg_upsample_bilinear_bwd", dcode(dy), _p(_c(dy)), _p(dx), B, h, w, C, H, W, ldy, c0, 1 if accumulate else 0, _stream())
+
+
+def se_fc(gap: Tensor, w1: Tensor, w2: Tensor):
+    B, C = gap.shape
+    R = w1.shape[0]
+    hidden = torch.empty((B, R), dtype=torch.float32, device=gap.device)
+    scale = torch.empty((B, C), dtype=torch.float32, device=gap.device)
+    _lib.call("spg_se_fc", _p(f32(gap)), _p(f32(w1)), _p(f32(w2)), _p(hidden), _p(scale), B, C, R, _stream())
+    return hidden, scale
+
+
+def se_fc_bwd(gap, w1, w2, hidden, scale, dscale, dw1, dw2) -> Tensor:
+    B, C = gap.shape
+    R = w1.shape[0]
+    dgap = torch.empty_like(gap)
+    _lib.call("spg_se_fc_bwd", _p(gap), _p(f32(w1)), _p(f32(w2)), _p(hidden), _p(scale), _p(f32(dscale)), _p(dgap), _p(f32(dw1)),
+              _p(f32(dw2)), B, C, R, _stream())
+    return dgap
+
+
+def chan_scale(x: Tensor, scale: Tensor, B: int, HW: int, C: int) -> Tensor:
+    y = torch.empty_like(x)
+    _lib.call("spg_chan_scale", dcode(x), _p(_c(x)), _p(scale), _p(y), B, HW, C, _stream())
+    return y
+
+
+def chan_scale_bwd(dy: Tensor, scale: Tensor, dgap: Tensor, B: int, HW: int, C: int) -> Tensor:
+    dx = torch.empty_like(dy)
+    _lib.call("spg_chan_scale_bwd", dcode(dy), _p(_c(dy)), _p(scale), _p(dgap), _p(dx), B, HW, C, _stream())
+    return dx
+
+
+def dwconv3x3(x: Tensor, w: Tensor, B: int, H: int, W: int, C: int, dil: int, flip: bool = False) -> Tensor:
+    y = torch.empty_like(x)
+    _lib.call("spg_dwconv3x3", dcode(x), _p(_c(x)), _p(f32(w)), _p(y), B, H, W, C, dil, 1 if flip else 0, _stream())
+    return y
+
+
+def dwconv3x3_wgrad(dy: Tensor, x: Tensor, dw: Tensor, B: int, H: int, W: int, C: int, dil: int) -> None:
+    _lib.call("spg_dwconv3x3_wgrad", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(dw)), B, H, W, C, dil, _stream())
+
+
+def easpp_fuse(br, glob: Tensor, w: Tensor, B: int, HW: int, C: int) -> Tensor:
+    y = torch.empty_like(br[0])
+    _lib.call("spg_easpp_fuse", dcode(y), _p(br[0]), _p(br[1]), _p(br[2]), _p(br[3]), _p(f32(glob)), _p(f32(w)), _p(y), B, HW, C,
+              _stream())
+    return y
+
+
+def easpp_fuse_bwd(dy: Tensor, br, glob: Tensor, w: Tensor, dw: Tensor, B: int, HW: int, C: int):
+    d = [torch.empty_like(b) for b in br]
+    dglob = torch.zeros_like(glob)
+    _lib.call("spg_easpp_fuse_bwd", dcode(dy), _p(_c(dy)), _p(br[0]), _p(br[1]), _p(br[2]), _p(br[3]), _p(glob), _p(f32(w)),
+              _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(dglob), _p(f32(dw)), B, HW, C, _stream())
+    return d, dglob
+
+
+def head1x1(x: Tensor, w: Tensor, b: Tensor, M: int, C: int) -> Tensor:
+    y = torch.empty(M, dtype=x.dtype, device=x.device)
+    _lib.call("spg_head1x1", dcode(x), _p(_c(x)), _p(f32(w)), _p(f32(b)), _p(y), M, C, _stream())
+    return y
+
+
+def head1x1_bwd(dy: Tensor, x: Tensor, w: Tensor, dx: Tensor, dw: Tensor, db: Tensor, M: int, C: int, accumulate: bool) -> None:
+    _lib.call("spg_head1x1_bwd", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(w)), _p(dx), _p(f32(dw)), _p(f32(db)), M, C,
+              1 if accumulate else 0, _stream())

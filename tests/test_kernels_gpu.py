@@ -1,0 +1,406 @@
+"""GPU parity tests of every C-ABI kernel against plain PyTorch fp32 references of the same op.
+fp32 storage must agree to ~1e-5 (exact-f32 MFMA, only summation order differs); bf16 storage to bf16 rounding."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt, f32=2e-5, bf16=2.5e-2):
+    return f32 if dt == torch.float32 else bf16
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def check(a, b, t, what=""):
+    e = rel(a, b)
+    if not (e < t):
+        d = (a.double().cpu() - b.double().cpu()).abs()
+        idx = torch.nonzero(d > t * b.abs().max().cpu(), as_tuple=False)[:8].tolist()
+        raise AssertionError(f"{what}: rel err {e:.3e} >= {t:.1e}; shape {tuple(a.shape)}; first bad idx {idx}; "
+                             f"got {a.flatten()[:6].tolist()} want {b.flatten()[:6].tolist()}")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from spegnet_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+# ------------------------------------------------------------------------------------------- GEMM NT
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 144), (77, 432, 144), (1000, 576, 2304), (64, 16, 32)])
+def test_gemm_nt_dense(ops, dt, M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    xq, wq = x.to(dt), w.to(dt)
+    ref = xq.float() @ wq.float().t() + b
+    out = ops.gemm_nt(xq, wq, bias=b)
+    check(out.float(), ref, tol(dt), "bias")
+    res = rnd(M, N, seed=4).to(dt)
+    pre = torch.empty(M, N, dtype=dt, device="cuda")
+    out = ops.gemm_nt(xq, wq, bias=b, act=ops.ACT_GELU, residual=res, preact_out=pre)
+    check(pre.float(), ref, tol(dt), "preact")
+    check(out.float(), F.gelu(ref) + res.float(), tol(dt), "gelu+res")
+    h = rnd(M, N, seed=5).to(dt)
+    out = ops.gemm_nt(xq, wq, gelu_h=h)
+    hf = h.float().requires_grad_(True)
+    F.gelu(hf).sum().backward()
+    check(out.float(), (xq.float() @ wq.float().t()) * hf.grad, tol(dt), "gelu'")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_nt_identity_asymmetric(ops, dt):
+    """A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md §3)."""
+    n = 128
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).cuda()  # exactly representable in bf16? use small ints
+    w = (w % 17 - 8)
+    x = torch.eye(n, device="cuda")
+    out = ops.gemm_nt(x.to(dt), w.to(dt))
+    assert torch.equal(out.float(), w.t().contiguous()), "C[m][n] must equal W[n][m] for X = I"
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 9, 7, 16, 24), (1, 16, 16, 64, 64), (2, 12, 12, 40, 136)])
+def test_conv3x3_fwd_dgrad_wgrad(ops, dt, B, H, W, Ci, Co):
+    x = rnd(B, Ci, H, W, seed=1).to(dt).float().requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=(9 * Ci) ** -0.5).to(dt).float().requires_grad_(True)
+    bias = rnd(Co, seed=3)
+    y = F.conv2d(x, w, bias, padding=1)
+    dy = rnd(B, Co, H, W, seed=4).to(dt).float()
+    y.backward(dy)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(dt)
+    wf, wd = ops.pack_conv3x3(w.detach().contiguous(), dt)
+    out = ops.gemm_nt(xn, wf, bias=bias, conv=(B, H, W, Ci)).view(B, H, W, Co)
+    check(out.float().permute(0, 3, 1, 2), y.detach(), tol(dt), "conv fwd")
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(dt)
+    dx = ops.gemm_nt(dyn, wd, conv=(B, H, W, Co)).view(B, H, W, Ci)
+    check(dx.float().permute(0, 3, 1, 2), x.grad, tol(dt), "conv dgrad")
+    dwp = torch.zeros(Co, 9 * Ci, device="cuda")
+    ops.gemm_tn(dyn, xn, dwp, conv=(B, H, W, Ci))
+    dwt = torch.empty(Co, Ci, 3, 3, device="cuda")
+    ops.unpack_conv3x3_grad(dwp, dwt)
+    check(dwt, w.grad, tol(dt), "conv wgrad")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 200, 144), (4608, 576, 288), (50, 16, 32)])
+def test_gemm_tn(ops, dt, M, N, K):
+    dy, x = rnd(M, N, seed=1).to(dt), rnd(M, K, seed=2).to(dt)
+    dw = torch.zeros(N, K, device="cuda")
+    ops.gemm_tn(dy, x, dw)
+    check(dw, dy.float().t() @ x.float(), tol(dt, 2e-5, 1e-2), "tn")
+    ops.gemm_tn(dy, x, dw)  # accumulates
+    check(dw, 2 * (dy.float().t() @ x.float()), tol(dt, 2e-5, 1e-2), "tn accumulate")
+
+
+def test_pack_matrix(ops):
+    w = rnd(37, 53, seed=1)
+    assert torch.equal(ops.pack_matrix(w, torch.float32), w)
+    assert torch.equal(ops.pack_matrix(w, torch.float32, transpose=True), w.t().contiguous())
+    assert torch.equal(ops.pack_matrix(w, torch.bfloat16, transpose=True), w.t().contiguous().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,C", [(100, 144), (37, 1152), (64, 16), (513, 576)])
+def test_layernorm(ops, dt, M, C):
+    x = rnd(M, C, seed=1).to(dt)
+    g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    xf = x.float().requires_grad_(True)
+    gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xf, (C,), gf, bf, 1e-6)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+    check(y.float(), ref.detach(), tol(dt, 2e-5, 1e-2), "ln fwd")
+    dy = rnd(M, C, seed=4).to(dt)
+    dres = rnd(M, C, seed=5).to(dt)
+    ref.backward(dy.float())
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres)
+    check(dx.float(), xf.grad + dres.float(), tol(dt, 5e-5, 2e-2), "ln dx")
+    check(dg, gf.grad, tol(dt, 5e-5, 2e-2), "ln dgamma")
+    check(db, bf.grad, tol(dt, 5e-5, 2e-2), "ln dbeta")
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attn_reference(qkv, bias, B, H, W, heads, hd, ws, pooled):
+    """The reference block's attention on an explicit zero-padded, partitioned map (sam2 Hiera semantics):
+    padded tokens carry qkv == bias.  qkv: [B,H,W,3C] float (requires_grad ok).  Returns [B,Hq,Wq,C]."""
+    C = heads * hd
+    if ws <= 0:
+        ws_, Hp, Wp = 0, H, W
+        x = qkv
+    else:
+        ws_ = ws
+        ph, pw = (-H) % ws, (-W) % ws
+        Hp, Wp = H + ph, W + pw
+        x = bias.view(1, 1, 1, 3 * C).expand(B, Hp, Wp, 3 * C).clone()
+        x[:, :H, :W] = qkv
+    if ws_ > 0:
+        x = x.view(B, Hp // ws, ws, Wp // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, 3 * C)
+    Bw, h, w = x.shape[0], x.shape[1], x.shape[2]
+    q, k, v = x.reshape(Bw, h * w, 3, heads, hd).unbind(2)
+    if pooled:
+        q = F.max_pool2d(q.reshape(Bw, h, w, C).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+        h, w = h // 2, w // 2
+        q = q.reshape(Bw, h * w, heads, hd)
+    att = (q.transpose(1, 2) * hd ** -0.5) @ k.transpose(1, 2).transpose(-2, -1)
+    o = (att.softmax(-1) @ v.transpose(1, 2)).transpose(1, 2).reshape(Bw, h, w, C)
+    if ws_ > 0:
+        wq = ws // 2 if pooled else ws
+        Hq, Wq = (Hp // 2, Wp // 2) if pooled else (Hp, Wp)
+        o = o.view(B, Hq // wq, Wq // wq, wq, wq, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hq, Wq, C)
+        Ho, Wo = (H // 2, W // 2) if pooled else (H, W)
+        o = o[:, :Ho, :Wo]
+    return o
+
+
+ATTN_CASES = [
+    # B, H, W, heads, hd, ws, pooled
+    (2, 8, 8, 2, 16, 8, False),
+    (2, 8, 8, 2, 16, 4, False),
+    (1, 12, 12, 2, 16, 8, False),    # padded windows
+    (2, 10, 10, 1, 16, 0, False),    # global, 100 tokens (2 key tiles)
+    (2, 8, 8, 2, 16, 8, True),       # pooled queries
+    (1, 12, 12, 2, 16, 8, True),     # pooled + padded
+    (1, 24, 24, 2, 72, 16, False),   # the stage-3 configuration of Hiera-L @384
+    (1, 24, 24, 1, 72, 0, False),    # global block @384 (576 tokens)
+    (1, 24, 24, 2, 72, 16, True),    # block 44 style transition
+    (1, 12, 12, 2, 72, 8, False),    # stage 4 @384
+    (1, 6, 6, 2, 32, 4, False),
+]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_attention(ops, dt, case):
+    B, H, W, heads, hd, ws, pooled = case
+    C = heads * hd
+    qkv = rnd(B, H, W, 3 * C, seed=1).to(dt)
+    bias = (0.5 * rnd(3 * C, seed=2)).to(dt)
+    qf = qkv.float().requires_grad_(True)
+    bf = bias.float().requires_grad_(True)
+    ref = attn_reference(qf, bf, B, H, W, heads, hd, ws, pooled)
+    qp = idx = None
+    if pooled:
+        qp, idx = ops.maxpool2_fwd(qkv, B, H, W, C, 3 * C, 0)
+    out, lse = ops.attn_fwd(qkv, bias, B, H, W, heads, hd, ws, q_pooled=qp)
+    check(out.float(), ref.detach(), tol(dt, 3e-5, 2e-2), "attn fwd")
+    dout = rnd(*ref.shape, seed=3).to(dt)
+    ref.backward(dout.float())
+    dbias = torch.zeros(3 * C, device="cuda")
+    dqkv, dqp = ops.attn_bwd(qkv, bias, out, dout, lse, dbias, B, H, W, heads, hd, ws, q_pooled=qp)
+    if pooled:
+        ops.maxpool2_bwd(dqp, idx, dqkv, B, H, W, C, 3 * C, 0)
+    check(dqkv.float(), qf.grad, tol(dt, 1e-4, 3e-2), "attn dqkv")
+    # bias gradient THROUGH PADDING only (the dense part is the colsum of dqkv, tested elsewhere)
+    want = bf.grad
+    if float(want.abs().max()) > 0:
+        check(dbias[C:], want[C:], tol(dt, 1e-4, 3e-2), "attn dbias(pad) k,v")
+    else:
+        assert float(dbias.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- pooling / resize
+@pytest.mark.parametrize("dt", DT)
+def test_maxpool2(ops, dt):
+    B, H, W, C, ld, c0 = 2, 6, 8, 16, 48, 16
+    x = rnd(B, H, W, ld, seed=1).to(dt)
+    y, idx = ops.maxpool2_fwd(x, B, H, W, C, ld, c0)
+    xs = x[..., c0:c0 + C].float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.max_pool2d(xs, 2, 2)
+    assert torch.equal(y.float(), ref.detach().permute(0, 2, 3, 1))
+    dy = rnd(B, H // 2, W // 2, C, seed=2).to(dt)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    dx = torch.full((B, H, W, ld), 7.0, device="cuda").to(dt)
+    ops.maxpool2_bwd(dy, idx, dx, B, H, W, C, ld, c0)
+    assert torch.equal(dx[..., c0:c0 + C].float(), xs.grad.permute(0, 2, 3, 1))
+    assert float((dx[..., :c0].float() - 7).abs().max()) == 0  # untouched outside the window
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("h,w,s", [(6, 5, 2), (4, 4, 4), (3, 7, 8), (5, 5, 1)])
+def test_upsample_bilinear(ops, dt, h, w, s):
+    B, C, ld, c0 = 2, 16, 40, 16
+    H, W = h * s, w * s
+    x = rnd(B, h, w, C, seed=1).to(dt)
+    xs = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.interpolate(xs, size=(H, W), mode="bilinear", align_corners=False)
+    y = torch.zeros(B, H, W, ld, device="cuda").to(dt)
+    ops.upsample_into(x, y, B, h, w, C, H, W, ld, c0)
+    check(y[..., c0:c0 + C].float(), ref.detach().permute(0, 2, 3, 1), tol(dt, 1e-6, 8e-3), "upsample")
+    assert float(y[..., :c0].abs().max()) == 0
+    dy = rnd(B, H, W, ld, seed=2).to(dt)
+    ref.backward(dy[..., c0:c0 + C].float().permute(0, 3, 1, 2))
+    dx = torch.empty(B, h, w, C, device="cuda").to(dt)
+    ops.upsample_bwd(dy, dx, B, h, w, C, H, W, ld, c0)
+    check(dx.float(), xs.grad.permute(0, 2, 3, 1), tol(dt, 1e-5, 1e-2), "upsample bwd")
+    ops.upsample_bwd(dy, dx, B, h, w, C, H, W, ld, c0, accumulate=True)
+    check(dx.float(), 2 * xs.grad.permute(0, 2, 3, 1), tol(dt, 1e-5, 2e-2), "upsample bwd acc")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_patch_embed(ops, dt):
+    B, S, D, KP = 2, 32, 48, 160
+    img = rnd(B, 3, S, S, seed=1)
+    w, b = rnd(D, 3, 7, 7, seed=2, scale=0.08), rnd(D, seed=3)
+    cols = ops.patch_im2col(img, dt, KP)
+    wp = torch.zeros(D, KP, device="cuda")
+    wp[:, :147] = w.reshape(D, 147)
+    out = ops.gemm_nt(cols, wp.to(dt), bias=b).view(B, S // 4, S // 4, D)
+    ref = F.conv2d(img.to(dt).float(), w.to(dt).float(), b, stride=4, padding=3)
+    check(out.float().permute(0, 3, 1, 2), ref, tol(dt), "patch embed")
+
+
+# ------------------------------------------------------------------------------------------- BatchNorm
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,C,relu", [(500, 64, True), (2304, 512, True), (4, 128, True), (1000, 16, False)])
+def test_batchnorm_train(ops, dt, M, C, relu):
+    x = (rnd(M, C, seed=1) * 1.5 + 0.3).to(dt)
+    g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    rm, rv = 0.1 * rnd(C, seed=4), 1 + 0.1 * rnd(C, seed=5).abs()
+    xf = x.float().requires_grad_(True)
+    gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(xf.t()[None], rm_ref, rv_ref, gf, bf, True, 0.1, 1e-5)[0].t()
+    if relu:
+        ref = F.relu(ref)
+    stats = ops.bn_stats(x, C)
+    ss, mi = ops.bn_finalize(stats, g, b, rm, rv, M, True)
+    y = ops.bn_apply(x, ss, C, relu)
+    check(y.float(), ref.detach(), tol(dt, 3e-5, 1.5e-2), "bn y")
+    check(rm, rm_ref, 1e-5, "running mean")
+    check(rv, rv_ref, 1e-4, "running var")
+    dy = rnd(M, C, seed=6).to(dt)
+    ref.backward(dy.float())
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ops.bn_bwd(dy, x, ss, mi, g, dg, db, C, relu)
+    check(dx.float(), xf.grad, tol(dt, 2e-4, 3e-2), "bn dx")
+    check(dg, gf.grad, tol(dt, 1e-4, 3e-2), "bn dgamma")
+    check(db, bf.grad, tol(dt, 1e-4, 3e-2), "bn dbeta")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_batchnorm_eval(ops, dt):
+    M, C = 300, 64
+    x = rnd(M, C, seed=1).to(dt)
+    g, b, rm, rv = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4), 1 + 0.1 * rnd(C, seed=5).abs()
+    ss, _ = ops.bn_finalize(None, g, b, rm, rv, M, False)
+    y = ops.bn_apply(x, ss, C, True)
+    ref = F.relu(F.batch_norm(x.float().t()[None], rm, rv, g, b, False, 0.1, 1e-5)[0].t())
+    check(y.float(), ref, tol(dt, 1e-5, 1e-2), "bn eval")
+
+
+# ------------------------------------------------------------------------------------------- CFI pieces
+@pytest.mark.parametrize("dt", DT)
+def test_se_block(ops, dt):
+    B, HW, C, R = 3, 36, 64, 32
+    x = rnd(B, HW, C, seed=1).to(dt)
+    w1, w2 = rnd(R, C, seed=2, scale=0.2), rnd(C, R, seed=3, scale=0.3)
+    xf = x.float().requires_grad_(True)
+    w1f, w2f = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    gap_ref = xf.mean(1)
+    s_ref = torch.sigmoid(F.linear(F.relu(F.linear(gap_ref, w1f)), w2f))
+    ref = xf * s_ref[:, None]
+    gap = ops.gap_sum(x, B, HW, C) / HW
+    hidden, scale = ops.se_fc(gap, w1, w2)
+    y = ops.chan_scale(x, scale, B, HW, C)
+    check(y.float(), ref.detach(), tol(dt, 1e-5, 1e-2), "se fwd")
+    dy = rnd(B, HW, C, seed=4).to(dt)
+    ref.backward(dy.float())
+    dscale = ops.chan_prod_sum(dy, x, B, HW, C)
+    dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+    dgap = ops.se_fc_bwd(gap, w1, w2, hidden, scale, dscale, dw1, dw2)
+    dx = ops.chan_scale_bwd(dy, scale, dgap, B, HW, C)
+    check(dx.float(), xf.grad, tol(dt, 1e-4, 2e-2), "se dx")
+    check(dw1, w1f.grad, tol(dt, 1e-4, 3e-2), "se dw1")
+    check(dw2, w2f.grad, tol(dt, 1e-4, 3e-2), "se dw2")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("dil", [1, 6, 18])
+def test_dwconv(ops, dt, dil):
+    B, H, W, C = 2, 13, 11, 32
+    x = rnd(B, H, W, C, seed=1).to(dt)
+    w = rnd(C, 1, 3, 3, seed=2, scale=0.3)
+    xs = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wf = w.clone().requires_grad_(True)
+    ref = F.conv2d(xs, wf, padding=dil, dilation=dil, groups=C)
+    y = ops.dwconv3x3(x, w.view(C, 9), B, H, W, C, dil)
+    check(y.float(), ref.detach().permute(0, 2, 3, 1), tol(dt, 1e-5, 1e-2), "dw fwd")
+    dy = rnd(B, H, W, C, seed=3).to(dt)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    dx = ops.dwconv3x3(dy, w.view(C, 9), B, H, W, C, dil, flip=True)
+    check(dx.float(), xs.grad.permute(0, 2, 3, 1), tol(dt, 1e-5, 1e-2), "dw dx")
+    dw = torch.zeros(C, 9, device="cuda")
+    ops.dwconv3x3_wgrad(dy, x, dw, B, H, W, C, dil)
+    check(dw, wf.grad.view(C, 9), tol(dt, 1e-4, 2e-2), "dw dw")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_easpp_fuse(ops, dt):
+    B, HW, C = 2, 30, 32
+    br = [rnd(B * HW, C, seed=i).to(dt) for i in range(4)]
+    glob = rnd(B, C, seed=9)
+    w = rnd(C, 5, seed=10, scale=0.4)
+    brf = [b.float().requires_grad_(True) for b in br]
+    gf, wf = glob.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    cat = torch.cat([b.view(B, HW, C) for b in brf] + [gf[:, None].expand(B, HW, C)], -1)  # branch-major
+    ref = F.conv2d(cat.permute(0, 2, 1)[..., None], wf.view(C, 5, 1, 1), groups=C)[..., 0].permute(0, 2, 1)
+    y = ops.easpp_fuse(br, glob, w, B, HW, C)
+    check(y.float().view(B, HW, C), ref.detach(), tol(dt, 1e-5, 1e-2), "fuse fwd")
+    dy = rnd(B * HW, C, seed=11).to(dt)
+    ref.backward(dy.float().view(B, HW, C))
+    dw = torch.zeros_like(w)
+    d, dglob = ops.easpp_fuse_bwd(dy, br, glob, w, dw, B, HW, C)
+    for i in range(4):
+        check(d[i].float(), brf[i].grad, tol(dt, 1e-5, 1e-2), f"fuse d{i}")
+    check(dglob, gf.grad, tol(dt, 1e-4, 2e-2), "fuse dglob")
+    check(dw, wf.grad, tol(dt, 1e-4, 2e-2), "fuse dw")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C", [64, 128, 256, 16])
+def test_head1x1(ops, dt, C):
+    M = 1000
+    x = rnd(M, C, seed=1).to(dt)
+    w, b = rnd(C, seed=2, scale=0.2), rnd(1, seed=3)
+    xf, wf, bf = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = xf @ wf + bf
+    y = ops.head1x1(x, w, b, M, C)
+    check(y.float(), ref.detach(), tol(dt, 1e-5, 1e-2), "head fwd")
+    dy = rnd(M, seed=4).to(dt)
+    ref.backward(dy.float())
+    dx = rnd(M, C, seed=5).to(dt)
+    base = dx.float().clone()
+    dw, db = torch.zeros(C, device="cuda"), torch.zeros(1, device="cuda")
+    ops.head1x1_bwd(dy, x, w, dx, dw, db, M, C, accumulate=True)
+    check(dx.float(), base + xf.grad, tol(dt, 1e-5, 1.5e-2), "head dx")
+    check(dw, wf.grad, tol(dt, 1e-4, 2e-2), "head dw")
+    check(db, bf.grad, tol(dt, 1e-4, 2e-2), "head db")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_small_utils(ops, dt):
+    M, C = 333, 48
+    x = rnd(M, C, seed=1).to(dt)
+    out = torch.zeros(C, device="cuda")
+    ops.colsum(x, out)
+    check(out, x.float().sum(0), tol(dt, 1e-5, 1e-5), "colsum")
+    y = torch.zeros(M, 80, device="cuda").to(dt)
+    ops.copy_channels(x, y, M, 16, C, 16, 80, 32)
+    assert torch.equal(y[:, 32:48], x[:, 16:32]) and float(y[:, :32].abs().max()) == 0
+    a, b = rnd(64, 40, seed=2).to(dt), rnd(64, 40, seed=3).to(dt)
+    check(ops.add(a, b).float(), a.float() + b.float(), tol(dt, 1e-7, 8e-3), "add")
