@@ -49,7 +49,7 @@ int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, int M, int 
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
  * spg_pack_matrix: dst[r][c] = src[r][c] (transpose=0) or dst[c][r] = src[r][c] (transpose=1), src f32 [R,C].
  * spg_pack_conv3x3: torch [Co,Ci,3,3] f32 -> fwd pack [Co][tap][Ci] and dgrad pack [Ci][tap'][Co] (tap' flipped).
- * spg_unpack_conv3x3_grad: packed f32 grad [Co][tap][Ci] -> torch layout [Co,Ci,3,3] (+= if accumulate). */
+ * spg_unpack_conv3x3_grad: packed f32 grad [Co][tap][Ci] -> torch layout [Co,Ci,3,3] (accumulates: dst += packed). */
 int spg_pack_matrix(int dtype, const float* src, void* dst, int R, int C, int transpose, spg_stream_t stream);
 int spg_pack_conv3x3(int dtype, const float* src, void* dst_fwd, void* dst_dgrad, int Co, int Ci, spg_stream_t stream);
 int spg_unpack_conv3x3_grad(const float* packed, float* dst, int Co, int Ci, spg_stream_t stream);

@@ -399,7 +399,7 @@ __global__ void unpack_conv3x3_grad_kernel(const float* __restrict__ packed, flo
     const int tap = (int)(i % 9);
     const long t = i / 9;
     const int ci = (int)(t % Ci), co = (int)(t / Ci);
-    dst[i] = packed[((long)co * 9 + tap) * Ci + ci];
+    dst[i] += packed[((long)co * 9 + tap) * Ci + ci];
   }
 }
 

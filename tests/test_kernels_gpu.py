@@ -90,7 +90,7 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dt, B, H, W, Ci, Co):
     check(dx.float().permute(0, 3, 1, 2), x.grad, tol(dt), "conv dgrad")
     dwp = torch.zeros(Co, 9 * Ci, device="cuda")
     ops.gemm_tn(dyn, xn, dwp, conv=(B, H, W, Ci))
-    dwt = torch.empty(Co, Ci, 3, 3, device="cuda")
+    dwt = torch.zeros(Co, Ci, 3, 3, device="cuda")
     ops.unpack_conv3x3_grad(dwp, dwt)
     check(dwt, w.grad, tol(dt), "conv wgrad")
 
@@ -207,7 +207,7 @@ def test_attention(ops, dt, case):
     check(dqkv.float(), qf.grad, tol(dt, 1e-4, 3e-2), "attn dqkv")
     # bias gradient THROUGH PADDING only (the dense part is the colsum of dqkv, tested elsewhere)
     want = bf.grad
-    if float(want.abs().max()) > 0:
+    if want is not None and float(want.abs().max()) > 0:
         check(dbias[C:], want[C:], tol(dt, 1e-4, 3e-2), "attn dbias(pad) k,v")
     else:
         assert float(dbias.abs().max()) == 0.0
