@@ -147,6 +147,15 @@ int spg_head1x1(int dtype, const void* x, const float* w, const float* b, void* 
 int spg_head1x1_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, long M,
                     int C, int accumulate, spg_stream_t stream);
 
+/* ---- optimizer (engine/trainer.py:274-306 param groups, :399-409 clip + AdamW step) over a flat f32 arena ---------
+ * sumsq: out[0] += sum x^2.  adamw: step_f[0] += 1, then clip coefficient min(1, clip/(sqrt(gnorm_sq)*grad_scale+1e-6))
+ * and a decoupled-weight-decay Adam update; group_of_chunk[i/256] selects lr[g], wd[g] (device arrays, so the
+ * scheduler can change them without re-capturing a hipGraph).  Every parameter starts on a 256-element boundary.  */
+int spg_sumsq(const float* x, float* out, long n, spg_stream_t stream);
+int spg_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,
+              const float* wd, const float* gnorm_sq, float* step_f, float clip, float beta1, float beta2, float eps,
+              float grad_scale, long n, spg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,8 +356,16 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
 
 extern "C" int spg_colsum(int dtype, const void* x, float* out, int M, int C, int ldx, spg_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM>(x, nullptr, nullptr, nullptr, out, M, C, ldx, 0, 0, 0, s, "colsum")),
-                    (launch_colreduce<float, RED_SUM>(x, nullptr, nullptr, nullptr, out, M, C, ldx, 0, 0, 0, s, "colsum")));
+  const int vec = dtype == SPG_BF16 ? 8 : 4;
+  const int step = 256 * vec;  // columns per launch
+  for (int c0 = 0; c0 < C; c0 += step) {
+    const int cs = C - c0 < step ? C - c0 : step;
+    const char* xp = (const char*)x + (size_t)c0 * (dtype == SPG_BF16 ? 2 : 4);
+    int rc = DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM>(xp, nullptr, nullptr, nullptr, out + c0, M, cs, ldx, 0, 0, 0, s, "colsum")),
+                        (launch_colreduce<float, RED_SUM>(xp, nullptr, nullptr, nullptr, out + c0, M, cs, ldx, 0, 0, 0, s, "colsum")));
+    if (rc) return rc;
+  }
+  return SPG_OK;
 }
 
 extern "C" int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, spg_stream_t stream) {

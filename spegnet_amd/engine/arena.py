@@ -1,0 +1,107 @@
+"""Flat fp32 parameter / gradient arena and the fused optimizer step over it.
+
+Parameters are laid out in the order their gradients become final during backward (head first, then trunk
+blocks last-to-first, then patch/pos embedding), each starting on a 256-element boundary.  That gives
+  * one memset to clear gradients, one kernel for the global grad norm, one kernel for AdamW;
+  * contiguous, in-order-ready ranges for the bucketed RCCL all-reduce (engine/distributed.py).
+Group rules follow Trainer._get_param_groups (reference engine/trainer.py:274-306), including its quirk that BN
+layers inside nn.Sequential (no 'bn'/'norm' in the name) do receive weight decay.
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, List, Tuple
+
+import torch
+
+from .. import _lib
+
+ALIGN = 256
+
+
+def backward_order(names: List[str]) -> List[str]:
+    def key(n: str):
+        if not n.startswith("encoder."):
+            return (0, 0)
+        m = re.search(r"blocks\.(\d+)\.", n)
+        if m:
+            return (1, -int(m.group(1)))
+        return (2, 0)
+    return sorted(names, key=key)  # stable: keeps definition order inside a unit
+
+
+def group_of(name: str) -> int:
+    norm = ('norm' in name) or ('bn' in name)
+    if 'encoder' in name:
+        return 1 if norm else 0
+    return 3 if norm else 2
+
+
+class Arena:
+    def __init__(self, model: torch.nn.Module):
+        params: Dict[str, torch.nn.Parameter] = dict(model.named_parameters())
+        self.names = backward_order(list(params.keys()))
+        dev = next(iter(params.values())).device
+        offs, off = {}, 0
+        for n in self.names:
+            offs[n] = off
+            off += (params[n].numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.size = off
+        self.offsets = offs
+        self.p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(off, dtype=torch.float32, device=dev)
+        groups = torch.zeros(off // ALIGN, dtype=torch.uint8)
+        for n in self.names:
+            prm = params[n]
+            k = prm.numel()
+            o = offs[n]
+            self.p[o:o + k].copy_(prm.data.reshape(-1))
+            prm.data = self.p[o:o + k].view(prm.shape)
+            prm.grad = self.g[o:o + k].view(prm.shape)
+            groups[o // ALIGN:(o + k + ALIGN - 1) // ALIGN] = group_of(n)
+        self.group_of_chunk = groups.to(dev)
+        # unit boundaries (end offsets) in readiness order: head, block L-1, ..., block 0, embeddings
+        self.unit_ends: List[int] = []
+        prev_key = None
+        for n in self.names:
+            m = re.search(r"blocks\.(\d+)\.", n) if n.startswith("encoder.") else None
+            key = ("head",) if not n.startswith("encoder.") else (("blk", m.group(1)) if m else ("emb",))
+            if prev_key is not None and key != prev_key:
+                self.unit_ends.append(offs[n])
+            prev_key = key
+        self.unit_ends.append(off)
+        self.m = self.v = None
+        self.step_f = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.lr = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.wd = torch.zeros(4, dtype=torch.float32, device=dev)
+
+    def reattach(self, model: torch.nn.Module):
+        """Restore .grad views (e.g. after optimizer.zero_grad(set_to_none=True))."""
+        for n, prm in model.named_parameters():
+            o, k = self.offsets[n], prm.numel()
+            prm.grad = self.g[o:o + k].view(prm.shape)
+
+    def set_hyper(self, base_lr: float, weight_decay: float, encoder_lr_ratio: float):
+        self.lr.copy_(torch.tensor([base_lr * encoder_lr_ratio, base_lr * encoder_lr_ratio, base_lr, base_lr]))
+        self.wd.copy_(torch.tensor([0.0, 0.0, weight_decay, 0.0]))
+
+    def scale_lr(self, factor: float, min_lr: float):
+        self.lr.copy_(torch.clamp(self.lr * factor, min=min_lr))
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        if self.m is None:
+            self.m = torch.zeros_like(self.p)
+            self.v = torch.zeros_like(self.p)
+        s = torch.cuda.current_stream().cuda_stream
+        self.gnorm_sq.zero_()
+        _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, s)
+        _lib.call("spg_adamw", self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                  self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
+                  self.step_f.data_ptr(), float(clip), betas[0], betas[1], eps, float(grad_scale), self.size, s)
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "step": self.step_f.clone(), "lr": self.lr.clone(), "wd": self.wd.clone()}

@@ -1,0 +1,102 @@
+"""Data-parallel gradient synchronisation: one process per GPU, RCCL (torch.distributed backend "nccl" on ROCm)
+over xGMI.  The reference is single-GPU (no distributed code at all); SURVEY.md §8(e) defines this row.
+
+The image batch shards naturally: every rank runs the same step on its own images (BatchNorm statistics stay
+per-rank, as in stock DDP).  The only collective is the gradient sum: the flat gradient arena (engine/arena.py)
+is ordered by backward-completion, so as soon as the head / a trunk block has finished its backward, the
+contiguous range that just became final is all-reduced on a side stream while the next block's backward runs on
+the compute stream.  Buckets are >= `bucket_mb` so each collective is large enough to spread over the 7 xGMI
+links; the optimizer then applies 1/world_size through its grad_scale (no extra pass over the gradients).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, int]:
+    """(rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def make_buckets(unit_ends: List[int], bucket_elems: int) -> List[Tuple[int, int]]:
+    """Greedy grouping of consecutive units into buckets of at least `bucket_elems` elements (last may be smaller)."""
+    buckets, start = [], 0
+    for e in unit_ends:
+        if e - start >= bucket_elems:
+            buckets.append((start, e))
+            start = e
+    if start < unit_ends[-1]:
+        buckets.append((start, unit_ends[-1]))
+    return buckets
+
+
+class GradSync:
+    def __init__(self, grad_flat: torch.Tensor, unit_ends: List[int], bucket_mb: float = 48.0, group=None,
+                 compress_bf16: bool = False):
+        self.g = grad_flat
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.group = group
+        self.buckets = make_buckets(unit_ends, int(bucket_mb * 1024 * 1024 / 4))
+        self.compress = compress_bf16
+        self.cuda = grad_flat.is_cuda
+        self.stream = torch.cuda.Stream() if self.cuda else None
+        self._next = 0
+        self._works = []
+        self._tmp = {}
+
+    def reset(self):
+        self._next = 0
+        self._works = []
+
+    def ready(self, upto: int):
+        """Gradients in [0, upto) are final: launch every not-yet-launched bucket that ends at or before `upto`."""
+        if self.world == 1:
+            return
+        while self._next < len(self.buckets) and self.buckets[self._next][1] <= upto:
+            s, e = self.buckets[self._next]
+            self._next += 1
+            self._launch(s, e)
+
+    def _launch(self, s: int, e: int):
+        view = self.g[s:e]
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                if self.compress:
+                    tmp = self._tmp.get((s, e))
+                    if tmp is None:
+                        tmp = self._tmp[(s, e)] = torch.empty(e - s, dtype=torch.bfloat16, device=view.device)
+                    tmp.copy_(view)
+                    dist.all_reduce(tmp, group=self.group)
+                    view.copy_(tmp)
+                else:
+                    dist.all_reduce(view, group=self.group)
+        else:
+            self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
+
+    def finish(self):
+        """All buckets launched and complete w.r.t. the current stream; returns the grad scale 1/world."""
+        if self.world > 1:
+            self.ready(self.buckets[-1][1])
+            if self.cuda:
+                torch.cuda.current_stream().wait_stream(self.stream)
+            else:
+                for w in self._works:
+                    w.wait()
+        self.reset()
+        return 1.0 / self.world

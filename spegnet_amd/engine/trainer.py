@@ -1,0 +1,253 @@
+"""Training entry points for the MI355X path, mirroring the reference's engine/trainer.py surface:
+`Trainer(config, dir_manager, device)`, `.train(dataset_dirs)`, `.train_epoch(loader, epoch)`,
+`.validate(loader)`, `._process_batch(batch, is_train)` (reference engine/trainer.py:201-606).
+
+What differs by design (MI355X-first):
+  * mixed precision is bf16 compute with fp32 master weights and NO GradScaler (`use_amp: true` -> bf16,
+    false -> fp32 parity mode); the reference's fp16 autocast + GradScaler is a CUDA policy, not the algorithm;
+  * optimizer = fused global-norm clip + AdamW over a flat arena with the reference's 4 parameter groups;
+  * the fixed-shape step can be captured into one hipGraph (`TrainStep(capture=True)`);
+  * data parallelism over RCCL is built in (engine/distributed.py) -- the reference is single-GPU.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from ..models.spegnet import SPEGNet
+from ..utils.loss_functions import CODLoss
+from .arena import Arena
+from .distributed import GradSync
+
+logger = logging.getLogger(__name__)
+
+
+class TrainStep:
+    """One optimisation step on fixed-shape device tensors: forward, CODLoss, backward, (all-reduce), clip+AdamW,
+    weight re-pack.  With capture=True the whole step is recorded once into a hipGraph and replayed."""
+
+    def __init__(self, model: SPEGNet, criterion: CODLoss, arena: Arena, grad_clip: float = 1.0, sync: Optional[GradSync] = None,
+                 capture: bool = False):
+        self.model, self.criterion, self.arena, self.clip, self.sync = model, criterion, arena, grad_clip, sync
+        self.capture = capture
+        self.graph = None
+        self.static = None
+        self.losses = None
+        if sync is not None:
+            ends = arena.unit_ends
+            model.engine.unit_cb = lambda k: sync.ready(ends[k])
+
+    def _eager(self, images, masks, edges):
+        model, arena = self.model, self.arena
+        arena.zero_grad()
+        out = model(images)
+        losses = self.criterion.forward_batched(out['predictions'], out['edge'], masks, edges)
+        losses['loss'].backward()
+        scale = self.sync.finish() if self.sync is not None else 1.0
+        arena.step(self.clip, grad_scale=scale)
+        eng = model._engine
+        eng.pack()  # compute-dtype copies for the next forward (kept inside the step so it is captured too)
+        return {k: v.detach() for k, v in losses.items()}
+
+    def __call__(self, images: torch.Tensor, masks: torch.Tensor, edges: torch.Tensor) -> Dict[str, torch.Tensor]:
+        model = self.model
+        model.train()
+        _ = model.engine  # make sure weights are packed before the first step
+        if not self.capture:
+            return self._eager(images, masks, edges)
+        if self.graph is None:
+            self.static = (images.clone(), masks.clone(), edges.clone())
+            # warm-up must not advance training: snapshot every piece of state the step mutates, restore after
+            ar = self.arena
+            if ar.m is None:
+                ar.m, ar.v = torch.zeros_like(ar.p), torch.zeros_like(ar.p)
+            keep = [t for t in (ar.p, ar.m, ar.v, ar.step_f)] + list(model.buffers())
+            snap = [t.clone() for t in keep]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):        # warm-up on a side stream (allocator + lazy init), as torch requires
+                for _i in range(2):
+                    self._eager(*self.static)
+            torch.cuda.current_stream().wait_stream(side)
+            for t, c in zip(keep, snap):
+                t.copy_(c)
+            model._engine.pack()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.losses = self._eager(*self.static)
+        for dst, src in zip(self.static, (images, masks, edges)):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.losses
+
+
+class TrainingMonitor:
+    """Running means + best-model bookkeeping (reference engine/trainer.py:42-199, JSON written atomically)."""
+
+    def __init__(self, dir_manager=None):
+        self.dir_manager = dir_manager
+        self.history: List[Dict] = []
+        self.best = -1.0
+        self._sums: Dict[str, float] = {}
+        self._n = 0
+
+    def update_batch(self, metrics: Dict[str, torch.Tensor], n: int):
+        for k, v in metrics.items():
+            self._sums[k] = self._sums.get(k, 0.0) + float(v) * n
+        self._n += n
+
+    def end_epoch(self, epoch: int, phase: str) -> Dict[str, float]:
+        m = {k: v / max(self._n, 1) for k, v in self._sums.items()}
+        self.history.append({"epoch": epoch, "phase": phase, **m})
+        self._sums, self._n = {}, 0
+        if self.dir_manager is not None and hasattr(self.dir_manager, "run_dir"):
+            path = os.path.join(str(self.dir_manager.run_dir), "metrics.json")
+            tmp = path + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump(self.history, f)
+            os.replace(tmp, path)
+        return m
+
+
+class Trainer:
+    def __init__(self, config: Dict, dir_manager, device: torch.device):
+        self.config = config['training']
+        self.model_config = dict(config['model'])
+        self.device = torch.device(device)
+        self.use_amp = self.config.get('use_amp', True)
+        self.model_config.setdefault('compute_dtype', 'bf16' if self.use_amp else 'fp32')
+        self.model = SPEGNet(self.model_config).to(self.device)
+        self.batch_size = self.config['batch_size']
+        self.num_epochs = self.config['num_epochs']
+        self.grad_clip = self.config.get('gradient_clip', 1.0)
+        self.early_stop_patience = self.config.get('early_stop_patience', 15)
+        self.save_freq = self.config.get('save_freq', 1)
+        self.dir_manager = dir_manager
+        self._setup_optimization()
+        self.criterion = CODLoss(**self.config['loss']).to(self.device)
+        self.monitor = TrainingMonitor(dir_manager)
+        self.sync = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self.sync = GradSync(self.arena.g, self.arena.unit_ends)
+        self.step_fn = TrainStep(self.model, self.criterion, self.arena, self.grad_clip, self.sync,
+                                 capture=bool(self.config.get('capture_graph', False)))
+        self._plateau_best, self._plateau_bad = -1.0, 0
+
+    # ---- optimisation set-up (reference engine/trainer.py:255-306) --------------------------------------
+    def _get_param_groups(self) -> List[Dict]:
+        from .arena import group_of
+        base_lr = self.config['optimizer']['learning_rate']
+        ratio = self.config['optimizer'].get('encoder_lr_ratio', 0.1)
+        wd = self.config['optimizer'].get('weight_decay', 0.01)
+        groups = [{'params': [], 'weight_decay': 0.0, 'lr': base_lr * ratio}, {'params': [], 'weight_decay': 0.0, 'lr': base_lr * ratio},
+                  {'params': [], 'weight_decay': wd, 'lr': base_lr}, {'params': [], 'weight_decay': 0.0, 'lr': base_lr}]
+        for name, p in self.model.named_parameters():
+            groups[group_of(name)]['params'].append(p)
+        return groups
+
+    def _setup_optimization(self):
+        opt = self.config['optimizer']
+        self.arena = Arena(self.model)
+        self.model.mark_params_changed()
+        self.arena.set_hyper(opt['learning_rate'], opt.get('weight_decay', 0.01), opt.get('encoder_lr_ratio', 0.1))
+        sch = self.config.get('scheduler', {})
+        self._sched = dict(factor=sch.get('factor', 0.5), patience=sch.get('patience', 5), min_lr=sch.get('min_lr', 1e-6))
+
+    def scheduler_step(self, metric: float):
+        """ReduceLROnPlateau(mode='max') on the device-resident learning rates."""
+        if metric > self._plateau_best:
+            self._plateau_best, self._plateau_bad = metric, 0
+        else:
+            self._plateau_bad += 1
+            if self._plateau_bad > self._sched['patience']:
+                self.arena.scale_lr(self._sched['factor'], self._sched['min_lr'])
+                self._plateau_bad = 0
+
+    # ---- the step (reference engine/trainer.py:308-427) --------------------------------------------------
+    def _process_batch(self, batch: Dict, is_train: bool) -> Tuple[Dict[str, torch.Tensor], Dict[str, float]]:
+        timing = {}
+        t0 = time.time()
+        images = batch['images'].to(self.device, non_blocking=True)
+        masks = [m.to(self.device, non_blocking=True) for m in batch['masks']]
+        edges = [e.to(self.device, non_blocking=True) for e in batch['edges']]
+        timing['data_time'] = time.time() - t0
+        same = all(m.shape == masks[0].shape for m in masks) and all(e.shape == edges[0].shape for e in edges)
+        if is_train and same:
+            t1 = time.time()
+            metrics = self.step_fn(images, torch.stack(masks), torch.stack(edges))
+            timing['step_time'] = time.time() - t1
+        else:
+            t1 = time.time()
+            self.model.train(is_train)
+            with torch.set_grad_enabled(is_train):
+                out = self.model(images)
+            timing['forward_time'] = time.time() - t1
+            preds, eds = [], []
+            for i in range(len(masks)):  # per-sample resize to each ground-truth size (ragged batches)
+                preds.append([F.interpolate(p[i:i + 1].float(), size=masks[i].shape[-2:], mode='bilinear', align_corners=False)
+                              for p in out['predictions']])
+                eds.append(F.interpolate(out['edge'][i:i + 1].float(), size=edges[i].shape[-2:], mode='bilinear', align_corners=False))
+            metrics = self.criterion(predictions=preds, edge_pred=eds, masks=masks, edges=edges)
+            if is_train:
+                self.arena.zero_grad()
+                metrics['loss'].backward()
+                scale = self.sync.finish() if self.sync is not None else 1.0
+                self.arena.step(self.grad_clip, grad_scale=scale)
+                self.model.mark_params_changed()
+            metrics = {k: v.detach() for k, v in metrics.items()}
+        timing['batch_time'] = time.time() - t0
+        return metrics, timing
+
+    def train_epoch(self, loader, epoch: int) -> Dict[str, float]:
+        self.model.train()
+        for batch in loader:
+            metrics, _ = self._process_batch(batch, is_train=True)
+            self.monitor.update_batch(metrics, len(batch['masks']))
+        return self.monitor.end_epoch(epoch, "train")
+
+    @torch.no_grad()
+    def validate(self, loader) -> Dict[str, float]:
+        self.model.eval()
+        for batch in loader:
+            metrics, _ = self._process_batch(batch, is_train=False)
+            self.monitor.update_batch(metrics, len(batch['masks']))
+        return self.monitor.end_epoch(-1, "val")
+
+    def train(self, dataset_dirs: Sequence[str]):
+        """Full loop of reference engine/trainer.py:522-586; needs the COD datasets on disk."""
+        from ..utils.data_loader import get_training_loaders
+        train_loader, val_loader = get_training_loaders(dataset_dirs, self.model_config['image_processing'], self.batch_size,
+                                                        self.config.get('num_workers', 8), self.config.get('val_ratio', 0.1))
+        best, bad = float('inf'), 0
+        for epoch in range(self.num_epochs):
+            tr = self.train_epoch(train_loader, epoch)
+            va = self.validate(val_loader)
+            self.scheduler_step(-va['loss'])
+            logger.info("epoch %d train %s val %s", epoch, tr, va)
+            if va['loss'] < best - self.config.get('min_delta', 0.0):
+                best, bad = va['loss'], 0
+                self._save_checkpoint(epoch, va, is_best=True)
+            else:
+                bad += 1
+                if bad >= self.early_stop_patience:
+                    break
+            if (epoch + 1) % self.save_freq == 0:
+                self._save_checkpoint(epoch, va, is_best=False)
+
+    def _save_checkpoint(self, epoch: int, metrics: Dict, is_best: bool = False):
+        """Same checkpoint schema as reference engine/trainer.py:588-606 (model_state_dict + config are what
+        Predictor / main.py read back)."""
+        ckpt = {'epoch': epoch, 'model_state_dict': {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                'optimizer_state_dict': {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.arena.state_dict().items()},
+                'scheduler_state_dict': dict(self._sched, best=self._plateau_best, bad=self._plateau_bad), 'scaler': None,
+                'metrics': metrics, 'config': {'training': self.config, 'model': self.model_config}}
+        d = str(getattr(self.dir_manager, "checkpoint_dir", getattr(self.dir_manager, "run_dir", ".")))
+        os.makedirs(d, exist_ok=True)
+        torch.save(ckpt, os.path.join(d, 'model_best.pth' if is_best else f'checkpoint_{epoch:03d}.pth'))

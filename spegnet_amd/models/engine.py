@@ -1,0 +1,420 @@
+"""Forward/backward orchestration of the SPEGNet hot path over the HIP kernels (spegnet_amd.ops).
+
+Everything numeric here is a call into libspegnet_hip.so; Python only sequences launches and owns the saved
+activations.  Layout: NHWC activations in the compute dtype T (float32 = parity mode, bfloat16 = fast mode),
+fp32 master parameters, T copies of the matrix weights re-packed once per optimizer step (`pack()`).
+
+Reference anchors: SPEGNet.forward models/spegnet.py:137-206; Hiera trunk via models/feature_encoding.py:236
+(algorithm: SURVEY.md §8 row E); CFI models/feature_integration.py:128-151,205-246,369-417; EFE/PED
+models/object_detection.py:132-157,201-238,309-342.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from .params import block_table
+
+Tensor = torch.Tensor
+EASPP_RATES = (1, 6, 12, 18)
+PATCH_KPAD = 160  # 3*7*7 = 147 padded to a multiple of 16 elements
+
+
+class BNState:
+    """Per-call BatchNorm record (train: batch statistics; eval: running statistics)."""
+    __slots__ = ("x", "ss", "mi", "C", "relu", "prefix")
+
+
+class Engine:
+    def __init__(self, module, cfg, dtype: torch.dtype):
+        self.m = module
+        self.cfg = cfg
+        self.dtype = dtype
+        self.blocks = block_table(cfg)
+        self.P: Dict[str, Tensor] = {}
+        self.W: Dict[str, Tensor] = {}      # packed T copies
+        self._pos_cache = None
+        self.unit_cb = None   # called with the index of each finished backward unit (head=0, then blocks last-to-first)
+        self.refresh_params()
+
+    # ------------------------------------------------------------------------------------------------
+    def refresh_params(self):
+        self.P = dict(self.m.named_parameters())
+        self.P.update(dict(self.m.named_buffers()))
+
+    def grad(self, name: str) -> Tensor:
+        p = self.P[name]
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        return p.grad
+
+    def pack(self):
+        """fp32 master -> compute-dtype copies ([N,K] and [K,N]; 3x3 convs in [Co][tap][Ci] / dgrad form)."""
+        T, P, W = self.dtype, self.P, self.W
+        for name, p in P.items():
+            if not name.endswith(".weight") or p.dim() < 2:
+                continue
+            if name.endswith("patch_embed.proj.weight"):
+                w2 = torch.zeros((p.shape[0], PATCH_KPAD), dtype=torch.float32, device=p.device)
+                w2[:, :147] = p.detach().reshape(p.shape[0], 147)
+                W[name] = ops.pack_matrix(w2, T, out=W.get(name))
+            elif p.dim() == 4 and p.shape[2] == 3 and p.shape[1] > 1:
+                f, d = ops.pack_conv3x3(p.detach(), T, W.get(name), W.get(name + ":dgrad"))
+                W[name], W[name + ":dgrad"] = f, d
+            elif p.dim() == 4 and p.shape[1] == 1:
+                continue  # depth-wise weights are read as fp32 [C][9]
+            elif "se_block" in name or "global_branch" in name or "context.fusion.0" in name or "pred_heads" in name or "edge_conv" in name:
+                continue  # tiny fp32-only layers
+            else:
+                w2 = p.detach().reshape(p.shape[0], -1)
+                W[name] = ops.pack_matrix(w2, T, out=W.get(name))
+                W[name + ":T"] = ops.pack_matrix(w2, T, transpose=True, out=W.get(name + ":T"))
+        for b in self.blocks:
+            n = f"encoder.encoder.blocks.{b['idx']}.attn.qkv.bias"
+            W[n] = P[n].detach().to(T)
+        self._pos_cache = None
+
+    # ------------------------------------------------------------------------------------------------ BN
+    def bn_fwd(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool):
+        P = self.P
+        M = x.numel() // C
+        if training:
+            stats = ops.bn_stats(x, C)
+            ss, mi = ops.bn_finalize(stats, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
+                                     P[prefix + "running_var"], M, True)
+            P[prefix + "num_batches_tracked"] += 1
+        else:
+            ss, mi = ops.bn_finalize(None, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
+                                     P[prefix + "running_var"], M, False)
+        y = ops.bn_apply(x, ss, C, relu)
+        st = None
+        if save:
+            st = BNState()
+            st.x, st.ss, st.mi, st.C, st.relu, st.prefix = x, ss, mi, C, relu, prefix
+        return y, st
+
+    def bn_bwd(self, st: BNState, dy: Tensor) -> Tensor:
+        return ops.bn_bwd(dy, st.x, st.ss, st.mi, self.P[st.prefix + "weight"], self.grad(st.prefix + "weight"),
+                          self.grad(st.prefix + "bias"), st.C, st.relu)
+
+    # ------------------------------------------------------------------------------------------------ linear helpers
+    def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
+                residual: Optional[Tensor] = None, bias: bool = True) -> Optional[Tensor]:
+        """dW += dy^T x, db += colsum(dy), returns dx = dy W (optionally * gelu'(h), + residual)."""
+        ops.gemm_tn(dy, x, self.grad(name + ".weight").view(dy.shape[-1], -1))
+        if bias:
+            ops.colsum(dy, self.grad(name + ".bias"))
+        if not need_dx:
+            return None
+        return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual)
+
+    # ================================================================================================ trunk
+    def pos_embed(self, h: int, w: int, B: int, training: bool):
+        """bicubic(pos_embed -> h x w) + tiled window embedding (parameter-only, 1.3 M elements): built with
+        torch ops once per pack() and differentiated by autograd -- bookkeeping, not the hot path."""
+        e = "encoder.encoder."
+        if self._pos_cache is not None and self._pos_cache[0] == (h, w, B, training):
+            return self._pos_cache[1], self._pos_cache[2]
+        with torch.enable_grad() if training else torch.no_grad():
+            pe, we = self.P[e + "pos_embed"], self.P[e + "pos_embed_window"]
+            pos = F.interpolate(pe, size=(h, w), mode="bicubic")
+            pos = pos + we.tile([a // b for a, b in zip(pos.shape, we.shape)])
+            pos = pos.permute(0, 2, 3, 1)
+        posT = pos.detach().to(self.dtype).expand(B, h, w, pos.shape[-1]).contiguous()
+        self._pos_cache = ((h, w, B, training), pos, posT)
+        return pos, posT
+
+    def trunk_fwd(self, img: Tensor, training: bool, save: bool):
+        e = "encoder.encoder."
+        P, W, T = self.P, self.W, self.dtype
+        B, _, S, S2 = img.shape
+        h = w = S // 4
+        D = self.cfg["embed_dim"]
+        cols = ops.patch_im2col(img.float().contiguous(), T, PATCH_KPAD)
+        pos, posT = self.pos_embed(h, w, B, training and save)
+        x = ops.gemm_nt(cols, W[e + "patch_embed.proj.weight"], bias=P[e + "patch_embed.proj.bias"], residual=posT)
+        x = x.view(B, h, w, D)
+        ctx = {"cols": cols, "pos": pos, "blocks": [], "B": B}
+        feats = []
+        H, Wd = h, w
+        for b in self.blocks:
+            x, c = self.block_fwd(b, x, B, H, Wd, save)
+            if b["q_stride"]:
+                H, Wd = H // 2, Wd // 2
+            ctx["blocks"].append(c)
+            if b["stage_end"]:
+                feats.append(x)
+        return feats, ctx
+
+    def block_fwd(self, b, x: Tensor, B: int, H: int, Wd: int, save: bool):
+        p = f"encoder.encoder.blocks.{b['idx']}."
+        P, W = self.P, self.W
+        dim, do, heads, ws, qs = b["dim"], b["dim_out"], b["heads"], b["window"], b["q_stride"]
+        hd = do // heads
+        eps = self.cfg["ln_eps"]
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x, P[p + "norm1.weight"], P[p + "norm1.bias"], eps)
+        sc_idx = None
+        if dim != do:
+            sc_full = ops.gemm_nt(ln1, W[p + "proj.weight"], bias=P[p + "proj.bias"])
+            shortcut, sc_idx = ops.maxpool2_fwd(sc_full, B, H, Wd, do, do, 0)
+        else:
+            shortcut = x
+        qkv = ops.gemm_nt(ln1, W[p + "attn.qkv.weight"], bias=P[p + "attn.qkv.bias"])
+        qp = q_idx = None
+        if qs:
+            qp, q_idx = ops.maxpool2_fwd(qkv, B, H, Wd, do, 3 * do, 0)
+        att, lse = ops.attn_fwd(qkv, W[p + "attn.qkv.bias"], B, H, Wd, heads, hd, ws, q_pooled=qp)
+        Hq, Wq = (H // 2, Wd // 2) if qs else (H, Wd)
+        x1 = ops.gemm_nt(att, W[p + "attn.proj.weight"], bias=P[p + "attn.proj.bias"], residual=shortcut)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, P[p + "norm2.weight"], P[p + "norm2.bias"], eps)
+        hpre = torch.empty((x1.shape[0], 4 * do), dtype=x.dtype, device=x.device) if save else None
+        g = ops.gemm_nt(ln2, W[p + "mlp.layers.0.weight"], bias=P[p + "mlp.layers.0.bias"], act=ops.ACT_GELU, preact_out=hpre)
+        x2 = ops.gemm_nt(g, W[p + "mlp.layers.1.weight"], bias=P[p + "mlp.layers.1.bias"], residual=x1)
+        x2 = x2.view(B, Hq, Wq, do)
+        c = None
+        if save:
+            c = dict(x=x, ln1=ln1, mean1=mean1, rstd1=rstd1, sc_idx=sc_idx, qkv=qkv, qp=qp, q_idx=q_idx, att=att, lse=lse,
+                     x1=x1, ln2=ln2, mean2=mean2, rstd2=rstd2, h=hpre, g=g, H=H, W=Wd)
+        return x2, c
+
+    def block_bwd(self, b, c, dx2: Tensor, B: int) -> Tensor:
+        p = f"encoder.encoder.blocks.{b['idx']}."
+        P, W, G = self.P, self.W, self.grad
+        dim, do, heads, ws, qs = b["dim"], b["dim_out"], b["heads"], b["window"], b["q_stride"]
+        hd = do // heads
+        H, Wd = c["H"], c["W"]
+        dx2 = dx2.reshape(-1, do)
+        # MLP
+        dh = self.lin_bwd(p + "mlp.layers.1", dx2, c["g"], gelu_h=c["h"])
+        dln2 = self.lin_bwd(p + "mlp.layers.0", dh, c["ln2"])
+        dx1 = ops.layernorm_bwd(dln2, c["x1"], P[p + "norm2.weight"], c["mean2"], c["rstd2"], G(p + "norm2.weight"),
+                                G(p + "norm2.bias"), dres=dx2)
+        # attention branch
+        datt = self.lin_bwd(p + "attn.proj", dx1, c["att"])
+        dqkv, dqp = ops.attn_bwd(c["qkv"], W[p + "attn.qkv.bias"], c["att"], datt, c["lse"], G(p + "attn.qkv.bias"), B, H, Wd,
+                                 heads, hd, ws, q_pooled=c["qp"])
+        if qs:
+            ops.maxpool2_bwd(dqp, c["q_idx"], dqkv, B, H, Wd, do, 3 * do, 0)
+        dln1 = self.lin_bwd(p + "attn.qkv", dqkv.view(-1, 3 * do), c["ln1"])
+        if dim != do:
+            dsc = torch.empty((B, H, Wd, do), dtype=dx1.dtype, device=dx1.device)
+            ops.maxpool2_bwd(dx1, c["sc_idx"], dsc, B, H, Wd, do, do, 0)
+            dln1 = self.lin_bwd(p + "proj", dsc.view(-1, do), c["ln1"], residual=dln1)
+            dres = None
+        else:
+            dres = dx1
+        dx = ops.layernorm_bwd(dln1, c["x"], P[p + "norm1.weight"], c["mean1"], c["rstd1"], G(p + "norm1.weight"),
+                               G(p + "norm1.bias"), dres=dres)
+        return dx.view(B, H, Wd, dim)
+
+    def trunk_bwd(self, ctx, dfeats: List[Optional[Tensor]]):
+        """dfeats: gradients w.r.t. the 4 stage maps (NHWC, compute dtype) or None."""
+        e = "encoder.encoder."
+        B = ctx["B"]
+        dx = None
+        unit = 0
+        if self.unit_cb is not None:
+            self.unit_cb(0)   # head gradients are final once trunk backward starts
+        stage = len(dfeats) - 1
+        for b, c in zip(reversed(self.blocks), reversed(ctx["blocks"])):
+            if b["stage_end"]:
+                d = dfeats[stage]
+                stage -= 1
+                if d is not None:
+                    dx = d if dx is None else ops.add(dx, d.contiguous())
+            if dx is None:
+                raise RuntimeError("trunk_bwd: no gradient reaches the last stage")
+            dx = self.block_bwd(b, c, dx, B)
+            unit += 1
+            if self.unit_cb is not None:
+                self.unit_cb(unit)
+        D = dx.shape[-1]
+        d2 = dx.reshape(-1, D)
+        pw = torch.zeros((D, PATCH_KPAD), dtype=torch.float32, device=dx.device)
+        ops.gemm_tn(d2, ctx["cols"], pw)
+        self.grad(e + "patch_embed.proj.weight").view(D, 147).add_(pw[:, :147])
+        ops.colsum(d2, self.grad(e + "patch_embed.proj.bias"))
+        pos = ctx["pos"]
+        if pos.requires_grad:
+            dpos = dx.float().sum(0, keepdim=True)
+            gp, gw = torch.autograd.grad(pos, [self.P[e + "pos_embed"], self.P[e + "pos_embed_window"]], dpos, retain_graph=True)
+            self.grad(e + "pos_embed").add_(gp)
+            self.grad(e + "pos_embed_window").add_(gw)
+
+    # ================================================================================================ head
+    def conv3_fwd(self, name: str, x: Tensor, B, H, W, Ci, bias: bool):
+        return ops.gemm_nt(x, self.W[name + ".weight"], bias=self.P[name + ".bias"] if bias else None, conv=(B, H, W, Ci))
+
+    def conv3_bwd(self, name: str, dy: Tensor, x: Tensor, B, H, W, Ci, Co, bias: bool, need_dx: bool = True):
+        gp = torch.zeros((Co, 9 * Ci), dtype=torch.float32, device=dy.device)
+        ops.gemm_tn(dy, x, gp, conv=(B, H, W, Ci))
+        ops.unpack_conv3x3_grad(gp, self.grad(name + ".weight"))
+        if bias:
+            ops.colsum(dy, self.grad(name + ".bias"))
+        if not need_dx:
+            return None
+        return ops.gemm_nt(dy, self.W[name + ".weight:dgrad"], conv=(B, H, W, Co))
+
+    def head_fwd(self, feats: List[Tensor], training: bool, save: bool):
+        """feats: [s2,s3,s4] NHWC.  Returns dict of NHWC outputs + ctx."""
+        P, W, T = self.P, self.W, self.dtype
+        s2, s3, s4 = feats
+        B, h, w, C2 = s2.shape
+        C3, C4 = s3.shape[-1], s4.shape[-1]
+        HW = h * w
+        M = B * HW
+        Ct = C2 + C3 + C4
+        dev = s2.device
+        c: dict = {"B": B, "h": h, "w": w, "chans": (C2, C3, C4), "s_shapes": (s3.shape, s4.shape)}
+        # --- CFI fusion: gather-upsample-concat -> 1x1 -> BN -> ReLU -> SE
+        cat = torch.empty((M, Ct), dtype=T, device=dev)
+        ops.copy_channels(s2, cat, M, C2, C2, 0, Ct, 0)
+        ops.upsample_into(s3, cat, B, s3.shape[1], s3.shape[2], C3, h, w, Ct, C2)
+        ops.upsample_into(s4, cat, B, s4.shape[1], s4.shape[2], C4, h, w, Ct, C2 + C3)
+        f0 = ops.gemm_nt(cat, W["fusion.conv1x1.weight"])
+        f1, c["bn_f"] = self.bn_fwd("fusion.bn.", f0, 512, True, training, save)
+        gap = ops.gap_sum(f1, B, HW, 512) / HW
+        hidden, scale = ops.se_fc(gap, P["fusion.se_block.fc.0.weight"], P["fusion.se_block.fc.2.weight"])
+        fused = ops.chan_scale(f1, scale, B, HW, 512)
+        # --- e-ASPP
+        r0 = ops.gemm_nt(fused, W["context.reduce.0.weight"])
+        r1, c["bn_r"] = self.bn_fwd("context.reduce.1.", r0, 128, True, training, save)
+        brs, bn_b, dws = [], [], []
+        for i, dil in enumerate(EASPP_RATES):
+            d = ops.dwconv3x3(r1, P[f"context.branches.{i}.0.weight"].view(128, 9), B, h, w, 128, dil)
+            y, st = self.bn_fwd(f"context.branches.{i}.1.", d, 128, True, training, save)
+            brs.append(y); bn_b.append(st)
+        gm = ops.gap_sum(r1, B, HW, 128) / HW                                    # [B,128] fp32
+        gl0 = ops.gemm_nt(gm, P["context.global_branch.1.weight"].view(128, 128))  # fp32 MFMA on 8 rows
+        glob, c["bn_g"] = self.bn_fwd("context.global_branch.2.", gl0, 128, True, training, save)
+        fu0 = ops.easpp_fuse(brs, glob, P["context.fusion.0.weight"].view(128, 5), B, HW, 128)
+        fu1, c["bn_u"] = self.bn_fwd("context.fusion.1.", fu0, 128, True, training, save)
+        e0 = ops.gemm_nt(fu1, W["context.expand.0.weight"])
+        context, c["bn_e"] = self.bn_fwd("context.expand.1.", e0, 256, True, training, save)
+        # --- EFE
+        ec = self.conv3_fwd("edge_detector.conv1", context, B, h, w, 256, bias=False)
+        edge_f, c["bn_ef"] = self.bn_fwd("edge_detector.bn1.", ec, 64, True, training, save)
+        edge = ops.head1x1(edge_f, P["edge_detector.edge_conv.weight"].view(64), P["edge_detector.edge_conv.bias"], M, 64)
+        # --- PED
+        preds, stages = [], []
+        x, Hc, Wc, Cin = context, h, w, 256
+        for i, (Co, ec_ch) in enumerate(zip((256, 128, 64), (64, 64, 0))):
+            H2, W2 = Hc * 2, Wc * 2
+            Cc = Cin + ec_ch
+            pc = torch.empty((B * H2 * W2, Cc), dtype=T, device=dev)
+            ops.upsample_into(x, pc, B, Hc, Wc, Cin, H2, W2, Cc, 0)
+            if ec_ch:
+                ops.upsample_into(edge_f, pc, B, h, w, 64, H2, W2, Cc, Cin)
+            pre = f"decoder.decoder_blocks.{i}."
+            a0 = self.conv3_fwd(pre + "conv1", pc, B, H2, W2, Cc, bias=True)
+            a1, st1 = self.bn_fwd(pre + "bn1.", a0, Co, True, training, save)
+            b0 = self.conv3_fwd(pre + "conv2", a1, B, H2, W2, Co, bias=True)
+            b1, st2 = self.bn_fwd(pre + "bn2.", b0, Co, True, training, save)
+            pred = ops.head1x1(b1, P[f"decoder.pred_heads.{i}.weight"].view(Co), P[f"decoder.pred_heads.{i}.bias"], B * H2 * W2, Co)
+            preds.append(pred.view(B, 1, H2, W2))
+            stages.append(dict(pc=pc if save else None, a1=a1, b1=b1, bn1=st1, bn2=st2, H=H2, W=W2, Cin=Cin, ec=ec_ch, Co=Co))
+            x, Hc, Wc, Cin = b1, H2, W2, Co
+        out = {"predictions": preds, "edge": edge.view(B, 1, h, w), "context": context.view(B, h, w, 256),
+               "fused": fused.view(B, h, w, 512), "edge_features": edge_f.view(B, h, w, 64)}
+        if save:
+            c.update(cat=cat, f1=f1, gap=gap, hidden=hidden, scale=scale, fused=fused, r1=r1, brs=brs, bn_b=bn_b, gm=gm,
+                     glob=glob, fu1=fu1, context=context, edge_f=edge_f, stages=stages)
+        return out, (c if save else None)
+
+    def head_bwd(self, c, dpreds: List[Optional[Tensor]], dedge: Optional[Tensor], dextra: Optional[dict] = None):
+        """Returns gradients w.r.t. [s2,s3,s4] (NHWC).  dpreds[i]: [B,1,H,W] or None; dedge: [B,1,h,w] or None."""
+        P, W, G, T = self.P, self.W, self.grad, self.dtype
+        B, h, w = c["B"], c["h"], c["w"]
+        HW, M = h * w, c["B"] * c["h"] * c["w"]
+        dev = c["cat"].device
+        C2, C3, C4 = c["chans"]
+
+        def zeros(*shape):
+            return torch.zeros(shape, dtype=T, device=dev)
+
+        d_edge_f = zeros(M, 64)
+        d_context = zeros(M, 256)
+        have_ctx = False
+        # --- PED, last stage first
+        d_next = None  # gradient w.r.t. this stage's output b1 coming from the next stage
+        for i in (2, 1, 0):
+            st = c["stages"][i]
+            H2, W2, Cin, ec_ch, Co = st["H"], st["W"], st["Cin"], st["ec"], st["Co"]
+            Mi = B * H2 * W2
+            if d_next is None:
+                d_b1 = zeros(Mi, Co)
+            else:
+                d_b1 = d_next
+            if dpreds[i] is not None:
+                ops.head1x1_bwd(dpreds[i].to(T).contiguous().view(Mi), st["b1"], P[f"decoder.pred_heads.{i}.weight"].view(Co), d_b1,
+                                G(f"decoder.pred_heads.{i}.weight").view(Co), G(f"decoder.pred_heads.{i}.bias"), Mi, Co, True)
+            pre = f"decoder.decoder_blocks.{i}."
+            d_b0 = self.bn_bwd(st["bn2"], d_b1)
+            d_a1 = self.conv3_bwd(pre + "conv2", d_b0, st["a1"], B, H2, W2, Co, Co, bias=True)
+            d_a0 = self.bn_bwd(st["bn1"], d_a1)
+            Cc = Cin + ec_ch
+            d_pc = self.conv3_bwd(pre + "conv1", d_a0, st["pc"], B, H2, W2, Cc, Co, bias=True)
+            Hc, Wc = H2 // 2, W2 // 2
+            if i == 0:
+                ops.upsample_bwd(d_pc, d_context, B, Hc, Wc, Cin, H2, W2, Cc, 0, accumulate=False)
+                have_ctx = True
+                d_next = None
+            else:
+                d_next = torch.empty((B * Hc * Wc, Cin), dtype=T, device=dev)
+                ops.upsample_bwd(d_pc, d_next, B, Hc, Wc, Cin, H2, W2, Cc, 0, accumulate=False)
+            if ec_ch:
+                ops.upsample_bwd(d_pc, d_edge_f, B, h, w, 64, H2, W2, Cc, Cin, accumulate=True)
+        # --- EFE
+        if dedge is not None:
+            ops.head1x1_bwd(dedge.to(T).contiguous().view(M), c["edge_f"], P["edge_detector.edge_conv.weight"].view(64), d_edge_f,
+                            G("edge_detector.edge_conv.weight").view(64), G("edge_detector.edge_conv.bias"), M, 64, True)
+        if dextra and dextra.get("edge_features") is not None:
+            d_edge_f = ops.add(d_edge_f, dextra["edge_features"].to(T).contiguous().view(M, 64))
+        d_ec = self.bn_bwd(c["bn_ef"], d_edge_f)
+        d_ctx2 = self.conv3_bwd("edge_detector.conv1", d_ec, c["context"], B, h, w, 256, 64, bias=False)
+        d_context = ops.add(d_context, d_ctx2) if have_ctx else d_ctx2
+        if dextra and dextra.get("context") is not None:
+            d_context = ops.add(d_context, dextra["context"].to(T).contiguous().view(M, 256))
+        # --- e-ASPP
+        d_e0 = self.bn_bwd(c["bn_e"], d_context)
+        d_fu1 = self.lin_bwd("context.expand.0", d_e0, c["fu1"], bias=False)
+        d_fu0 = self.bn_bwd(c["bn_u"], d_fu1)
+        d_brs, d_glob = ops.easpp_fuse_bwd(d_fu0, c["brs"], c["glob"], P["context.fusion.0.weight"].view(128, 5),
+                                           G("context.fusion.0.weight").view(128, 5), B, HW, 128)
+        d_gl0 = self.bn_bwd(c["bn_g"], d_glob)                                   # fp32 [B,128]
+        ops.gemm_tn(d_gl0, c["gm"], G("context.global_branch.1.weight").view(128, 128))
+        wg_t = P["context.global_branch.1.weight"].view(128, 128).t().contiguous()
+        d_gm = ops.gemm_nt(d_gl0, wg_t)                                            # [B,128] fp32
+        d_r1 = None
+        for i, dil in enumerate(EASPP_RATES):
+            d_d = self.bn_bwd(c["bn_b"][i], d_brs[i])
+            wd = P[f"context.branches.{i}.0.weight"].view(128, 9)
+            ops.dwconv3x3_wgrad(d_d, c["r1"], G(f"context.branches.{i}.0.weight").view(128, 9), B, h, w, 128, dil)
+            dx = ops.dwconv3x3(d_d, wd, B, h, w, 128, dil, flip=True)
+            d_r1 = dx if d_r1 is None else ops.add(d_r1, dx)
+        # global-average-pool adjoint: + d_gm[b][c] / HW on every pixel (scale = 1 -> chan_scale_bwd with ones)
+        ones = torch.ones((B, 128), dtype=torch.float32, device=dev)
+        d_r1 = ops.chan_scale_bwd(d_r1, ones, d_gm, B, HW, 128)
+        d_r0 = self.bn_bwd(c["bn_r"], d_r1)
+        d_fused = self.lin_bwd("context.reduce.0", d_r0, c["fused"], bias=False)
+        if dextra and dextra.get("fused") is not None:
+            d_fused = ops.add(d_fused, dextra["fused"].to(T).contiguous().view(M, 512))
+        # --- SE + fusion
+        dscale = ops.chan_prod_sum(d_fused, c["f1"], B, HW, 512)
+        dgap = ops.se_fc_bwd(c["gap"], P["fusion.se_block.fc.0.weight"], P["fusion.se_block.fc.2.weight"], c["hidden"], c["scale"],
+                             dscale, G("fusion.se_block.fc.0.weight"), G("fusion.se_block.fc.2.weight"))
+        d_f1 = ops.chan_scale_bwd(d_fused, c["scale"], dgap, B, HW, 512)
+        d_f0 = self.bn_bwd(c["bn_f"], d_f1)
+        d_cat = self.lin_bwd("fusion.conv1x1", d_f0, c["cat"], bias=False)
+        Ct = C2 + C3 + C4
+        s3s, s4s = c["s_shapes"]
+        d_s2 = torch.empty((B, h, w, C2), dtype=T, device=dev)
+        ops.copy_channels(d_cat, d_s2, M, C2, Ct, 0, C2, 0)
+        d_s3 = torch.empty(s3s, dtype=T, device=dev)
+        ops.upsample_bwd(d_cat, d_s3, B, s3s[1], s3s[2], C3, h, w, Ct, C2)
+        d_s4 = torch.empty(s4s, dtype=T, device=dev)
+        ops.upsample_bwd(d_cat, d_s4, B, s4s[1], s4s[2], C4, h, w, Ct, C2 + C3)
+        return [d_s2, d_s3, d_s4]
