@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""SPEGNet train-step benchmark on MI355X (BASELINE.json metric: img/s fwd+bwd @384x384 bf16).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one full optimisation step of the reference's Trainer._process_batch (engine/trainer.py:308-427) on a
+synthetic batch of 8 images/GPU at 384x384 (BASELINE.json configs[1]): forward (Hiera-L trunk + CFI + EFE + PED) in
+bf16 on the HIP kernels, CODLoss, backward, global-norm clip + AdamW on fp32 master weights, weight re-pack.  Weak
+scaling: every rank keeps 8 images; ranks only exchange the gradient all-reduce (RCCL).
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the roofline and cpu_baseline legs).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PER_GPU_BATCH = 8
+S = 384
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    """progress on stderr (the JSON line is the only thing on stdout)"""
+    print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def synthetic(B, S, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    images = torch.randn(B, 3, S, S, generator=g, device=device)
+    masks = (torch.rand(B, 1, S, S, generator=g, device=device) > 0.7).float()
+    edges = (torch.rand(B, 1, S, S, generator=g, device=device) > 0.95).float()
+    return images, masks, edges
+
+
+def cpu_baseline():
+    """The CPU oracle (fp32 restatement of the reference path) timed on this box's host cores: one full train step
+    at batch 2 @384x384 (bounded sample of the same workload)."""
+    from oracle import spegnet_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:  # cgroup CPU quota (the GPU box gives each job a share of the host's cores)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
+    cores = min(cores, int(os.environ.get("SPG_CPU_THREADS", "16")))
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle train step on {cores} threads")
+    sd = O.init_state_dict(seed=0)
+    B, n = 4, 2
+    x, masks, edges = O.synthetic_batch(B, S, seed=0)
+    st = {}
+    t0 = time.time()
+    for _ in range(n):
+        O.train_step(sd, st, x, masks, edges)
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fp32 train steps (fwd+CODLoss+bwd+clip+AdamW) of the CPU oracle, batch {B} @{S}x{S}, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU (default: BASELINE config)")
+    ap.add_argument("--size", type=int, default=S)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (bucketed all-reduce overlaps backward)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from spegnet_amd.engine.distributed import GradSync, init_process_group_from_env
+    rank, world, local = init_process_group_from_env("cuda")
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from spegnet_amd import ops
+    from spegnet_amd.engine.arena import Arena
+    from spegnet_amd.engine.trainer import TrainStep
+    from spegnet_amd.models import SPEGNet
+    from spegnet_amd.utils.loss_functions import CODLoss
+
+    log(f"rank {rank}/{world} building model")
+    model = SPEGNet({"encoder": {"variant": "large"}, "compute_dtype": args.dtype, "init_seed": 0}).to(dev).train()
+    arena = Arena(model)
+    model.mark_params_changed()
+    arena.set_hyper(1e-4, 1e-5, 0.05)                      # configs/default.yaml:25-28 of the reference
+    crit = CODLoss(scale_weights=[0.2, 0.3, 0.5], boundary_weight=2.0, bce_weight=1.25, iou_weight=1.0, edge_weight=0.75,
+                   edge_focal_alpha=0.75, edge_focal_gamma=2.0).to(dev)  # configs/default.yaml:34-43
+    sync = GradSync(arena.g, arena.unit_ends) if world > 1 else None
+    step = TrainStep(model, crit, arena, grad_clip=1.0, sync=sync, capture=not args.no_graph)
+    images, masks, edges = synthetic(args.batch, args.size, dev, seed=1000 * rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(args.warmup, 1)):
+        losses = step(images, masks, edges)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done (includes hipGraph capture)" if not args.no_graph else "first eager step done")
+    barrier()
+    log("warm-up done, timing")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step(images, masks, edges)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    log(f"timed {args.steps} steps in {dt:.3f} s")
+    loss_val = float(losses["loss"])
+    assert loss_val == loss_val, "loss is NaN"
+
+    # ---- roofline leg: the dominant kernel (gemm_nt, bf16 dense MFMA GEMM) timed with HIP events on its own stream over
+    #      instrumented eager steps run right after the timed region (hipGraph replays cannot carry per-kernel events).
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        eager = TrainStep(model, crit, arena, grad_clip=1.0, sync=None, capture=False) if world == 1 else None
+        if eager is not None:
+            ops.PROFILE = []
+            for _ in range(2):
+                eager(images, masks, edges)
+            torch.cuda.synchronize()
+            rec, ops.PROFILE = ops.PROFILE, None
+            tot = {}
+            for kind, dt_, fl, e0, e1 in rec:
+                k = (kind, str(dt_))
+                a = tot.setdefault(k, [0.0, 0.0, 0])
+                a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+            want = ("dense", "torch.bfloat16" if args.dtype == "bf16" else "torch.float32")
+            fl, sec, n = tot[want]
+            ach = fl / sec / 1e12
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s,dense>" % args.dtype, "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": n,
+                    "avg_launch_us": round(sec / n * 1e6, 2), "flop_per_launch_avg": fl / n,
+                    "other": {f"{k[0]}": {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "launches": v[2], "avg_us": round(v[1] / v[2] * 1e6, 2)}
+                              for k, v in tot.items() if k != want}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        n_img = world * args.batch * args.steps
+        line = {
+            "metric": "img/s fwd+bwd @384x384 bf16" if (args.size == 384 and args.dtype == "bf16") else f"img/s fwd+bwd @{args.size}x{args.size} {args.dtype}",
+            "value": round(n_img / dt, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"SPEGNet (Hiera-L trunk + CFI + EFE + PED) train step: fwd + CODLoss + bwd + clip + AdamW, "
+                                   f"batch {args.batch}/GPU @{args.size}x{args.size}, random-init weights",
+                       "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
+                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph fwd+bwd | RCCL all-reduce | hipGraph optimizer"),
+                       "final_loss": round(loss_val, 5)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -222,7 +222,7 @@ static int launch_colreduce(const void* a, const void* b, const float* p0, const
   }
   const long rows = img_rows > 0 ? img_rows : M;
   const int rpar = 256 / (C / VEC);
-  long want = 2048 / (nimg > 0 ? nimg : 1);
+  long want = 384 / (nimg > 0 ? nimg : 1);  // few blocks per output address: the final atomics contend per column
   if (want < 1) want = 1;
   long rpb = cdiv(rows, want);
   const long min_rpb = (long)rpar * 8;
@@ -344,8 +344,8 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(M > 0 && C > 0 && C % vec == 0 && C / vec <= 64 * LN_MAXCH, "layernorm_bwd: bad C=%d", C);
   hipStream_t s = (hipStream_t)stream;
-  int grid = cdiv(M, 4 * 8);
-  if (grid > 1024) grid = 1024;
+  int grid = cdiv(M, 4 * 2);
+  if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   if (dtype == SPG_BF16)
     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, M, C);

@@ -30,30 +30,84 @@ logger = logging.getLogger(__name__)
 
 class TrainStep:
     """One optimisation step on fixed-shape device tensors: forward, CODLoss, backward, (all-reduce), clip+AdamW,
-    weight re-pack.  With capture=True the whole step is recorded once into a hipGraph and replayed."""
+    weight re-pack.
+
+    capture=False : eager launches; with a GradSync the bucketed all-reduce overlaps the trunk backward.
+    capture=True  : the step is recorded once into hipGraphs and replayed (removes ~1.5k host launches per step).
+                    world==1: one graph for the whole step.  world>1: graph A = zero-grad + forward + loss + backward,
+                    then ONE eager RCCL all-reduce of the flat gradient arena, then graph B = clip + AdamW + re-pack
+                    (collectives stay outside the graphs; at 8 img/GPU the exposed all-reduce is a few ms)."""
 
     def __init__(self, model: SPEGNet, criterion: CODLoss, arena: Arena, grad_clip: float = 1.0, sync: Optional[GradSync] = None,
                  capture: bool = False):
         self.model, self.criterion, self.arena, self.clip, self.sync = model, criterion, arena, grad_clip, sync
         self.capture = capture
-        self.graph = None
+        self.graph = self.graph_b = None
         self.static = None
         self.losses = None
-        if sync is not None:
+        self.world = sync.world if sync is not None else 1
+        if sync is not None and not capture:
             ends = arena.unit_ends
             model.engine.unit_cb = lambda k: sync.ready(ends[k])
 
-    def _eager(self, images, masks, edges):
-        model, arena = self.model, self.arena
-        arena.zero_grad()
-        out = model(images)
+    # ---- pieces -------------------------------------------------------------------------------------------
+    def _fwd_bwd(self, images, masks, edges):
+        self.arena.zero_grad()
+        out = self.model(images)
         losses = self.criterion.forward_batched(out['predictions'], out['edge'], masks, edges)
         losses['loss'].backward()
-        scale = self.sync.finish() if self.sync is not None else 1.0
-        arena.step(self.clip, grad_scale=scale)
-        eng = model._engine
-        eng.pack()  # compute-dtype copies for the next forward (kept inside the step so it is captured too)
         return {k: v.detach() for k, v in losses.items()}
+
+    def _opt(self, scale: float):
+        self.arena.step(self.clip, grad_scale=scale)
+        self.model._engine.pack()  # compute-dtype copies for the next forward (inside the step so it is captured too)
+
+    def _eager(self, images, masks, edges):
+        losses = self._fwd_bwd(images, masks, edges)
+        scale = self.sync.finish() if self.sync is not None else 1.0
+        self._opt(scale)
+        return losses
+
+    def _allreduce_flat(self):
+        import torch.distributed as dist
+        dist.all_reduce(self.arena.g)
+
+    def _step_split(self, images, masks, edges):
+        losses = self._fwd_bwd(images, masks, edges)
+        if self.world > 1:
+            self._allreduce_flat()
+        self._opt(1.0 / self.world)
+        return losses
+
+    # ---- capture --------------------------------------------------------------------------------------------
+    def _capture(self, images, masks, edges):
+        model, ar = self.model, self.arena
+        self.static = (images.clone(), masks.clone(), edges.clone())
+        if ar.m is None:
+            ar.m, ar.v = torch.zeros_like(ar.p), torch.zeros_like(ar.p)
+        # warm-up must not advance training: snapshot every piece of state the step mutates, restore after
+        keep = [ar.p, ar.m, ar.v, ar.step_f] + list(model.buffers())
+        snap = [t.clone() for t in keep]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):        # warm-up on a side stream (allocator + lazy init), as torch requires
+            for _i in range(2):
+                self._step_split(*self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        for t, c in zip(keep, snap):
+            t.copy_(c)
+        model._engine.pack()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        if self.world == 1:
+            with torch.cuda.graph(self.graph):
+                self.losses = self._eager(*self.static)
+        else:
+            with torch.cuda.graph(self.graph):
+                self.losses = self._fwd_bwd(*self.static)
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+                self._opt(1.0 / self.world)
 
     def __call__(self, images: torch.Tensor, masks: torch.Tensor, edges: torch.Tensor) -> Dict[str, torch.Tensor]:
         model = self.model
@@ -62,29 +116,14 @@ class TrainStep:
         if not self.capture:
             return self._eager(images, masks, edges)
         if self.graph is None:
-            self.static = (images.clone(), masks.clone(), edges.clone())
-            # warm-up must not advance training: snapshot every piece of state the step mutates, restore after
-            ar = self.arena
-            if ar.m is None:
-                ar.m, ar.v = torch.zeros_like(ar.p), torch.zeros_like(ar.p)
-            keep = [t for t in (ar.p, ar.m, ar.v, ar.step_f)] + list(model.buffers())
-            snap = [t.clone() for t in keep]
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):        # warm-up on a side stream (allocator + lazy init), as torch requires
-                for _i in range(2):
-                    self._eager(*self.static)
-            torch.cuda.current_stream().wait_stream(side)
-            for t, c in zip(keep, snap):
-                t.copy_(c)
-            model._engine.pack()
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.losses = self._eager(*self.static)
+            self._capture(images, masks, edges)
         for dst, src in zip(self.static, (images, masks, edges)):
-            dst.copy_(src)
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
         self.graph.replay()
+        if self.graph_b is not None:
+            self._allreduce_flat()
+            self.graph_b.replay()
         return self.losses
 
 

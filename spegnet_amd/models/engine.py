@@ -36,7 +36,6 @@ class Engine:
         self.blocks = block_table(cfg)
         self.P: Dict[str, Tensor] = {}
         self.W: Dict[str, Tensor] = {}      # packed T copies
-        self._pos_cache = None
         self.unit_cb = None   # called with the index of each finished backward unit (head=0, then blocks last-to-first)
         self.refresh_params()
 
@@ -75,7 +74,6 @@ class Engine:
         for b in self.blocks:
             n = f"encoder.encoder.blocks.{b['idx']}.attn.qkv.bias"
             W[n] = P[n].detach().to(T)
-        self._pos_cache = None
 
     # ------------------------------------------------------------------------------------------------ BN
     def bn_fwd(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool):
@@ -112,20 +110,39 @@ class Engine:
         return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual)
 
     # ================================================================================================ trunk
-    def pos_embed(self, h: int, w: int, B: int, training: bool):
-        """bicubic(pos_embed -> h x w) + tiled window embedding (parameter-only, 1.3 M elements): built with
-        torch ops once per pack() and differentiated by autograd -- bookkeeping, not the hot path."""
+    def pos_basis(self, h: int, w: int, B: int) -> Tensor:
+        """The position embedding bicubic(pos_embed -> h x w) + tile(pos_embed_window) is LINEAR in its two parameters:
+        pos[hw, C] = Abasis[hw, 49 + 64] . [pos_embed | pos_embed_window]^T.  Abasis depends only on the sizes, so it
+        is built once (by interpolating an identity) and both the embedding and its gradient become one small GEMM
+        on the HIP path instead of a bicubic kernel and its atomic-scatter backward."""
+        key = (h, w, B)
+        if getattr(self, "_basis_key", None) == key:
+            return self._basis
+        bh, bw = self.cfg["bkg"]
+        w0 = self.cfg["window_spec"][0]
+        dev = self.P["fusion.bn.weight"].device
+        n_b, n_w = bh * bw, w0 * w0
+        with torch.no_grad():
+            eye = torch.eye(n_b, device=dev).view(n_b, 1, bh, bw)
+            A = F.interpolate(eye, size=(h, w), mode="bicubic").view(n_b, h * w).t()          # [hw, 49]
+            yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+            Tm = F.one_hot(((yy % w0) * w0 + (xx % w0)).reshape(-1), n_w).float()               # [hw, 64]
+            K = n_b + n_w
+            Kp = (K + 7) // 8 * 8
+            Ab = torch.zeros((h * w, Kp), device=dev)
+            Ab[:, :n_b], Ab[:, n_b:K] = A, Tm
+            self._basis = Ab.to(self.dtype).repeat(B, 1).contiguous()                           # [B*hw, Kp]
+        self._basis_key, self._basis_dims = key, (n_b, n_w, Kp)
+        return self._basis
+
+    def pos_params_packed(self) -> Tensor:
         e = "encoder.encoder."
-        if self._pos_cache is not None and self._pos_cache[0] == (h, w, B, training):
-            return self._pos_cache[1], self._pos_cache[2]
-        with torch.enable_grad() if training else torch.no_grad():
-            pe, we = self.P[e + "pos_embed"], self.P[e + "pos_embed_window"]
-            pos = F.interpolate(pe, size=(h, w), mode="bicubic")
-            pos = pos + we.tile([a // b for a, b in zip(pos.shape, we.shape)])
-            pos = pos.permute(0, 2, 3, 1)
-        posT = pos.detach().to(self.dtype).expand(B, h, w, pos.shape[-1]).contiguous()
-        self._pos_cache = ((h, w, B, training), pos, posT)
-        return pos, posT
+        n_b, n_w, Kp = self._basis_dims
+        C = self.cfg["embed_dim"]
+        m = torch.zeros((C, Kp), dtype=torch.float32, device=self.P[e + "pos_embed"].device)
+        m[:, :n_b] = self.P[e + "pos_embed"].detach().view(C, n_b)
+        m[:, n_b:n_b + n_w] = self.P[e + "pos_embed_window"].detach().view(C, n_w)
+        return m.to(self.dtype)
 
     def trunk_fwd(self, img: Tensor, training: bool, save: bool):
         e = "encoder.encoder."
@@ -134,10 +151,11 @@ class Engine:
         h = w = S // 4
         D = self.cfg["embed_dim"]
         cols = ops.patch_im2col(img.float().contiguous(), T, PATCH_KPAD)
-        pos, posT = self.pos_embed(h, w, B, training and save)
+        basis = self.pos_basis(h, w, B)
+        posT = ops.gemm_nt(basis, self.pos_params_packed())                       # [B*h*w, D]
         x = ops.gemm_nt(cols, W[e + "patch_embed.proj.weight"], bias=P[e + "patch_embed.proj.bias"], residual=posT)
         x = x.view(B, h, w, D)
-        ctx = {"cols": cols, "pos": pos, "blocks": [], "B": B}
+        ctx = {"cols": cols, "basis": basis, "blocks": [], "B": B}
         feats = []
         H, Wd = h, w
         for b in self.blocks:
@@ -237,12 +255,11 @@ class Engine:
         ops.gemm_tn(d2, ctx["cols"], pw)
         self.grad(e + "patch_embed.proj.weight").view(D, 147).add_(pw[:, :147])
         ops.colsum(d2, self.grad(e + "patch_embed.proj.bias"))
-        pos = ctx["pos"]
-        if pos.requires_grad:
-            dpos = dx.float().sum(0, keepdim=True)
-            gp, gw = torch.autograd.grad(pos, [self.P[e + "pos_embed"], self.P[e + "pos_embed_window"]], dpos, retain_graph=True)
-            self.grad(e + "pos_embed").add_(gp)
-            self.grad(e + "pos_embed_window").add_(gw)
+        n_b, n_w, Kp = self._basis_dims
+        gpos = torch.zeros((D, Kp), dtype=torch.float32, device=dx.device)
+        ops.gemm_tn(d2, ctx["basis"], gpos)
+        self.grad(e + "pos_embed").view(D, n_b).add_(gpos[:, :n_b])
+        self.grad(e + "pos_embed_window").view(D, n_w).add_(gpos[:, n_b:n_b + n_w])
 
     # ================================================================================================ head
     def conv3_fwd(self, name: str, x: Tensor, B, H, W, Ci, bias: bool):

@@ -43,6 +43,10 @@ def f32(t: Tensor) -> Tensor:
     return _c(t)
 
 
+# ---- optional live kernel timing (bench.py roofline leg): HIP events on the launch stream -----------------------
+PROFILE = None  # set to a list -> every gemm_nt appends (kind, flops, start_event, end_event)
+
+
 # ---- GEMM family ---------------------------------------------------------------------------------------
 def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = ACT_NONE, residual: Optional[Tensor] = None,
             gelu_h: Optional[Tensor] = None, out: Optional[Tensor] = None, preact_out: Optional[Tensor] = None,
@@ -63,8 +67,14 @@ def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = ACT_
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     assert out.numel() == M * N and w.dtype == x.dtype
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("spg_gemm_nt", dcode(x), _p(_c(x)), _p(_c(w)), _p(_c(out)), _p(preact_out), _p(bias), _p(residual),
               _p(gelu_h), M, N, K, ldx, N, act, 1 if conv else 0, B, H, W, Ci, _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("conv3x3" if conv else "dense", x.dtype, 2.0 * M * N * K, e0, e1))
     return out
 
 
