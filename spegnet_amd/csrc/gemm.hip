@@ -52,20 +52,30 @@ struct ConvGeom {
   int B, H, W, Ci;  // NHWC input of a 3x3/pad1/stride1 convolution
 };
 
-// One 16-byte chunk of row m, K offset k0 of the (possibly gathered) X operand; zero outside.
+// Branch-free operand loads: raw buffer loads with hardware bounds checking (out-of-range offsets return 0), so
+// hipcc keeps every load of a K-tile in flight behind a counted vmcnt instead of branching around each one
+// (cdna_hip_programming.md §5 "Three .s-level traps" (c)).
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned bufvec_t;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  bufvec_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return u32x4{v[0], v[1], v[2], v[3]};
+}
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+// byte offset of the 16-byte chunk (row m, K offset k0) of the (possibly gathered) X operand; OOB when outside.
 template <typename T, bool CONV>
-__device__ __forceinline__ u32x4 load_x_chunk(const T* __restrict__ X, int m, int k0, int M, int K, int ldx,
-                                              const ConvGeom& g, int py, int px, long pix_base) {
-  u32x4 z = {0u, 0u, 0u, 0u};
-  if (m >= M || k0 >= K) return z;
+__device__ __forceinline__ unsigned x_chunk_off(int m, int k0, int ldx, const ConvGeom& g, int py, int px) {
   if constexpr (!CONV) {
-    return ld16(X + (long)m * ldx + k0);
+    return (unsigned)(((long)m * ldx + k0) * (long)sizeof(T));
   } else {
     const int tap = k0 / g.Ci, ci = k0 - tap * g.Ci;
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    const int yy = py + dy, xx = px + dx;
-    if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return z;
-    return ld16(X + (pix_base + (long)dy * g.W + dx) * g.Ci + ci);
+    const bool in = (unsigned)(py + dy) < (unsigned)g.H && (unsigned)(px + dx) < (unsigned)g.W;
+    const unsigned off = (unsigned)((((long)m + (long)dy * g.W + dx) * g.Ci + ci) * (long)sizeof(T));
+    return in ? off : OOB;
   }
 }
 
@@ -102,7 +112,8 @@ struct NtEpi {
 template <typename T, bool CONV>
 __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                              T* __restrict__ C, NtEpi epi, int M, int N, int K,
-                                                             int ldx, int ldc, ConvGeom g, int tiles_n, int nwg) {
+                                                             int ldx, int ldc, ConvGeom g, int tiles_n, int nwg,
+                                                             unsigned xbytes, unsigned wbytes) {
   constexpr int VEC = ST<T>::VEC;
   constexpr int BK = ROWB / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -117,7 +128,6 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict
   // staging assignment: chunk c = tid&7 of rows (tid>>3) + 32*i
   const int sc = tid & 7, sr = tid >> 3;
   int py[4], px[4];
-  long pbase[4];
   if constexpr (CONV) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -126,12 +136,12 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict
       const int b = m / hw, rem = m - b * hw;
       py[i] = rem / g.W;
       px[i] = rem - py[i] * g.W;
-      pbase[i] = (long)m;
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { py[i] = px[i] = 0; pbase[i] = 0; }
+    for (int i = 0; i < 4; ++i) { py[i] = px[i] = 0; }
   }
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, xbytes), wr = make_rsrc(W, wbytes);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -139,17 +149,20 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 rx[4], rw[4];
-  auto gload = [&](int kt) {
+  // two register stages: tile t+1 and t+2 are in flight while tile t is multiplied (global latency spans two MFMA phases)
+  u32x4 rxA[4], rwA[4], rxB[4], rwB[4];
+  auto gload = [&](int kt, u32x4 (&rx)[4], u32x4 (&rw)[4]) {
     const int k0 = kt * BK + sc * VEC;
+    const bool kin = k0 < K;   // K tail (only the last tile): out-of-range offset -> hardware returns 0, no branch, no post-load op
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      rx[i] = load_x_chunk<T, CONV>(X, m0 + sr + 32 * i, k0, M, K, ldx, g, py[i], px[i], pbase[i]);
-      const int n = n0 + sr + 32 * i;
-      rw[i] = (n < N && k0 < K) ? ld16(W + (long)n * K + k0) : u32x4{0u, 0u, 0u, 0u};
+      const unsigned xo = x_chunk_off<T, CONV>(m0 + sr + 32 * i, k0, ldx, g, py[i], px[i]);
+      const unsigned wo = (unsigned)(((long)(n0 + sr + 32 * i) * K + k0) * (long)sizeof(T));
+      rx[i] = bload16(xr, kin ? xo : OOB);
+      rw[i] = bload16(wr, kin ? wo : OOB);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const u32x4 (&rx)[4], const u32x4 (&rw)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = sr + 32 * i;
@@ -160,56 +173,98 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict
   };
 
   const int nk = (K + BK - 1) / BK;
-  gload(0);
-  sstore(0);
+  gload(0, rxA, rwA);
+  if (nk > 1) gload(1, rxB, rwB);
+  sstore(0, rxA, rwA);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    mma_tile<T>(Ws + cur * BN * ROWB, Xs + cur * BM * ROWB, wn, wm, lane, acc);
-    if (kt + 1 < nk) sstore(cur ^ 1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) gload(kt + 2, rxA, rwA);
+    mma_tile<T>(Ws, Xs, wn, wm, lane, acc);
+    if (kt + 1 < nk) sstore(1, rxB, rwB);
     __syncthreads();
+    if (kt + 1 < nk) {
+      if (kt + 3 < nk) gload(kt + 3, rxB, rwB);
+      mma_tile<T>(Ws + BN * ROWB, Xs + BM * ROWB, wn, wm, lane, acc);
+      if (kt + 2 < nk) sstore(0, rxA, rwA);
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue: lane holds n = nb + 4q + r (r = 0..3), m = mb + (lane&15)
+  // ---- epilogue: accumulators -> LDS (per-wave 32 x 64 f32 slab, two halves) -> 16-byte coalesced row segments.
+  // lane holds acc[ni][mi][r] = D[n = ni*16 + 4q + r][m = mi*16 + (lane&15)]
+  constexpr int EPS = 68;  // f32 row stride of the slab (64 + 4 pad: conflict-free b128 writes)
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * EPS);
   const int r15 = lane & 15, q = lane >> 4;
   const T* R = reinterpret_cast<const T*>(epi.residual);
   const T* Hh = reinterpret_cast<const T*>(epi.gelu_h);
   T* C2 = reinterpret_cast<T*>(epi.C2);
+  const bool vec_ok = (ldc % 8 == 0);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + r15;
-    if (m >= M) continue;
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 64 + ni * 16 + q * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-      const long o = (long)m * ldc + n;
-      const bool full = (n + 3 < N);
+    for (int mi2 = 0; mi2 < 2; ++mi2)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (!full && n + e >= N) break;
-        float x = v[e];
-        if (epi.bias) x += epi.bias[n + e];
-        if (C2) ST<T>::st(C2 + o + e, x);
-        if (epi.act == SPG_ACT_GELU) x = gelu_f(x);
-        else if (epi.act == SPG_ACT_RELU) x = fmaxf(x, 0.f);
-        if (Hh) x *= gelu_grad_f(ST<T>::ld(Hh + o + e));
-        if (R) x += ST<T>::ld(R + o + e);
-        v[e] = x;
-      }
-      if (full) {
-        if constexpr (sizeof(T) == 2) {
-          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(C + o) = pk;
+      for (int ni = 0; ni < 4; ++ni)
+        *reinterpret_cast<f32x4*>(slab + (mi2 * 16 + r15) * EPS + ni * 16 + q * 4) = acc[ni][half * 2 + mi2];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lane >> 3) + 8 * j, ch = lane & 7;
+      const int m = m0 + wm * 64 + half * 32 + row;
+      const int n = n0 + wn * 64 + ch * 8;
+      if (m < M && n < N) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8 + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const long o = (long)m * ldc + n;
+        if (vec_ok && n + 7 < N) {
+          if (epi.bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(epi.bias + n), b1 = *reinterpret_cast<const f32x4*>(epi.bias + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          }
+          if (C2) {
+            if constexpr (sizeof(T) == 2) st16(C2 + o, pack16<T>(v));
+            else { st16(C2 + o, pack16<T>(v)); st16(C2 + o + 4, pack16<T>(v + 4)); }
+          }
+          if (epi.act == SPG_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          } else if (epi.act == SPG_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (Hh) {
+            float h[8];
+            if constexpr (sizeof(T) == 2) unpack16<T>(ld16(Hh + o), h);
+            else { unpack16<T>(ld16(Hh + o), h); unpack16<T>(ld16(Hh + o + 4), h + 4); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(h[e]);
+          }
+          if (R) {
+            float rr[8];
+            if constexpr (sizeof(T) == 2) unpack16<T>(ld16(R + o), rr);
+            else { unpack16<T>(ld16(R + o), rr); unpack16<T>(ld16(R + o + 4), rr + 4); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rr[e];
+          }
+          if constexpr (sizeof(T) == 2) st16(C + o, pack16<T>(v));
+          else { st16(C + o, pack16<T>(v)); st16(C + o + 4, pack16<T>(v + 4)); }
         } else {
-          *reinterpret_cast<f32x4*>(C + o) = f32x4{v[0], v[1], v[2], v[3]};
+          for (int e = 0; e < 8 && n + e < N; ++e) {
+            float x = v[e];
+            if (epi.bias) x += epi.bias[n + e];
+            if (C2) ST<T>::st(C2 + o + e, x);
+            if (epi.act == SPG_ACT_GELU) x = gelu_f(x);
+            else if (epi.act == SPG_ACT_RELU) x = fmaxf(x, 0.f);
+            if (Hh) x *= gelu_grad_f(ST<T>::ld(Hh + o + e));
+            if (R) x += ST<T>::ld(R + o + e);
+            ST<T>::st(C + o + e, x);
+          }
         }
-      } else {
-        for (int e = 0; e < 4 && n + e < N; ++e) ST<T>::st(C + o + e, v[e]);
       }
     }
+    if (half == 0) __syncthreads();
   }
 }
 
@@ -272,7 +327,8 @@ __device__ __forceinline__ void store_patch(char* img, const u32x4 (&rows)[4], i
 template <typename T, bool CONV>
 __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict__ dY, const T* __restrict__ X,
                                                              float* __restrict__ dW, int M, int N, int K, int ldy,
-                                                             int ldx, int ldw, ConvGeom g, int tiles_k, int m_per_split) {
+                                                             int ldx, int ldw, ConvGeom g, int tiles_k, int m_per_split,
+                                                             unsigned ybytes, unsigned xbytes) {
   constexpr int VEC = ST<T>::VEC;
   constexpr int MSTEP = ROWB / (int)sizeof(T);  // m rows per LDS tile: 64 (bf16) / 32 (f32)
   constexpr int NCH = 128 / VEC;                // feature chunks per tile row: 16 / 32
@@ -295,28 +351,35 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 ra[4], rb[4];
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(dY, ybytes), xr = make_rsrc(X, xbytes);
+  int tap_dy = 0, tap_dx = 0, tap_ci = 0;
+  {
+    const int k = k0 + fc * VEC;
+    if constexpr (CONV) {
+      const int tap = k / g.Ci;
+      tap_ci = k - tap * g.Ci; tap_dy = tap / 3 - 1; tap_dx = tap - (tap / 3) * 3 - 1;
+    }
+  }
   auto gload = [&](int mt) {
     const int mb = m_begin + mt * MSTEP + mg * 4;
     const int n = n0 + fc * VEC, k = k0 + fc * VEC;
+    const bool nin = n < N, kin = k < K;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mb + i;
       const bool mv = m < m_end;
-      ra[i] = (mv && n < N) ? ld16(dY + (long)m * ldy + n) : u32x4{0u, 0u, 0u, 0u};
+      const unsigned yo = (unsigned)(((long)m * ldy + n) * (long)sizeof(T));
+      ra[i] = bload16(yr, (mv && nin) ? yo : OOB);
       if constexpr (!CONV) {
-        rb[i] = (mv && k < K) ? ld16(X + (long)m * ldx + k) : u32x4{0u, 0u, 0u, 0u};
+        const unsigned xo = (unsigned)(((long)m * ldx + k) * (long)sizeof(T));
+        rb[i] = bload16(xr, (mv && kin) ? xo : OOB);
       } else {
-        u32x4 z = {0u, 0u, 0u, 0u};
-        if (mv && k < K) {
-          const int hw = g.H * g.W;
-          const int b = m / hw, rem = m - b * hw;
-          const int y = rem / g.W, x = rem - y * g.W;
-          const int tap = k / g.Ci, ci = k - tap * g.Ci;
-          const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-          if ((unsigned)(y + dy) < (unsigned)g.H && (unsigned)(x + dx) < (unsigned)g.W)
-            z = ld16(X + ((long)m + (long)dy * g.W + dx) * g.Ci + ci);
-        }
-        rb[i] = z;
+        const int hw = g.H * g.W;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / g.W, x = rem - y * g.W;
+        const bool in = mv && (unsigned)(y + tap_dy) < (unsigned)g.H && (unsigned)(x + tap_dx) < (unsigned)g.W;
+        const unsigned xo = (unsigned)((((long)m + (long)tap_dy * g.W + tap_dx) * g.Ci + tap_ci) * (long)sizeof(T));
+        rb[i] = bload16(xr, (in && kin) ? xo : OOB);
       }
     }
   };
@@ -409,12 +472,17 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
   const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, BM);
   const int nwg = tiles_n * tiles_m;
   const size_t lds = 4 * 128 * ROWB;
+  const long xb = (conv ? (long)M * g.Ci : (long)M * ldx) * (long)sizeof(T), wb = (long)N * K * (long)sizeof(T);
+  if (xb >= 0xFFFFFFF0L || wb >= 0xFFFFFFF0L) {
+    set_error("gemm_nt: operand larger than 4 GiB (X %ld B, W %ld B) is not addressable by one buffer descriptor", xb, wb);
+    return SPG_ERR_UNSUPPORTED;
+  }
   if (conv)
     hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(nwg), dim3(NT_THREADS), lds, s, (const T*)X, (const T*)W, (T*)C,
-                       epi, M, N, K, ldx, ldc, g, tiles_n, nwg);
+                       epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(nwg), dim3(NT_THREADS), lds, s, (const T*)X, (const T*)W,
-                       (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg);
+                       (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
   return check_launch("gemm_nt");
 }
 
@@ -431,12 +499,17 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
   int m_per_split = cdiv(cdiv(M, splits), MSTEP) * MSTEP;
   splits = cdiv(M, m_per_split);
   const size_t lds = 4 * 128 * ROWB;
+  const long yb = (long)M * ldy * (long)sizeof(T), xb = (conv ? (long)M * g.Ci : (long)M * ldx) * (long)sizeof(T);
+  if (xb >= 0xFFFFFFF0L || yb >= 0xFFFFFFF0L) {
+    set_error("gemm_tn: operand larger than 4 GiB is not addressable by one buffer descriptor");
+    return SPG_ERR_UNSUPPORTED;
+  }
   if (conv)
     hipLaunchKernelGGL((gemm_tn_kernel<T, true>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
-                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split);
+                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<T, false>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
-                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split);
+                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb);
   return check_launch("gemm_tn");
 }
 
