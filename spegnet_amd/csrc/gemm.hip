@@ -13,6 +13,7 @@
 //
 // MFMA operand roles: "A" = weight rows (n), "B" = activation rows (m)  =>  D[n][m]: a lane holds 4
 // consecutive n for one m, so the epilogue reads bias / writes C as 8- or 16-byte vectors.
+#include <stdlib.h>
 #include "common.h"
 
 namespace spg {
@@ -269,6 +270,187 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_nt, LDS-DMA pipeline (the default): persistent workgroups (one per CU) walk their tiles; operands stream
+// global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, so hipcc has no register dependences to serialise)
+// into a 3-stage ring; a K-step is {counted vmcnt -> raw s_barrier -> issue DMA for step+2 -> 32 MFMAs per wave}.
+// The ring runs across tile boundaries, so the next tile's first K-steps land while the current tile's epilogue runs.
+// LDS image per stage is identical to the register-staged kernel: 128-byte rows, 16-byte chunk p of row r holds logical
+// chunk p ^ (r & 7); the DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE offset
+// (cdna_hip_programming.md rule 21).  Out-of-range rows / the K tail use out-of-range buffer offsets (hardware zero fill).
+// ------------------------------------------------------------------------------------------------
+constexpr int DMA_STAGES = 3;
+constexpr int DMA_STAGE_BYTES = 2 * 128 * ROWB;      // X tile + W tile
+constexpr int DMA_SLAB_BYTES = 4 * 32 * 68 * 4;      // per-wave epilogue slabs
+constexpr int DMA_LDS_BYTES = DMA_STAGES * DMA_STAGE_BYTES + DMA_SLAB_BYTES;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <typename T, bool CONV>
+__global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                 T* __restrict__ C, NtEpi epi, int M, int N, int K, int ldx,
+                                                                 int ldc, ConvGeom g, int tiles_n, int ntiles,
+                                                                 unsigned xbytes, unsigned wbytes) {
+  constexpr int VEC = ST<T>::VEC;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int nkt = (K + BK - 1) / BK;
+  const int G = (int)gridDim.x;
+  const int first = xcd_remap(blockIdx.x, G);
+  if (first >= ntiles) return;
+  const int my_tiles = (ntiles - first + G - 1) / G;
+  const int total = my_tiles * nkt;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, xbytes), wr = make_rsrc(W, wbytes);
+
+  // ---- DMA issue stream state (runs DMA_STAGES-1 steps ahead of the MFMAs)
+  const int lrow = lane >> 3;             // row within an 8-row DMA piece
+  const int lp = lane & 7;                // physical 16-byte chunk
+  int is_j = -1, is_m0 = 0, is_n0 = 0;
+  int py[4], px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { py[i] = 0; px[i] = 0; }
+  auto issue = [&](int gs) {
+    const int j = gs / nkt, kt = gs - j * nkt;
+    if (j != is_j) {
+      is_j = j;
+      const int tile = first + j * G;
+      const int tn = tile % tiles_n, tm = tile / tiles_n;
+      is_m0 = tm * BM; is_n0 = tn * BN;
+      if constexpr (CONV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = is_m0 + 32 * i + wave * 8 + lrow;
+          const int hw = g.H * g.W;
+          const int b = m / hw, rem = m - b * hw;
+          py[i] = rem / g.W; px[i] = rem - py[i] * g.W;
+        }
+      }
+    }
+    char* st = smem + (gs % DMA_STAGES) * DMA_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int prow = 32 * i + wave * 8;           // first row of this wave-instruction's 1 KiB piece
+      const int row = prow + lrow;
+      const int k0 = kt * BK + ((lp ^ (row & 7)) * VEC);
+      const bool kin = k0 < K;
+      const unsigned xo = x_chunk_off<T, CONV>(is_m0 + row, k0, ldx, g, py[i], px[i]);
+      const unsigned wo = (unsigned)(((long)(is_n0 + row) * K + k0) * (long)sizeof(T));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + prow * ROWB), 16, kin ? xo : OOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * ROWB + prow * ROWB), 16, kin ? wo : OOB, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int gi = 0;
+  for (; gi < DMA_STAGES - 1 && gi < total; ++gi) issue(gi);
+
+  constexpr int EPS = 68;
+  float* slab = reinterpret_cast<float*>(smem + DMA_STAGES * DMA_STAGE_BYTES) + wave * (32 * EPS);
+  const int r15 = lane & 15, q = lane >> 4;
+  const T* R = reinterpret_cast<const T*>(epi.residual);
+  const T* Hh = reinterpret_cast<const T*>(epi.gelu_h);
+  T* C2 = reinterpret_cast<T*>(epi.C2);
+  const bool vec_ok = (ldc % 8 == 0);
+
+  int kt = 0, j = 0;
+  for (int gc = 0; gc < total; ++gc) {
+    // step gc's 8 DMA pieces (per wave) must have landed; newer groups may stay in flight
+    if (gi - gc >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (gi < total) { issue(gi); ++gi; }
+    const char* st = smem + (gc % DMA_STAGES) * DMA_STAGE_BYTES;
+    mma_tile<T>(st + BM * ROWB, st, wn, wm, lane, acc);
+    if (++kt == nkt) {
+      // ---- epilogue of tile j (per-wave slab, no block barrier: waves run ahead into the next tile independently)
+      const int tile = first + j * G;
+      const int tn = tile % tiles_n, tm = tile / tiles_n;
+      const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            *reinterpret_cast<f32x4*>(slab + (mi2 * 16 + r15) * EPS + ni * 16 + q * 4) = acc[ni][half * 2 + mi2];
+            acc[ni][half * 2 + mi2] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int row = (lane >> 3) + 8 * jj, ch = lane & 7;
+          const int m = m0 + wm * 64 + half * 32 + row;
+          const int n = n0 + wn * 64 + ch * 8;
+          if (m < M && n < N) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8 + 4);
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const long o = (long)m * ldc + n;
+            if (vec_ok && n + 7 < N) {
+              if (epi.bias) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(epi.bias + n), b1 = *reinterpret_cast<const f32x4*>(epi.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+              }
+              if (C2) {
+                if constexpr (sizeof(T) == 2) st16(C2 + o, pack16<T>(v));
+                else { st16(C2 + o, pack16<T>(v)); st16(C2 + o + 4, pack16<T>(v + 4)); }
+              }
+              if (epi.act == SPG_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+              } else if (epi.act == SPG_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+              }
+              if (Hh) {
+                float h[8];
+                if constexpr (sizeof(T) == 2) unpack16<T>(ld16(Hh + o), h);
+                else { unpack16<T>(ld16(Hh + o), h); unpack16<T>(ld16(Hh + o + 4), h + 4); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(h[e]);
+              }
+              if (R) {
+                float rr[8];
+                if constexpr (sizeof(T) == 2) unpack16<T>(ld16(R + o), rr);
+                else { unpack16<T>(ld16(R + o), rr); unpack16<T>(ld16(R + o + 4), rr + 4); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rr[e];
+              }
+              if constexpr (sizeof(T) == 2) st16(C + o, pack16<T>(v));
+              else { st16(C + o, pack16<T>(v)); st16(C + o + 4, pack16<T>(v + 4)); }
+            } else {
+              for (int e = 0; e < 8 && n + e < N; ++e) {
+                float x = v[e];
+                if (epi.bias) x += epi.bias[n + e];
+                if (C2) ST<T>::st(C2 + o + e, x);
+                if (epi.act == SPG_ACT_GELU) x = gelu_f(x);
+                else if (epi.act == SPG_ACT_RELU) x = fmaxf(x, 0.f);
+                if (Hh) x *= gelu_grad_f(ST<T>::ld(Hh + o + e));
+                if (R) x += ST<T>::ld(R + o + e);
+                ST<T>::st(C + o + e, x);
+              }
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+      kt = 0; ++j;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // TN: dW[n][k] += sum_m dY[m][n] * X[m][k].  LDS rows are output features (n for the dY operand, k for the
 // X operand), 128 bytes of consecutive m per row; register transpose of 4(m) x 16-byte patches.
 // swizzle for these images: sw(f) = (f ^ (f >> 4)) & 7 -> fragment reads conflict free, patch writes 2-way.
@@ -466,17 +648,52 @@ __global__ void unpack_conv3x3_grad_kernel(const float* __restrict__ packed, flo
   }
 }
 
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+static int gemm_variant() {  // SPG_GEMM=staged selects the register-staged kernel (A/B runs); default = LDS-DMA pipeline
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SPG_GEMM");
+    v = (e && strcmp(e, "staged") == 0) ? 0 : 1;
+  }
+  return v;
+}
+
 template <typename T>
 static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, int N, int K, int ldx, int ldc, int conv,
                      ConvGeom g, hipStream_t s) {
   const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, BM);
   const int nwg = tiles_n * tiles_m;
-  const size_t lds = 4 * 128 * ROWB;
   const long xb = (conv ? (long)M * g.Ci : (long)M * ldx) * (long)sizeof(T), wb = (long)N * K * (long)sizeof(T);
   if (xb >= 0xFFFFFFF0L || wb >= 0xFFFFFFF0L) {
     set_error("gemm_nt: operand larger than 4 GiB (X %ld B, W %ld B) is not addressable by one buffer descriptor", xb, wb);
     return SPG_ERR_UNSUPPORTED;
   }
+  if (gemm_variant() == 1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
+      attr_set = true;
+    }
+    const int grid = nwg < num_cus() ? nwg : num_cus();
+    if (conv)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, true>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
+                         (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+    else
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
+                         (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+    return check_launch("gemm_nt(dma)");
+  }
+  const size_t lds = 4 * 128 * ROWB;
   if (conv)
     hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(nwg), dim3(NT_THREADS), lds, s, (const T*)X, (const T*)W, (T*)C,
                        epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
