@@ -38,19 +38,23 @@ const char* spg_last_error(void);
  *   epilogue order: +bias[n] (f32) -> store pre-activation to C2 (optional) -> act -> *gelu'(gelu_h[m,n])
  *   (optional) -> +residual[m,n] (optional) -> C.
  *   conv3x3 != 0: X is NHWC [B,H,W,Ci], M=B*H*W, K=9*Ci, k = tap*Ci+ci (pad 1, stride 1), W packed [N][9*Ci].
- * spg_gemm_tn: dW[N,K] += dY[M,N]^T . X[M,K]   (f32 atomic accumulation; same conv3x3 gather on X)
+ * spg_gemm_tn: dW[N,K] += dY[M,N]^T . X[M,K]   (f32 atomic accumulation; same conv3x3 gather on X);
+ *   dbias != NULL: also dbias[n] += sum_m dY[m][n] (the bias gradient, fused so dY is read once)
  *   replaces the weight-gradient half of linear/conv backward (engine/trainer.py:402 .backward()).    */
 int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, void* C2, const float* bias,
                 const void* residual, const void* gelu_h, int M, int N, int K, int ldx, int ldc, int act,
                 int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream);
-int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx,
-                int ldw, int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream);
+int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy,
+                int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream);
 
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
  * spg_pack_matrix: dst[r][c] = src[r][c] (transpose=0) or dst[c][r] = src[r][c] (transpose=1), src f32 [R,C].
  * spg_pack_conv3x3: torch [Co,Ci,3,3] f32 -> fwd pack [Co][tap][Ci] and dgrad pack [Ci][tap'][Co] (tap' flipped).
  * spg_unpack_conv3x3_grad: packed f32 grad [Co][tap][Ci] -> torch layout [Co,Ci,3,3] (accumulates: dst += packed). */
 int spg_pack_matrix(int dtype, const float* src, void* dst, int R, int C, int transpose, spg_stream_t stream);
+/* spg_pack_batch: the same for a whole table of matrices in ONE launch.  jobs = device array of
+ * struct { const float* src; void* dst; int R, C, transpose, tile0; } (tile0 = prefix sum of ceil(R/32)*ceil(C/32)). */
+int spg_pack_batch(int dtype, const void* jobs, int njobs, int total_tiles, spg_stream_t stream);
 int spg_pack_conv3x3(int dtype, const float* src, void* dst_fwd, void* dst_dgrad, int Co, int Ci, spg_stream_t stream);
 int spg_unpack_conv3x3_grad(const float* packed, float* dst, int Co, int Ci, spg_stream_t stream);
 

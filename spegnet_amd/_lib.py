@@ -19,8 +19,9 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 # name -> argument type string (p pointer, i int, l long, f float); every function returns int
 SIGNATURES = {
     "spg_gemm_nt": "ipppppppiiiiiiiiiiip",
-    "spg_gemm_tn": "ipppiiiiiiiiiiip",
+    "spg_gemm_tn": "ippppiiiiiiiiiiip",
     "spg_pack_matrix": "ippiiip",
+    "spg_pack_batch": "ipiip",
     "spg_pack_conv3x3": "ipppiip",
     "spg_unpack_conv3x3_grad": "ppiip",
     "spg_layernorm_fwd": "ipppppp" "iifp",

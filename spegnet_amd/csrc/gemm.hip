@@ -278,14 +278,16 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict
 // chunk p ^ (r & 7); the DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE offset
 // (cdna_hip_programming.md rule 21).  Out-of-range rows / the K tail use out-of-range buffer offsets (hardware zero fill).
 // ------------------------------------------------------------------------------------------------
-constexpr int DMA_STAGES = 3;
+constexpr int DMA_STAGES = 4;
 constexpr int DMA_STAGE_BYTES = 2 * 128 * ROWB;      // X tile + W tile
-constexpr int DMA_SLAB_BYTES = 4 * 32 * 68 * 4;      // per-wave epilogue slabs
+constexpr int DMA_SLAB_BYTES = 4 * 16 * 68 * 4;      // per-wave epilogue slabs (16 rows x 64 f32 + pad)
 constexpr int DMA_LDS_BYTES = DMA_STAGES * DMA_STAGE_BYTES + DMA_SLAB_BYTES;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <typename T, bool CONV>
+// DBG: 0 = product kernel; 1 = skip the DMA issue (times MFMA + LDS reads alone); 2 = skip the MFMAs (times the fill
+// pipeline alone).  1 and 2 produce wrong results by construction and are reachable only through SPG_GEMM_DEBUG.
+template <typename T, bool CONV, int DBG = 0>
 __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                                  T* __restrict__ C, NtEpi epi, int M, int N, int K, int ldx,
                                                                  int ldc, ConvGeom g, int tiles_n, int ntiles,
@@ -337,8 +339,12 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __rest
       const bool kin = k0 < K;
       const unsigned xo = x_chunk_off<T, CONV>(is_m0 + row, k0, ldx, g, py[i], px[i]);
       const unsigned wo = (unsigned)(((long)(is_n0 + row) * K + k0) * (long)sizeof(T));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + prow * ROWB), 16, kin ? xo : OOB, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * ROWB + prow * ROWB), 16, kin ? wo : OOB, 0, 0, 0);
+      if constexpr (DBG != 1) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + prow * ROWB), 16, kin ? xo : OOB, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * ROWB + prow * ROWB), 16, kin ? wo : OOB, 0, 0, 0);
+      } else {
+        asm volatile("" :: "v"(xo), "v"(wo));
+      }
     }
   };
 
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __rest
   for (; gi < DMA_STAGES - 1 && gi < total; ++gi) issue(gi);
 
   constexpr int EPS = 68;
-  float* slab = reinterpret_cast<float*>(smem + DMA_STAGES * DMA_STAGE_BYTES) + wave * (32 * EPS);
+  float* slab = reinterpret_cast<float*>(smem + DMA_STAGES * DMA_STAGE_BYTES) + wave * (16 * EPS);
   const int r15 = lane & 15, q = lane >> 4;
   const T* R = reinterpret_cast<const T*>(epi.residual);
   const T* Hh = reinterpret_cast<const T*>(epi.gelu_h);
@@ -362,33 +368,35 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __rest
   int kt = 0, j = 0;
   for (int gc = 0; gc < total; ++gc) {
     // step gc's 8 DMA pieces (per wave) must have landed; newer groups may stay in flight
-    if (gi - gc >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+      const int ahead = gi - gc - 1;   // DMA groups younger than step gc's (8 pieces each)
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (gi < total) { issue(gi); ++gi; }
     const char* st = smem + (gc % DMA_STAGES) * DMA_STAGE_BYTES;
-    mma_tile<T>(st + BM * ROWB, st, wn, wm, lane, acc);
+    if constexpr (DBG != 2) mma_tile<T>(st + BM * ROWB, st, wn, wm, lane, acc);
     if (++kt == nkt) {
       // ---- epilogue of tile j (per-wave slab, no block barrier: waves run ahead into the next tile independently)
       const int tile = first + j * G;
       const int tn = tile % tiles_n, tm = tile / tiles_n;
       const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int quarter = 0; quarter < 4; ++quarter) {
 #pragma unroll
-        for (int mi2 = 0; mi2 < 2; ++mi2)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            *reinterpret_cast<f32x4*>(slab + (mi2 * 16 + r15) * EPS + ni * 16 + q * 4) = acc[ni][half * 2 + mi2];
-            acc[ni][half * 2 + mi2] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+        for (int ni = 0; ni < 4; ++ni) {
+          *reinterpret_cast<f32x4*>(slab + r15 * EPS + ni * 16 + q * 4) = acc[ni][quarter];
+          acc[ni][quarter] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < 2; ++jj) {
           const int row = (lane >> 3) + 8 * jj, ch = lane & 7;
-          const int m = m0 + wm * 64 + half * 32 + row;
+          const int m = m0 + wm * 64 + quarter * 16 + row;
           const int n = n0 + wn * 64 + ch * 8;
           if (m < M && n < N) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8);
@@ -510,7 +518,7 @@ template <typename T, bool CONV>
 __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict__ dY, const T* __restrict__ X,
                                                              float* __restrict__ dW, int M, int N, int K, int ldy,
                                                              int ldx, int ldw, ConvGeom g, int tiles_k, int m_per_split,
-                                                             unsigned ybytes, unsigned xbytes) {
+                                                             unsigned ybytes, unsigned xbytes, float* __restrict__ dbias) {
   constexpr int VEC = ST<T>::VEC;
   constexpr int MSTEP = ROWB / (int)sizeof(T);  // m rows per LDS tile: 64 (bf16) / 32 (f32)
   constexpr int NCH = 128 / VEC;                // feature chunks per tile row: 16 / 32
@@ -533,6 +541,11 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 ra[4], rb[4];
+  // fused bias gradient: the k-tile-0 blocks also accumulate column sums of their dY patches (db[n] = sum_m dY[m][n])
+  const bool do_bias = (dbias != nullptr) && (tk == 0);
+  float bsum[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) bsum[e] = 0.f;
   const __amdgpu_buffer_rsrc_t yr = make_rsrc(dY, ybytes), xr = make_rsrc(X, xbytes);
   int tap_dy = 0, tap_dx = 0, tap_ci = 0;
   {
@@ -566,6 +579,15 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
     }
   };
   auto sstore = [&](int buf) {
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f[VEC];
+        unpack16<T>(ra[i], f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bsum[e] += f[e];
+      }
+    }
     store_patch<T>(As + buf * 128 * ROWB, ra, fc * VEC, mg);
     store_patch<T>(Bs + buf * 128 * ROWB, rb, fc * VEC, mg);
   };
@@ -581,6 +603,18 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
     mma_tile_tn<T>(As + cur * 128 * ROWB, Bs + cur * 128 * ROWB, wn, wk, lane, acc);
     if (mt + 1 < nm) sstore(cur ^ 1);
     __syncthreads();
+  }
+  if (do_bias) {  // reduce the per-thread partial sums over the m-groups through LDS (the MFMA loop is finished)
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int NMG = NT_THREADS / NCH;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[mg * 128 + fc * VEC + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+      for (int r = 0; r < NMG; ++r) t += red[r * 128 + tid];
+      if (n0 + tid < N) atomicAdd(dbias + n0 + tid, t);
+    }
   }
   // lane holds n = nb + 4q + r, k = kb + (lane&15)
   const int r15 = lane & 15, q = lane >> 4;
@@ -620,6 +654,47 @@ __global__ void pack_matrix_kernel(const float* __restrict__ src, T* __restrict_
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int c = bx + j, r = by + tx;  // dst[c][r]
+    if (r < R && c < C) ST<T>::st(dst + (long)c * R + r, tile[tx][j]);
+  }
+}
+
+// Batched form of pack_matrix: one launch re-packs every Linear / 1x1 weight of the model (job table in device memory;
+// a block finds its job by binary search over the tile prefix sums).  Removes ~400 tiny launches per optimizer step.
+struct PackJob {
+  const float* src;
+  void* dst;
+  int R, C, transpose, tile0;   // tile0 = first 32x32 tile index of this job
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = njobs - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {  // last job with tile0 <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackJob jb = jobs[lo];
+  const int t = b - jb.tile0;
+  const int tiles_c = (jb.C + 31) >> 5;
+  const int bx = (t % tiles_c) * 32, by = (t / tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  T* dst = reinterpret_cast<T*>(jb.dst);
+  const int R = jb.R, C = jb.C;
+  if (!jb.transpose) {
+    for (int j = ty; j < 32; j += 8) {
+      const int r = by + j, c = bx + tx;
+      if (r < R && c < C) ST<T>::st(dst + (long)r * C + c, jb.src[(long)r * C + c]);
+    }
+    return;
+  }
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < R && c < C) ? jb.src[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
     if (r < R && c < C) ST<T>::st(dst + (long)c * R + r, tile[tx][j]);
   }
 }
@@ -685,6 +760,20 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
       attr_set = true;
     }
     const int grid = nwg < num_cus() ? nwg : num_cus();
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("SPG_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg == 1 && !conv) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 1>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
+                         (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      return check_launch("gemm_nt(dbg1)");
+    }
+    if (dbg == 2 && !conv) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 2>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
+                         (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      return check_launch("gemm_nt(dbg2)");
+    }
     if (conv)
       hipLaunchKernelGGL((gemm_nt_dma_kernel<T, true>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
                          (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
@@ -705,7 +794,7 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
 
 template <typename T>
 static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx, int ldw, int conv,
-                     ConvGeom g, hipStream_t s) {
+                     ConvGeom g, hipStream_t s, float* dbias) {
   constexpr int MSTEP = ROWB / (int)sizeof(T);
   const int tiles_n = cdiv(N, 128), tiles_k = cdiv(K, 128);
   const int tiles = tiles_n * tiles_k;
@@ -723,10 +812,10 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
   }
   if (conv)
     hipLaunchKernelGGL((gemm_tn_kernel<T, true>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
-                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb);
+                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<T, false>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
-                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb);
+                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
   return check_launch("gemm_tn");
 }
 
@@ -754,8 +843,8 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
                            : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s);
 }
 
-extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx,
-                           int ldw, int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream) {
+extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy,
+                           int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream) {
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "gemm_tn: bad dtype %d", dtype);
   SPG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem");
@@ -767,8 +856,8 @@ extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, 
     SPG_REQUIRE(ldx % vec == 0 && ldx >= K, "gemm_tn: bad ldx=%d", ldx);
   }
   hipStream_t s = (hipStream_t)stream;
-  return dtype == SPG_BF16 ? launch_tn<bf16_t>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s)
-                           : launch_tn<float>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s);
+  return dtype == SPG_BF16 ? launch_tn<bf16_t>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias)
+                           : launch_tn<float>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias);
 }
 
 extern "C" int spg_pack_matrix(int dtype, const float* src, void* dst, int R, int C, int transpose, spg_stream_t stream) {
@@ -779,6 +868,15 @@ extern "C" int spg_pack_matrix(int dtype, const float* src, void* dst, int R, in
   else
     hipLaunchKernelGGL(pack_matrix_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, R, C, transpose);
   return check_launch("pack_matrix");
+}
+
+extern "C" int spg_pack_batch(int dtype, const void* jobs, int njobs, int total_tiles, spg_stream_t stream) {
+  SPG_REQUIRE(njobs > 0 && total_tiles > 0, "pack_batch: empty job table");
+  if (dtype == SPG_BF16)
+    hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs, njobs);
+  else
+    hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs, njobs);
+  return check_launch("pack_batch");
 }
 
 extern "C" int spg_pack_conv3x3(int dtype, const float* src, void* dst_fwd, void* dst_dgrad, int Co, int Ci,

@@ -55,84 +55,53 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
-// dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) (+dres); dgamma += sum dy*xhat; dbeta += sum dy.
-// A wave walks rows with a grid stride and keeps per-lane channel partials in registers.
+// dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) (+dres).  One wave per row, row held in registers (full
+// thread-level parallelism hides HBM latency); the parameter gradients dgamma = sum_rows dy*xhat, dbeta = sum_rows dy are
+// column reductions done by colreduce_kernel<RED_LN> (a second, bandwidth-bound pass over dy and x).
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
-                                                            T* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int M, int C) {
+                                                            T* __restrict__ dx, int M, int C) {
   constexpr int VEC = ST<T>::VEC;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
   const int nch = C / VEC;
-  float g[LN_MAXCH][VEC], dg[LN_MAXCH][VEC], db[LN_MAXCH][VEC];
+  const float mu = mean[row], rs = rstd[row];
+  float xh[LN_MAXCH][VEC], gd[LN_MAXCH][VEC];
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
     const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float xv[VEC], dv[VEC];
+      unpack16<T>(ld16(x + (long)row * C + ch * VEC), xv);
+      unpack16<T>(ld16(dy + (long)row * C + ch * VEC), dv);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      g[i][e] = (ch < nch) ? gamma[ch * VEC + e] : 0.f;
-      dg[i][e] = 0.f; db[i][e] = 0.f;
-    }
-  }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[LN_MAXCH][VEC], gd[LN_MAXCH][VEC];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nch) {
-        float xv[VEC], dv[VEC];
-        unpack16<T>(ld16(x + (long)row * C + ch * VEC), xv);
-        unpack16<T>(ld16(dy + (long)row * C + ch * VEC), dv);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          xh[i][e] = (xv[e] - mu) * rs;
-          gd[i][e] = dv[e] * g[i][e];
-          s1 += gd[i][e];
-          s2 += gd[i][e] * xh[i][e];
-          dg[i][e] += dv[e] * xh[i][e];
-          db[i][e] += dv[e];
-        }
-      }
-    }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
-#pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nch) {
-        float o[VEC];
-        if (dres) unpack16<T>(ld16(dres + (long)row * C + ch * VEC), o);
-        else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) o[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] += rs * (gd[i][e] - s1 - xh[i][e] * s2);
-        st16(dx + (long)row * C + ch * VEC, pack16<T>(o));
+      for (int e = 0; e < VEC; ++e) {
+        xh[i][e] = (xv[e] - mu) * rs;
+        gd[i][e] = dv[e] * gamma[ch * VEC + e];
+        s1 += gd[i][e];
+        s2 += gd[i][e] * xh[i][e];
       }
     }
   }
-  // cross-wave reduce through LDS, then one atomic per channel per block
-  __shared__ float red[4][64 * VEC + 1];
-  for (int pass = 0; pass < 2; ++pass) {
+  s1 = wave_sum(s1) / C;
+  s2 = wave_sum(s2) / C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      if (64 * i >= nch) break;
-      __syncthreads();
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float o[VEC];
+      if (dres) unpack16<T>(ld16(dres + (long)row * C + ch * VEC), o);
+      else {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) red[wave][lane * VEC + e] = pass ? db[i][e] : dg[i][e];
-      __syncthreads();
-      for (int j = threadIdx.x; j < 64 * VEC; j += 256) {
-        const int c = 64 * i * VEC + j;
-        if (c < C) {
-          const float t = red[0][j] + red[1][j] + red[2][j] + red[3][j];
-          atomicAdd((pass ? dbeta : dgamma) + c, t);
-        }
+        for (int e = 0; e < VEC; ++e) o[e] = 0.f;
       }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] += rs * (gd[i][e] - s1 - xh[i][e] * s2);
+      st16(dx + (long)row * C + ch * VEC, pack16<T>(o));
     }
   }
 }
@@ -141,13 +110,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // Column reductions over [M, C] rows (channels fastest): sum (and optionally sum of squares, or sum of
 // dy'*(1, xhat) for BN backward).  A thread owns one 16-byte channel chunk and strides over rows.
 // ---------------------------------------------------------------------------------------------------
-enum { RED_SUM = 0, RED_SUM_SQ = 1, RED_BN_BWD = 2, RED_PROD = 3 };
+enum { RED_SUM = 0, RED_SUM_SQ = 1, RED_BN_BWD = 2, RED_PROD = 3, RED_LN = 4 };
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                         const float* __restrict__ p0, const float* __restrict__ p1,
                                                         float* __restrict__ out, long M, int C, int lda, long rows_per_block,
-                                                        long img_rows, int relu) {
+                                                        long img_rows, int relu, float* __restrict__ out1) {
   constexpr int VEC = ST<T>::VEC;
   const int nch = C / VEC;
   const int rpar = 256 / nch;  // rows handled in parallel by a block
@@ -178,6 +147,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
       } else if constexpr (MODE == RED_SUM_SQ) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { s0[e] += av[e]; s1[e] += av[e] * av[e]; }
+      } else if constexpr (MODE == RED_LN) {  // a = dy, b = x, p0 = mean[row], p1 = rstd[row]
+        float xv[VEC];
+        unpack16<T>(ld16(b + (base + r) * lda + ch * VEC), xv);
+        const float mu_r = p0[base + r], rs_r = p1[base + r];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s0[e] += av[e]; s1[e] += av[e] * (xv[e] - mu_r) * rs_r; }
       } else if constexpr (MODE == RED_PROD) {
         float bv[VEC];
         unpack16<T>(ld16(b + (base + r) * lda + ch * VEC), bv);
@@ -199,7 +174,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x * VEC + e] = s0[e]; red[1][threadIdx.x * VEC + e] = s1[e]; }
   __syncthreads();
-  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD);
+  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN);
   for (int c = threadIdx.x; c < C; c += 256) {
     float t0 = 0.f, t1 = 0.f;
     for (int r = 0; r < rpar; ++r) {
@@ -208,13 +183,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
     }
     float* o = out + (long)blockIdx.y * C * (TWO ? 2 : 1);
     atomicAdd(o + c, t0);
-    if (TWO) atomicAdd(o + C + c, t1);
+    if (TWO) atomicAdd((out1 ? out1 : o + C) + c, t1);
   }
 }
 
 template <typename T, int MODE>
 static int launch_colreduce(const void* a, const void* b, const float* p0, const float* p1, float* out, long M, int C,
-                            int lda, int nimg, long img_rows, int relu, hipStream_t s, const char* what) {
+                            int lda, int nimg, long img_rows, int relu, hipStream_t s, const char* what, float* out1 = nullptr) {
   constexpr int VEC = ST<T>::VEC;
   if (C % VEC != 0 || C / VEC > 256 || lda % VEC != 0) {
     set_error("%s: C=%d (lda=%d) must be a multiple of %d and C/%d <= 256", what, C, lda, VEC, VEC);
@@ -229,7 +204,7 @@ static int launch_colreduce(const void* a, const void* b, const float* p0, const
   if (rpb < min_rpb) rpb = min_rpb;
   const int gx = cdiv(rows, rpb);
   hipLaunchKernelGGL((colreduce_kernel<T, MODE>), dim3(gx, nimg > 0 ? nimg : 1), dim3(256), 0, s, (const T*)a, (const T*)b,
-                     p0, p1, out, M, C, lda, rpb, img_rows, relu);
+                     p0, p1, out, M, C, lda, rpb, img_rows, relu, out1);
   return check_launch(what);
 }
 
@@ -344,14 +319,24 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(M > 0 && C > 0 && C % vec == 0 && C / vec <= 64 * LN_MAXCH, "layernorm_bwd: bad C=%d", C);
   hipStream_t s = (hipStream_t)stream;
-  int grid = cdiv(M, 4 * 2);
-  if (grid > 2048) grid = 2048;
-  if (grid < 1) grid = 1;
   if (dtype == SPG_BF16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, M, C);
+    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(cdiv(M, 4)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
   else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, M, C);
-  return check_launch("layernorm_bwd");
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(cdiv(M, 4)), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, M, C);
+  int rc = check_launch("layernorm_bwd");
+  if (rc || (!dgamma && !dbeta)) return rc;
+  SPG_REQUIRE(dgamma && dbeta, "layernorm_bwd: dgamma and dbeta must both be given");
+  const int step = 256 * vec;
+  const size_t es = dtype == SPG_BF16 ? 2 : 4;
+  for (int c0 = 0; c0 < C; c0 += step) {
+    const int cs = C - c0 < step ? C - c0 : step;
+    const char* dyp = (const char*)dy + (size_t)c0 * es;
+    const char* xp = (const char*)x + (size_t)c0 * es;
+    rc = DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_LN>(dyp, xp, mean, rstd, dbeta + c0, M, cs, C, 0, 0, 0, s, "layernorm_bwd(params)", dgamma + c0)),
+                    (launch_colreduce<float, RED_LN>(dyp, xp, mean, rstd, dbeta + c0, M, cs, C, 0, 0, 0, s, "layernorm_bwd(params)", dgamma + c0)));
+    if (rc) return rc;
+  }
+  return SPG_OK;
 }
 
 extern "C" int spg_colsum(int dtype, const void* x, float* out, int M, int C, int ldx, spg_stream_t stream) {

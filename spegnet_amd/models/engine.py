@@ -51,26 +51,41 @@ class Engine:
         return p.grad
 
     def pack(self):
-        """fp32 master -> compute-dtype copies ([N,K] and [K,N]; 3x3 convs in [Co][tap][Ci] / dgrad form)."""
+        """fp32 master -> compute-dtype copies ([N,K] and [K,N]; 3x3 convs in [Co][tap][Ci] / dgrad form).  All plain
+        matrices go through ONE batched launch (job table built once; parameter storage is stable)."""
         T, P, W = self.dtype, self.P, self.W
-        for name, p in P.items():
-            if not name.endswith(".weight") or p.dim() < 2:
-                continue
-            if name.endswith("patch_embed.proj.weight"):
-                w2 = torch.zeros((p.shape[0], PATCH_KPAD), dtype=torch.float32, device=p.device)
-                w2[:, :147] = p.detach().reshape(p.shape[0], 147)
-                W[name] = ops.pack_matrix(w2, T, out=W.get(name))
-            elif p.dim() == 4 and p.shape[2] == 3 and p.shape[1] > 1:
-                f, d = ops.pack_conv3x3(p.detach(), T, W.get(name), W.get(name + ":dgrad"))
-                W[name], W[name + ":dgrad"] = f, d
-            elif p.dim() == 4 and p.shape[1] == 1:
-                continue  # depth-wise weights are read as fp32 [C][9]
-            elif "se_block" in name or "global_branch" in name or "context.fusion.0" in name or "pred_heads" in name or "edge_conv" in name:
-                continue  # tiny fp32-only layers
-            else:
-                w2 = p.detach().reshape(p.shape[0], -1)
-                W[name] = ops.pack_matrix(w2, T, out=W.get(name))
-                W[name + ":T"] = ops.pack_matrix(w2, T, transpose=True, out=W.get(name + ":T"))
+        if getattr(self, "_pack_jobs", None) is None or self._pack_key != tuple(p.data_ptr() for p in P.values()):
+            import struct
+            jobs, tile0 = [], 0
+            self._pack_conv, self._pack_keep = [], []
+            for name, p in P.items():
+                if not name.endswith(".weight") or p.dim() < 2:
+                    continue
+                if name.endswith("patch_embed.proj.weight"):
+                    continue
+                if p.dim() == 4 and p.shape[2] == 3 and p.shape[1] > 1:
+                    self._pack_conv.append(name)
+                    continue
+                if (p.dim() == 4 and p.shape[1] == 1) or any(k in name for k in ("se_block", "global_branch", "context.fusion.0", "pred_heads", "edge_conv")):
+                    continue  # depth-wise / tiny layers are read as fp32 by their kernels
+                R, C = p.shape[0], p.numel() // p.shape[0]
+                W[name] = torch.empty((R, C), dtype=T, device=p.device)
+                W[name + ":T"] = torch.empty((C, R), dtype=T, device=p.device)
+                for dst, tr in ((W[name], 0), (W[name + ":T"], 1)):
+                    jobs.append(struct.pack("<QQiiii", p.data_ptr(), dst.data_ptr(), R, C, tr, tile0))
+                    tile0 += ((R + 31) // 32) * ((C + 31) // 32)
+            blob = torch.frombuffer(bytearray(b"".join(jobs)), dtype=torch.uint8).to(next(iter(P.values())).device)
+            self._pack_jobs, self._pack_n, self._pack_tiles = blob, len(jobs), tile0
+            self._pack_key = tuple(p.data_ptr() for p in P.values())
+        ops.pack_batch(self._pack_jobs, self._pack_n, self._pack_tiles, T)
+        for name in self._pack_conv:
+            f, d = ops.pack_conv3x3(P[name].detach(), T, W.get(name), W.get(name + ":dgrad"))
+            W[name], W[name + ":dgrad"] = f, d
+        e = "encoder.encoder.patch_embed.proj.weight"
+        pw = P[e]
+        w2 = torch.zeros((pw.shape[0], PATCH_KPAD), dtype=torch.float32, device=pw.device)
+        w2[:, :147] = pw.detach().reshape(pw.shape[0], 147)
+        W[e] = ops.pack_matrix(w2, T, out=W.get(e))
         for b in self.blocks:
             n = f"encoder.encoder.blocks.{b['idx']}.attn.qkv.bias"
             W[n] = P[n].detach().to(T)
@@ -102,9 +117,7 @@ class Engine:
     def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
                 residual: Optional[Tensor] = None, bias: bool = True) -> Optional[Tensor]:
         """dW += dy^T x, db += colsum(dy), returns dx = dy W (optionally * gelu'(h), + residual)."""
-        ops.gemm_tn(dy, x, self.grad(name + ".weight").view(dy.shape[-1], -1))
-        if bias:
-            ops.colsum(dy, self.grad(name + ".bias"))
+        ops.gemm_tn(dy, x, self.grad(name + ".weight").view(dy.shape[-1], -1), dbias=self.grad(name + ".bias") if bias else None)
         if not need_dx:
             return None
         return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual)
@@ -252,9 +265,8 @@ class Engine:
         D = dx.shape[-1]
         d2 = dx.reshape(-1, D)
         pw = torch.zeros((D, PATCH_KPAD), dtype=torch.float32, device=dx.device)
-        ops.gemm_tn(d2, ctx["cols"], pw)
+        ops.gemm_tn(d2, ctx["cols"], pw, dbias=self.grad(e + "patch_embed.proj.bias"))
         self.grad(e + "patch_embed.proj.weight").view(D, 147).add_(pw[:, :147])
-        ops.colsum(d2, self.grad(e + "patch_embed.proj.bias"))
         n_b, n_w, Kp = self._basis_dims
         gpos = torch.zeros((D, Kp), dtype=torch.float32, device=dx.device)
         ops.gemm_tn(d2, ctx["basis"], gpos)
@@ -267,10 +279,8 @@ class Engine:
 
     def conv3_bwd(self, name: str, dy: Tensor, x: Tensor, B, H, W, Ci, Co, bias: bool, need_dx: bool = True):
         gp = torch.zeros((Co, 9 * Ci), dtype=torch.float32, device=dy.device)
-        ops.gemm_tn(dy, x, gp, conv=(B, H, W, Ci))
+        ops.gemm_tn(dy, x, gp, conv=(B, H, W, Ci), dbias=self.grad(name + ".bias") if bias else None)
         ops.unpack_conv3x3_grad(gp, self.grad(name + ".weight"))
-        if bias:
-            ops.colsum(dy, self.grad(name + ".bias"))
         if not need_dx:
             return None
         return ops.gemm_nt(dy, self.W[name + ".weight:dgrad"], conv=(B, H, W, Co))

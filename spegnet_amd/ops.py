@@ -78,8 +78,8 @@ def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = ACT_
     return out
 
 
-def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None) -> None:
-    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]  (conv: x NHWC gathered as in gemm_nt)."""
+def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbias: Optional[Tensor] = None) -> None:
+    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]  (conv: x NHWC gathered as in gemm_nt); dbias[N] += colsum(dy) if given."""
     N = dy.shape[-1]
     M = dy.numel() // N
     if conv is None:
@@ -93,8 +93,8 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None) -> 
         assert B * H * W == M and x.numel() == M * Ci
         ldx = Ci
     assert dw.dtype == torch.float32 and dw.numel() == N * K, (dw.shape, N, K)
-    _lib.call("spg_gemm_tn", dcode(x), _p(_c(dy)), _p(_c(x)), _p(_c(dw)), M, N, K, N, ldx, K, 1 if conv else 0, B, H, W, Ci,
-              _stream())
+    _lib.call("spg_gemm_tn", dcode(x), _p(_c(dy)), _p(_c(x)), _p(_c(dw)), _p(dbias), M, N, K, N, ldx, K, 1 if conv else 0, B, H, W,
+              Ci, _stream())
 
 
 def pack_matrix(src: Tensor, dtype: torch.dtype, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:
@@ -103,6 +103,10 @@ def pack_matrix(src: Tensor, dtype: torch.dtype, transpose: bool = False, out: O
         out = torch.empty((C, R) if transpose else (R, C), dtype=dtype, device=src.device)
     _lib.call("spg_pack_matrix", dcode(out), _p(f32(src)), _p(out), R, C, 1 if transpose else 0, _stream())
     return out
+
+
+def pack_batch(jobs: Tensor, njobs: int, total_tiles: int, dtype: torch.dtype) -> None:
+    _lib.call("spg_pack_batch", SPG_BF16 if dtype == torch.bfloat16 else SPG_F32, _p(jobs), njobs, total_tiles, _stream())
 
 
 def pack_conv3x3(src: Tensor, dtype: torch.dtype, fwd: Optional[Tensor] = None, dgrad: Optional[Tensor] = None):

@@ -89,7 +89,9 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dt, B, H, W, Ci, Co):
     dx = ops.gemm_nt(dyn, wd, conv=(B, H, W, Co)).view(B, H, W, Ci)
     check(dx.float().permute(0, 3, 1, 2), x.grad, tol(dt), "conv dgrad")
     dwp = torch.zeros(Co, 9 * Ci, device="cuda")
-    ops.gemm_tn(dyn, xn, dwp, conv=(B, H, W, Ci))
+    dbc = torch.zeros(Co, device="cuda")
+    ops.gemm_tn(dyn, xn, dwp, conv=(B, H, W, Ci), dbias=dbc)
+    check(dbc, dyn.float().sum((0, 1, 2)), tol(dt, 2e-5, 1e-4), "conv fused bias grad")
     dwt = torch.zeros(Co, Ci, 3, 3, device="cuda")
     ops.unpack_conv3x3_grad(dwp, dwt)
     check(dwt, w.grad, tol(dt), "conv wgrad")
@@ -102,8 +104,10 @@ def test_gemm_tn(ops, dt, M, N, K):
     dw = torch.zeros(N, K, device="cuda")
     ops.gemm_tn(dy, x, dw)
     check(dw, dy.float().t() @ x.float(), tol(dt, 2e-5, 1e-2), "tn")
-    ops.gemm_tn(dy, x, dw)  # accumulates
+    db = torch.zeros(N, device="cuda")
+    ops.gemm_tn(dy, x, dw, dbias=db)  # accumulates; fused bias gradient
     check(dw, 2 * (dy.float().t() @ x.float()), tol(dt, 2e-5, 1e-2), "tn accumulate")
+    check(db, dy.float().sum(0), tol(dt, 2e-5, 1e-4), "tn fused colsum")
 
 
 def test_pack_matrix(ops):
