@@ -80,25 +80,29 @@ __device__ __forceinline__ unsigned x_chunk_off(int m, int k0, int ldx, const Co
   }
 }
 
-template <typename T>
+// wave tile = 64 (n) x 16*MI (m); the wave's first m row inside the block tile is mrow0
+template <typename T, int MI = 4>
 __device__ __forceinline__ void mma_tile(const char* __restrict__ Ws, const char* __restrict__ Xs, int wn, int wm,
-                                         int lane, f32x4 (&acc)[4][4]) {
+                                         int lane, f32x4 (&acc)[4][MI]) {
   using M_ = Mma<T>;
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int s = 0; s < M_::SUB; ++s) {
-    typename M_::Frag a[4], b[4];
+    typename M_::Frag a[4], b[MI];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rowa = wn * 64 + i * 16 + r;
       a[i] = M_::load(Ws + rowa * ROWB, rowa & 7, s, q);
-      const int rowb = wm * 64 + i * 16 + r;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int rowb = wm * (16 * MI) + i * 16 + r;
       b[i] = M_::load(Xs + rowb * ROWB, rowb & 7, s, q);
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = M_::mma(a[ni], b[mi], acc[ni][mi]);
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = M_::mma(a[ni], b[mi], acc[ni][mi]);
   }
 }
 
@@ -287,13 +291,17 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // DBG: 0 = product kernel; 1 = skip the DMA issue (times MFMA + LDS reads alone); 2 = skip the MFMAs (times the fill
 // pipeline alone).  1 and 2 produce wrong results by construction and are reachable only through SPG_GEMM_DEBUG.
-template <typename T, bool CONV, int DBG = 0>
-__global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __restrict__ X, const T* __restrict__ W,
+template <typename T, bool CONV, int DBG = 0, int WM = 2>
+__global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                                  T* __restrict__ C, NtEpi epi, int M, int N, int K, int ldx,
                                                                  int ldc, ConvGeom g, int tiles_n, int ntiles,
                                                                  unsigned xbytes, unsigned wbytes) {
   constexpr int VEC = ST<T>::VEC;
   constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int MI = 8 / WM;            // 16-row m blocks per wave (wave tile 64 n x 16*MI m)
+  constexpr int NW = 2 * WM;            // waves per workgroup
+  constexpr int NP = 16 / NW;           // DMA pieces (1 KiB) per operand per wave per stage
+  constexpr int STAGES = WM == 2 ? DMA_STAGES : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -310,9 +318,9 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __rest
   const int lrow = lane >> 3;             // row within an 8-row DMA piece
   const int lp = lane & 7;                // physical 16-byte chunk
   int is_j = -1, is_m0 = 0, is_n0 = 0;
-  int py[4], px[4];
+  int py[NP], px[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { py[i] = 0; px[i] = 0; }
+  for (int i = 0; i < NP; ++i) { py[i] = 0; px[i] = 0; }
   auto issue = [&](int gs) {
     const int j = gs / nkt, kt = gs - j * nkt;
     if (j != is_j) {
@@ -322,18 +330,18 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __rest
       is_m0 = tm * BM; is_n0 = tn * BN;
       if constexpr (CONV) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = is_m0 + 32 * i + wave * 8 + lrow;
+        for (int i = 0; i < NP; ++i) {
+          const int m = is_m0 + (8 * NW) * i + wave * 8 + lrow;
           const int hw = g.H * g.W;
           const int b = m / hw, rem = m - b * hw;
           py[i] = rem / g.W; px[i] = rem - py[i] * g.W;
         }
       }
     }
-    char* st = smem + (gs % DMA_STAGES) * DMA_STAGE_BYTES;
+    char* st = smem + (gs % STAGES) * DMA_STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int prow = 32 * i + wave * 8;           // first row of this wave-instruction's 1 KiB piece
+    for (int i = 0; i < NP; ++i) {
+      const int prow = (8 * NW) * i + wave * 8;     // first row of this wave-instruction's 1 KiB piece
       const int row = prow + lrow;
       const int k0 = kt * BK + ((lp ^ (row & 7)) * VEC);
       const bool kin = k0 < K;
@@ -348,17 +356,17 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __rest
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][MI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int gi = 0;
-  for (; gi < DMA_STAGES - 1 && gi < total; ++gi) issue(gi);
+  for (; gi < STAGES - 1 && gi < total; ++gi) issue(gi);
 
   constexpr int EPS = 68;
-  float* slab = reinterpret_cast<float*>(smem + DMA_STAGES * DMA_STAGE_BYTES) + wave * (16 * EPS);
+  float* slab = reinterpret_cast<float*>(smem + STAGES * DMA_STAGE_BYTES) + wave * (16 * EPS);
   const int r15 = lane & 15, q = lane >> 4;
   const T* R = reinterpret_cast<const T*>(epi.residual);
   const T* Hh = reinterpret_cast<const T*>(epi.gelu_h);
@@ -369,23 +377,29 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __rest
   for (int gc = 0; gc < total; ++gc) {
     // step gc's 8 DMA pieces (per wave) must have landed; newer groups may stay in flight
     {
-      const int ahead = gi - gc - 1;   // DMA groups younger than step gc's (8 pieces each)
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ahead = gi - gc - 1;   // DMA groups younger than step gc's (2*NP pieces each per wave)
+      if constexpr (NP == 4) {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (gi < total) { issue(gi); ++gi; }
-    const char* st = smem + (gc % DMA_STAGES) * DMA_STAGE_BYTES;
-    if constexpr (DBG != 2) mma_tile<T>(st + BM * ROWB, st, wn, wm, lane, acc);
+    const char* st = smem + (gc % STAGES) * DMA_STAGE_BYTES;
+    if constexpr (DBG != 2) mma_tile<T, MI>(st + BM * ROWB, st, wn, wm, lane, acc);
     if (++kt == nkt) {
       // ---- epilogue of tile j (per-wave slab, no block barrier: waves run ahead into the next tile independently)
       const int tile = first + j * G;
       const int tn = tile % tiles_n, tm = tile / tiles_n;
       const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
-      for (int quarter = 0; quarter < 4; ++quarter) {
+      for (int quarter = 0; quarter < MI; ++quarter) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           *reinterpret_cast<f32x4*>(slab + r15 * EPS + ni * 16 + q * 4) = acc[ni][quarter];
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_dma_kernel(const T* __rest
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           const int row = (lane >> 3) + 8 * jj, ch = lane & 7;
-          const int m = m0 + wm * 64 + quarter * 16 + row;
+          const int m = m0 + wm * (16 * MI) + quarter * 16 + row;
           const int n = n0 + wn * 64 + ch * 8;
           if (m < M && n < N) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8);
@@ -774,6 +788,24 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
                          (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
       return check_launch("gemm_nt(dbg2)");
     }
+    static int waves = -1;
+    if (waves < 0) { const char* e = getenv("SPG_GEMM_WAVES"); waves = e ? atoi(e) : 8; }
+    if (waves == 8) {
+      constexpr int LDS8 = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
+      static bool attr8 = false;
+      if (!attr8) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, true, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+        attr8 = true;
+      }
+      if (conv)
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, true, 0, 4>), dim3(grid), dim3(512), LDS8, s, (const T*)X, (const T*)W,
+                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      else
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 0, 4>), dim3(grid), dim3(512), LDS8, s, (const T*)X, (const T*)W,
+                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      return check_launch("gemm_nt(dma8)");
+    }
     if (conv)
       hipLaunchKernelGGL((gemm_nt_dma_kernel<T, true>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
                          (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
@@ -798,7 +830,9 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
   constexpr int MSTEP = ROWB / (int)sizeof(T);
   const int tiles_n = cdiv(N, 128), tiles_k = cdiv(K, 128);
   const int tiles = tiles_n * tiles_k;
-  int splits = cdiv(768, tiles);  // aim for >= 3 blocks per CU
+  static int target = 0;
+  if (target == 0) { const char* e = getenv("SPG_TN_TARGET"); target = e ? atoi(e) : 384; }
+  int splits = cdiv(target, tiles);  // blocks ~ target; every split adds a 64 KB f32 atomic epilogue per tile
   const int max_splits = cdiv(M, 4 * MSTEP);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
