@@ -479,25 +479,28 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tn_sw(int f) { return (f ^ (f >> 4)) & 7; }
 
-template <typename T>
+template <typename T, int KI = 4>
 __device__ __forceinline__ void mma_tile_tn(const char* __restrict__ As, const char* __restrict__ Bs, int wn, int wk,
-                                            int lane, f32x4 (&acc)[4][4]) {
+                                            int lane, f32x4 (&acc)[4][KI]) {
   using M_ = Mma<T>;
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int s = 0; s < M_::SUB; ++s) {
-    typename M_::Frag a[4], b[4];
+    typename M_::Frag a[4], b[KI];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rowa = wn * 64 + i * 16 + r;
       a[i] = M_::load(As + rowa * ROWB, tn_sw(rowa), s, q);
-      const int rowb = wk * 64 + i * 16 + r;
+    }
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int rowb = wk * (16 * KI) + i * 16 + r;
       b[i] = M_::load(Bs + rowb * ROWB, tn_sw(rowb), s, q);
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int ki = 0; ki < 4; ++ki) acc[ni][ki] = M_::mma(a[ni], b[ki], acc[ni][ki]);
+      for (int ki = 0; ki < KI; ++ki) acc[ni][ki] = M_::mma(a[ni], b[ki], acc[ni][ki]);
   }
 }
 
@@ -528,8 +531,10 @@ __device__ __forceinline__ void store_patch(char* img, const u32x4 (&rows)[4], i
   }
 }
 
-template <typename T, bool CONV>
-__global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict__ dY, const T* __restrict__ X,
+// WK = waves along k (2: 4 waves, each thread stages a dY patch AND an X patch; 4: 8 waves, threads 0-255 stage dY,
+// 256-511 stage X, wave tile 64 n x 32 k)
+template <typename T, bool CONV, int WK = 2>
+__global__ __launch_bounds__(128 * WK) void gemm_tn_kernel(const T* __restrict__ dY, const T* __restrict__ X,
                                                              float* __restrict__ dW, int M, int N, int K, int ldy,
                                                              int ldx, int ldw, ConvGeom g, int tiles_k, int m_per_split,
                                                              unsigned ybytes, unsigned xbytes, float* __restrict__ dbias) {
@@ -539,24 +544,28 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                   // [2][128 n][ROWB]   (dY^T)
   char* Bs = smem + 2 * 128 * ROWB;  // [2][128 k][ROWB]   (X^T)
+  constexpr int KI = 8 / WK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wk = wave >> 1;
+  const int stid = tid & 255;                  // staging thread id within its operand team
+  const bool team_y = WK == 2 || tid < 256;    // stages dY patches
+  const bool team_x = WK == 2 || tid >= 256;   // stages X patches
   const int tk = blockIdx.x % tiles_k, tn = blockIdx.x / tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
   const int m_begin = blockIdx.y * m_per_split;
   const int m_end = min(M, m_begin + m_per_split);
 
-  const int fc = tid % NCH, mg = tid / NCH;  // feature chunk, m-group (4 rows each)
+  const int fc = stid % NCH, mg = stid / NCH;  // feature chunk, m-group (4 rows each)
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][KI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < KI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 ra[4], rb[4];
   // fused bias gradient: the k-tile-0 blocks also accumulate column sums of their dY patches (db[n] = sum_m dY[m][n])
-  const bool do_bias = (dbias != nullptr) && (tk == 0);
+  const bool do_bias = (dbias != nullptr) && (tk == 0) && team_y;
   float bsum[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) bsum[e] = 0.f;
@@ -578,7 +587,8 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
       const int m = mb + i;
       const bool mv = m < m_end;
       const unsigned yo = (unsigned)(((long)m * ldy + n) * (long)sizeof(T));
-      ra[i] = bload16(yr, (mv && nin) ? yo : OOB);
+      if (team_y) ra[i] = bload16(yr, (mv && nin) ? yo : OOB);
+      if (!team_x) continue;
       if constexpr (!CONV) {
         const unsigned xo = (unsigned)(((long)m * ldx + k) * (long)sizeof(T));
         rb[i] = bload16(xr, (mv && kin) ? xo : OOB);
@@ -602,8 +612,8 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
         for (int e = 0; e < VEC; ++e) bsum[e] += f[e];
       }
     }
-    store_patch<T>(As + buf * 128 * ROWB, ra, fc * VEC, mg);
-    store_patch<T>(Bs + buf * 128 * ROWB, rb, fc * VEC, mg);
+    if (team_y) store_patch<T>(As + buf * 128 * ROWB, ra, fc * VEC, mg);
+    if (team_x) store_patch<T>(Bs + buf * 128 * ROWB, rb, fc * VEC, mg);
   };
 
   const int nm = (m_end - m_begin + MSTEP - 1) / MSTEP;
@@ -614,15 +624,17 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
   for (int mt = 0; mt < nm; ++mt) {
     const int cur = mt & 1;
     if (mt + 1 < nm) gload(mt + 1);
-    mma_tile_tn<T>(As + cur * 128 * ROWB, Bs + cur * 128 * ROWB, wn, wk, lane, acc);
+    mma_tile_tn<T, KI>(As + cur * 128 * ROWB, Bs + cur * 128 * ROWB, wn, wk, lane, acc);
     if (mt + 1 < nm) sstore(cur ^ 1);
     __syncthreads();
   }
-  if (do_bias) {  // reduce the per-thread partial sums over the m-groups through LDS (the MFMA loop is finished)
+  if ((dbias != nullptr) && (tk == 0)) {  // reduce the per-thread partial sums over the m-groups through LDS (MFMA loop done)
     float* red = reinterpret_cast<float*>(smem);
-    constexpr int NMG = NT_THREADS / NCH;
+    constexpr int NMG = 256 / NCH;
+    if (team_y) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) red[mg * 128 + fc * VEC + e] = bsum[e];
+      for (int e = 0; e < VEC; ++e) red[mg * 128 + fc * VEC + e] = bsum[e];
+    }
     __syncthreads();
     if (tid < 128) {
       float t = 0.f;
@@ -635,8 +647,8 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_kernel(const T* __restrict
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-    for (int ki = 0; ki < 4; ++ki) {
-      const int k = k0 + wk * 64 + ki * 16 + r15;
+    for (int ki = 0; ki < KI; ++ki) {
+      const int k = k0 + wk * (16 * KI) + ki * 16 + r15;
       if (k >= K) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -843,6 +855,17 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
   if (xb >= 0xFFFFFFF0L || yb >= 0xFFFFFFF0L) {
     set_error("gemm_tn: operand larger than 4 GiB is not addressable by one buffer descriptor");
     return SPG_ERR_UNSUPPORTED;
+  }
+  static int waves = -1;
+  if (waves < 0) { const char* e = getenv("SPG_TN_WAVES"); waves = e ? atoi(e) : 4; }
+  if (waves == 8) {
+    if (conv)
+      hipLaunchKernelGGL((gemm_tn_kernel<T, true, 4>), dim3(tiles, splits), dim3(512), lds, s, (const T*)dY,
+                         (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
+    else
+      hipLaunchKernelGGL((gemm_tn_kernel<T, false, 4>), dim3(tiles, splits), dim3(512), lds, s, (const T*)dY,
+                         (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
+    return check_launch("gemm_tn(8w)");
   }
   if (conv)
     hipLaunchKernelGGL((gemm_tn_kernel<T, true>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,

@@ -197,7 +197,11 @@ static int launch_colreduce(const void* a, const void* b, const float* p0, const
   }
   const long rows = img_rows > 0 ? img_rows : M;
   const int rpar = 256 / (C / VEC);
-  long want = 384 / (nimg > 0 ? nimg : 1);  // few blocks per output address: the final atomics contend per column
+  // few blocks per output address (the final atomics contend per column), more when there are many rows to stream
+  long want = rows / ((long)rpar * 16);
+  if (want < 384) want = 384;
+  if (want > 2048) want = 2048;
+  want /= (nimg > 0 ? nimg : 1);
   if (want < 1) want = 1;
   long rpb = cdiv(rows, want);
   const long min_rpb = (long)rpar * 8;
@@ -236,58 +240,82 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
   if (mean_invstd) { mean_invstd[c] = mu; mean_invstd[C + c] = is; }
 }
 
-// y = act(x*scale+shift) [* chan_mul[b][c]]
+// y = act(x*scale+shift).  A thread owns one 16-byte channel chunk (its per-channel coefficients live in registers)
+// and strides over rows: 1 load + 1 store per 16 bytes, 2 VALU ops per element.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ ss,
-                                                       T* __restrict__ y, long M, int C, int relu) {
+                                                       T* __restrict__ y, long M, int C, int relu, long rows_per_block) {
   constexpr int VEC = ST<T>::VEC;
   const int nch = C / VEC;
-  const long total = M * nch;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int ch = (int)(i % nch);
+  const int rpar = 256 / nch;
+  const int ch = threadIdx.x % nch, rl = threadIdx.x / nch;
+  if (rl >= rpar) return;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { sc[e] = ss[ch * VEC + e]; sh[e] = ss[C + ch * VEC + e]; }
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (long r = r0 + rl; r < r1; r += rpar) {
     float v[VEC];
-    unpack16<T>(ld16(x + i * VEC), v);
+    unpack16<T>(ld16(x + r * C + ch * VEC), v);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const int c = ch * VEC + e;
-      float o = v[e] * ss[c] + ss[C + c];
+      const float o = v[e] * sc[e] + sh[e];
       v[e] = relu ? fmaxf(o, 0.f) : o;
     }
-    st16(y + i * VEC, pack16<T>(v));
+    st16(y + r * C + ch * VEC, pack16<T>(v));
   }
 }
 
-// dx = gamma*invstd*(dy' - s1/M - xhat*s2/M);  block 0 also does dgamma += s2, dbeta += s1
+// dx = gamma*invstd*(dy' - s1/M - xhat*s2/M) = A*dy' + B*x + D per channel;  block 0 also does dgamma += s2, dbeta += s1
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ ss, const float* __restrict__ mi,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            T* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, long M, int C, int relu) {
+                                                           float* __restrict__ dbeta, long M, int C, int relu,
+                                                           long rows_per_block) {
   constexpr int VEC = ST<T>::VEC;
   const int nch = C / VEC;
-  const long total = M * nch;
-  const float invM = 1.f / (float)M;
+  const int rpar = 256 / nch;
+  const int ch = threadIdx.x % nch, rl = threadIdx.x / nch;
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
       if (dbeta) atomicAdd(dbeta + c, sums[c]);
       if (dgamma) atomicAdd(dgamma + c, sums[C + c]);
     }
   }
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int ch = (int)(i % nch);
+  if (rl >= rpar) return;
+  const float invM = 1.f / (float)M;
+  float sc[VEC], sh[VEC], A[VEC], Bc[VEC], D[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int c = ch * VEC + e;
+    sc[e] = ss[c]; sh[e] = ss[C + c];
+    const float mu = mi[c], is = mi[C + c], g = gamma[c];
+    const float s1 = sums[c] * invM, s2 = sums[C + c] * invM;
+    A[e] = g * is;
+    Bc[e] = -g * is * is * s2;
+    D[e] = -g * is * s1 + g * is * is * mu * s2;
+  }
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (long r = r0 + rl; r < r1; r += rpar) {
     float dv[VEC], xv[VEC];
-    unpack16<T>(ld16(dy + i * VEC), dv);
-    unpack16<T>(ld16(x + i * VEC), xv);
+    unpack16<T>(ld16(dy + r * C + ch * VEC), dv);
+    unpack16<T>(ld16(x + r * C + ch * VEC), xv);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const int c = ch * VEC + e;
-      const float d = (relu && (xv[e] * ss[c] + ss[C + c] <= 0.f)) ? 0.f : dv[e];
-      const float xh = (xv[e] - mi[c]) * mi[C + c];
-      dv[e] = gamma[c] * mi[C + c] * (d - sums[c] * invM - xh * sums[C + c] * invM);
+      const float d = (relu && (xv[e] * sc[e] + sh[e] <= 0.f)) ? 0.f : dv[e];
+      dv[e] = A[e] * d + Bc[e] * xv[e] + D[e];
     }
-    st16(dx + i * VEC, pack16<T>(dv));
+    st16(dx + r * C + ch * VEC, pack16<T>(dv));
   }
+}
+
+static inline long bn_rows_per_block(long M, int nch) {
+  const long rpar = 256 / nch;
+  long rpb = (M + 4095) / 4096;          // up to ~4096 blocks
+  if (rpb < rpar * 4) rpb = rpar * 4;    // at least 4 rows per thread
+  return (rpb + rpar - 1) / rpar * rpar;
 }
 
 static inline int ew_grid(long n_items) {
@@ -373,12 +401,14 @@ extern "C" int spg_bn_apply(int dtype, const void* x, const float* scale_shift, 
                             spg_stream_t stream) {
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(C % vec == 0, "bn_apply: C=%d must be a multiple of %d", C, vec);
+  SPG_REQUIRE(C / vec <= 256, "bn_apply: C=%d too wide", C);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = ew_grid(M * (C / vec));
+  const long rpb = bn_rows_per_block(M, C / vec);
+  const int grid = cdiv(M, rpb);
   if (dtype == SPG_BF16)
-    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, scale_shift, (bf16_t*)y, M, C, relu);
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, scale_shift, (bf16_t*)y, M, C, relu, rpb);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, scale_shift, (float*)y, M, C, relu);
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, scale_shift, (float*)y, M, C, relu, rpb);
   return check_launch("bn_apply");
 }
 
@@ -394,12 +424,14 @@ extern "C" int spg_bn_bwd_apply(int dtype, const void* dy, const void* x, const 
                                 float* dbeta, long M, int C, int relu, spg_stream_t stream) {
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(C % vec == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, vec);
+  SPG_REQUIRE(C / vec <= 256, "bn_bwd_apply: C=%d too wide", C);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = ew_grid(M * (C / vec));
+  const long rpb = bn_rows_per_block(M, C / vec);
+  const int grid = cdiv(M, rpb);
   if (dtype == SPG_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, scale_shift, mean_invstd, gamma, sums, (bf16_t*)dx, dgamma, dbeta, M, C, relu);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, scale_shift, mean_invstd, gamma, sums, (bf16_t*)dx, dgamma, dbeta, M, C, relu, rpb);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, scale_shift, mean_invstd, gamma, sums, (float*)dx, dgamma, dbeta, M, C, relu);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, scale_shift, mean_invstd, gamma, sums, (float*)dx, dgamma, dbeta, M, C, relu, rpb);
   return check_launch("bn_bwd_apply");
 }
 
