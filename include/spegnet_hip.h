@@ -151,6 +151,23 @@ int spg_head1x1(int dtype, const void* x, const float* w, const float* b, void* 
 int spg_head1x1_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, long M,
                     int C, int accumulate, spg_stream_t stream);
 
+/* ---- CODLoss, fixed-size ground truth (utils/loss_functions.py:114-295 + resize loop engine/trainer.py:358-383) ----------
+ * weight_map: w = 1 + bw*(|Laplace3x3 m| + |avgpool31 m - m|); stats[b] = {sum m, sum w, sum edge_gt, 0} (caller zeroes).
+ * loss_reduce: per image sums at the TARGET resolution of the bilinearly resized logits: edge=0 -> {sum w*bce, sum s*m*w,
+ *   sum (s+m)*w}; edge=1 -> {sum focal, sum s*t, sum s} (caller zeroes sums f32 [B][3]).
+ * loss_finalize: out = {loss, seg_loss, edge_loss} from stats + seg_sums[3][B][3] + edge_sums[B][3].
+ * loss_grad: d loss / d prediction at the prediction's own resolution (bilinear adjoint in gather form), times
+ *   coef * grad_out[0] (grad_out may be NULL = 1).                                                                    */
+int spg_loss_weight_map(const float* mask, const float* edge_gt, float* wmap, float* stats, int B, int S,
+                        float boundary_weight, spg_stream_t stream);
+int spg_loss_reduce(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
+                    float* sums, int B, int S, int h, int w, int edge, float alpha, float gamma, spg_stream_t stream);
+int spg_loss_finalize(const float* stats, const float* seg_sums, const float* edge_sums, float* out, int B, int S,
+                      float sw0, float sw1, float sw2, float bce_w, float iou_w, float edge_w, spg_stream_t stream);
+int spg_loss_grad(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
+                  const float* sums, const float* grad_out, void* dpred, int B, int S, int h, int w, int edge, float coef,
+                  float bce_w, float iou_w, float alpha, float gamma, spg_stream_t stream);
+
 /* ---- optimizer (engine/trainer.py:274-306 param groups, :399-409 clip + AdamW step) over a flat f32 arena ---------
  * sumsq: out[0] += sum x^2.  adamw: step_f[0] += 1, then clip coefficient min(1, clip/(sqrt(gnorm_sq)*grad_scale+1e-6))
  * and a decoupled-weight-decay Adam update; group_of_chunk[i/256] selects lr[g], wd[g] (device arrays, so the

@@ -54,14 +54,14 @@ SIGNATURES = {
     "spg_easpp_fuse_bwd": "ipppppppppppp" "p" "ilip",
     "spg_head1x1": "ipppp" "lip",
     "spg_head1x1_bwd": "ipppppp" "liip",
+    "spg_loss_weight_map": "pppp" "iifp",
+    "spg_loss_reduce": "ippppp" "iiiiiffp",
+    "spg_loss_finalize": "pppp" "iiffffffp",
+    "spg_loss_grad": "ippppppp" "iiiiifffffp",
     "spg_sumsq": "pp" "lp",
     "spg_adamw": "ppppppppp" "fffff" "lp",
 }
-_OPTIONAL = {
-    "spg_loss_weight_map": "ppp" "iifp",
-    "spg_loss_scale": "ipppppp" "iiiiffffip",
-    "spg_loss_finalize": "pp" "ifffffffp",
-}
+_OPTIONAL = {}
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F}
 
 _lib = None

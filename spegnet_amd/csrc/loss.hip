@@ -1,0 +1,280 @@
+// Fused CODLoss for fixed-size ground truth (reference utils/loss_functions.py:114-295 + the resize loop of
+// engine/trainer.py:358-383), forward sums and analytic gradients, no autograd graph and no per-sample launches.
+//
+//   wmap      : w = 1 + bw*(|Laplace3x3(m)| + |avgpool31(m) - m|) per pixel, per-image sum(m), sum(w), sum(edge_gt)
+//   seg_reduce: per scale and image  A = sum w*bce(z,m;pw), I = sum s*m*w, U = sum (s+m)*w,  z = bilinear(pred -> SxS)
+//   edge_reduce: per image            F = sum focal(z,t;pw), I = sum s*t, P = sum s
+//   finalize  : loss = sum_i w_i * mean_b(bce_w*A/W + iou_w*(1-(I+1)/(U-I+1))) + edge_w * mean_b(F/HW + 1-(2I+1)/(P+T+1))
+//   seg_grad / edge_grad: d loss / d pred at the PREDICTION's resolution = bilinear-adjoint gather of the per-pixel
+//   gradient (each low-res logit sums over the full-res pixels whose interpolation touches it), scaled by the upstream
+//   gradient read from device memory (no host sync).
+// All HBM-trivial (a few MB); the point is launch count and staying inside the hipGraph.
+#include "common.h"
+
+namespace spg {
+
+__device__ __forceinline__ void bil_src_l(int dst, int in, int out, int& i0, int& i1, float& lam) {
+  float src = ((float)dst + 0.5f) * ((float)in / (float)out) - 0.5f;
+  src = fmaxf(src, 0.f);
+  i0 = min((int)src, in - 1);
+  i1 = min(i0 + 1, in - 1);
+  lam = src - (float)i0;
+}
+template <typename T>
+__device__ __forceinline__ float bil_at(const T* __restrict__ p, int h, int w, int S, int Y, int X) {
+  if (h == S && w == S) return ST<T>::ld(p + (long)Y * w + X);
+  int y0, y1, x0, x1; float ly, lx;
+  bil_src_l(Y, h, S, y0, y1, ly);
+  bil_src_l(X, w, S, x0, x1, lx);
+  const float a = ST<T>::ld(p + (long)y0 * w + x0), b = ST<T>::ld(p + (long)y0 * w + x1);
+  const float c = ST<T>::ld(p + (long)y1 * w + x0), d = ST<T>::ld(p + (long)y1 * w + x1);
+  return (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
+}
+__device__ __forceinline__ float pos_weight(float npos, float total) {
+  return fminf(fmaxf((total - npos) / (npos + 1e-7f), 0.1f), 10.f);
+}
+
+// stats[b] = {sum m, sum w, sum edge_gt, 0}
+__global__ __launch_bounds__(256) void loss_wmap_kernel(const float* __restrict__ mask, const float* __restrict__ egt,
+                                                        float* __restrict__ wmap, float* __restrict__ stats, int S, float bw) {
+  __shared__ float tile[62][65];
+  __shared__ float hs[62][33];
+  __shared__ float red[4];
+  const int b = blockIdx.z, ty0 = blockIdx.y * 32, tx0 = blockIdx.x * 32;
+  const float* m = mask + (long)b * S * S;
+  for (int i = threadIdx.x; i < 62 * 62; i += 256) {
+    const int r = i / 62, c = i - r * 62;
+    const int y = ty0 + r - 15, x = tx0 + c - 15;
+    tile[r][c] = ((unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S) ? m[(long)y * S + x] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 62 * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 31; ++d) s += tile[r][c + d];
+    hs[r][c] = s;
+  }
+  __syncthreads();
+  float sm = 0.f, sw = 0.f, se = 0.f;
+  for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    const int y = ty0 + r, x = tx0 + c;
+    if (y < S && x < S) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 31; ++d) s += hs[r + d][c];
+      const float mv = tile[r + 15][c + 15];
+      float nb = 0.f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) nb += tile[r + 15 + dy][c + 15 + dx];
+      const float lap = fabsf(9.f * mv - nb);                       // 8*m - sum(8 neighbours)
+      const float w = 1.f + bw * (lap + fabsf(s * (1.f / 961.f) - mv));
+      wmap[((long)b * S + y) * S + x] = w;
+      sm += mv; sw += w;
+      se += egt[((long)b * S + y) * S + x];
+    }
+  }
+  sm = block_sum<256>(sm, red);
+  sw = block_sum<256>(sw, red);
+  se = block_sum<256>(se, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(stats + b * 4 + 0, sm);
+    atomicAdd(stats + b * 4 + 1, sw);
+    atomicAdd(stats + b * 4 + 2, se);
+  }
+}
+
+// sums[b] = {A, I, U}
+template <typename T>
+__global__ __launch_bounds__(256) void loss_seg_reduce_kernel(const T* __restrict__ pred, const float* __restrict__ mask,
+                                                              const float* __restrict__ wmap, const float* __restrict__ stats,
+                                                              float* __restrict__ sums, int S, int h, int w) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const long HW = (long)S * S;
+  const float pw = pos_weight(stats[b * 4 + 0], (float)HW);
+  const T* p = pred + (long)b * h * w;
+  float A = 0.f, I = 0.f, U = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    const int Y = (int)(i / S), X = (int)(i - (long)Y * S);
+    const float z = bil_at<T>(p, h, w, S, Y, X);
+    const float m = mask[b * HW + i], wv = wmap[b * HW + i];
+    const float lw = 1.f + (pw - 1.f) * m;
+    const float bce = (1.f - m) * z + lw * (log1pf(__expf(-fabsf(z))) + fmaxf(-z, 0.f));
+    const float s = sigmoid_f(z);
+    A += wv * bce; I += s * m * wv; U += (s + m) * wv;
+  }
+  A = block_sum<256>(A, red); I = block_sum<256>(I, red); U = block_sum<256>(U, red);
+  if (threadIdx.x == 0) { atomicAdd(sums + b * 3 + 0, A); atomicAdd(sums + b * 3 + 1, I); atomicAdd(sums + b * 3 + 2, U); }
+}
+
+// sums[b] = {F, I, P}
+template <typename T>
+__global__ __launch_bounds__(256) void loss_edge_reduce_kernel(const T* __restrict__ pred, const float* __restrict__ egt,
+                                                               const float* __restrict__ stats, float* __restrict__ sums, int S,
+                                                               int h, int w, float alpha, float gamma) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const long HW = (long)S * S;
+  const float pw = pos_weight(stats[b * 4 + 2], (float)HW);
+  const T* p = pred + (long)b * h * w;
+  float Fs = 0.f, I = 0.f, P = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    const int Y = (int)(i / S), X = (int)(i - (long)Y * S);
+    const float z = bil_at<T>(p, h, w, S, Y, X);
+    const float t = egt[b * HW + i];
+    const float s = sigmoid_f(z);
+    const float pt = t * s + (1.f - t) * (1.f - s);
+    Fs += -pw * alpha * __powf(1.f - pt, gamma) * __logf(fmaxf(pt, 1e-7f));
+    I += s * t; P += s;
+  }
+  Fs = block_sum<256>(Fs, red); I = block_sum<256>(I, red); P = block_sum<256>(P, red);
+  if (threadIdx.x == 0) { atomicAdd(sums + b * 3 + 0, Fs); atomicAdd(sums + b * 3 + 1, I); atomicAdd(sums + b * 3 + 2, P); }
+}
+
+struct LossCfg {
+  float sw[3];
+  float bce_w, iou_w, edge_w, alpha, gamma;
+};
+
+// out = {loss, seg_loss, edge_loss}
+__global__ void loss_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ seg_sums /*[3][B][3]*/,
+                                     const float* __restrict__ edge_sums, float* __restrict__ out, int B, long HW, LossCfg c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float seg = 0.f, edge = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float W = stats[b * 4 + 1];
+    for (int i = 0; i < 3; ++i) {
+      const float* s = seg_sums + ((long)i * B + b) * 3;
+      seg += c.sw[i] * (c.bce_w * s[0] / W + c.iou_w * (1.f - (s[1] + 1.f) / (s[2] - s[1] + 1.f)));
+    }
+    const float* e = edge_sums + b * 3;
+    edge += e[0] / (float)HW + 1.f - (2.f * e[1] + 1.f) / (e[2] + stats[b * 4 + 2] + 1.f);
+  }
+  seg /= (float)B; edge /= (float)B;
+  out[0] = seg + c.edge_w * edge; out[1] = seg; out[2] = edge;
+}
+
+// gradient w.r.t. the low-res prediction: gather over the full-res pixels whose bilinear taps include (yl, xl)
+template <typename T, bool EDGE>
+__global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ pred, const float* __restrict__ tgt,
+                                                        const float* __restrict__ wmap, const float* __restrict__ stats,
+                                                        const float* __restrict__ sums, const float* __restrict__ go,
+                                                        T* __restrict__ dpred, int B, int S, int h, int w, float coef, float bce_w,
+                                                        float iou_w, float alpha, float gamma) {
+  const long total = (long)B * h * w;
+  const long HW = (long)S * S;
+  const int sy = S / h, sx = S / w;
+  const float g0 = go ? go[0] : 1.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xl = (int)(i % w);
+    const int yl = (int)((i / w) % h);
+    const int b = (int)(i / ((long)w * h));
+    const T* p = pred + (long)b * h * w;
+    float pw, k1 = 0.f, k2 = 0.f, k3 = 0.f, invW = 0.f;
+    if constexpr (EDGE) {
+      pw = pos_weight(stats[b * 4 + 2], (float)HW);
+      const float I = sums[b * 3 + 1], Ud = sums[b * 3 + 2] + stats[b * 4 + 2] + 1.f;   // dice = 1 - (2I+1)/Ud
+      k1 = -2.f / Ud;                 // d dice / d I
+      k2 = (2.f * I + 1.f) / (Ud * Ud);  // d dice / d P
+    } else {
+      pw = pos_weight(stats[b * 4 + 0], (float)HW);
+      invW = 1.f / stats[b * 4 + 1];
+      const float I = sums[b * 3 + 1], D = sums[b * 3 + 2] - I + 1.f;   // wiou = 1 - (I+1)/D, D = U - I + 1
+      k1 = -(D + (I + 1.f)) / (D * D);   // d wiou / d I  (dD/dI = -1)
+      k2 = (I + 1.f) / (D * D);          // d wiou / d U
+    }
+    (void)k3;
+    float acc = 0.f;
+    const int Y0 = max(0, (yl - 1) * sy), Y1 = min(S - 1, (yl + 2) * sy);
+    const int X0 = max(0, (xl - 1) * sx), X1 = min(S - 1, (xl + 2) * sx);
+    for (int Y = Y0; Y <= Y1; ++Y) {
+      float wy;
+      if (h == S) wy = (Y == yl) ? 1.f : 0.f;
+      else { int y0, y1; float ly; bil_src_l(Y, h, S, y0, y1, ly); wy = (y0 == yl ? 1.f - ly : 0.f) + (y1 == yl ? ly : 0.f); }
+      if (wy == 0.f) continue;
+      for (int X = X0; X <= X1; ++X) {
+        float wx;
+        if (w == S) wx = (X == xl) ? 1.f : 0.f;
+        else { int x0, x1; float lx; bil_src_l(X, w, S, x0, x1, lx); wx = (x0 == xl ? 1.f - lx : 0.f) + (x1 == xl ? lx : 0.f); }
+        if (wx == 0.f) continue;
+        const float z = bil_at<T>(p, h, w, S, Y, X);
+        const float t = tgt[b * HW + (long)Y * S + X];
+        const float s = sigmoid_f(z), ds = s * (1.f - s);
+        float g;
+        if constexpr (EDGE) {
+          const float pt = t * s + (1.f - t) * (1.f - s);
+          const float ptc = fmaxf(pt, 1e-7f);
+          const float om = 1.f - pt;
+          // f = -pw*alpha*om^gamma*log(ptc);  df/dpt = -pw*alpha*( -gamma*om^(gamma-1)*log(ptc) + om^gamma/ptc*[pt>1e-7] )
+          const float dfdpt = -pw * alpha * (-gamma * __powf(om, gamma - 1.f) * __logf(ptc) + (pt > 1e-7f ? __powf(om, gamma) / ptc : 0.f));
+          const float dptdz = (2.f * t - 1.f) * ds;
+          g = dfdpt * dptdz / (float)HW + (k1 * t + k2) * ds;
+        } else {
+          const float wv = wmap[b * HW + (long)Y * S + X];
+          const float lw = 1.f + (pw - 1.f) * t;
+          const float dbce = (1.f - t) - lw * (1.f - s);
+          g = bce_w * wv * dbce * invW + iou_w * (k1 * t + k2 * 1.f) * ds * wv;
+        }
+        acc += wy * wx * g;
+      }
+    }
+    ST<T>::st(dpred + i, acc * coef * g0);
+  }
+}
+
+}  // namespace spg
+
+using namespace spg;
+
+extern "C" int spg_loss_weight_map(const float* mask, const float* edge_gt, float* wmap, float* stats, int B, int S,
+                                   float boundary_weight, spg_stream_t stream) {
+  SPG_REQUIRE(B > 0 && S > 0, "loss_weight_map: empty");
+  hipLaunchKernelGGL(loss_wmap_kernel, dim3(cdiv(S, 32), cdiv(S, 32), B), dim3(256), 0, (hipStream_t)stream, mask, edge_gt, wmap, stats, S, boundary_weight);
+  return check_launch("loss_weight_map");
+}
+
+extern "C" int spg_loss_reduce(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
+                               float* sums, int B, int S, int h, int w, int edge, float alpha, float gamma, spg_stream_t stream) {
+  SPG_REQUIRE(S % h == 0 && S % w == 0, "loss_reduce: target size %d must be a multiple of the prediction size %dx%d", S, h, w);
+  long per = ((long)S * S + 255) / 256;
+  int gx = (int)(per < 64 ? per : 64);
+  dim3 grid(gx, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (edge) {
+    if (dtype == SPG_BF16) hipLaunchKernelGGL(loss_edge_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred, target, stats, sums, S, h, w, alpha, gamma);
+    else hipLaunchKernelGGL(loss_edge_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)pred, target, stats, sums, S, h, w, alpha, gamma);
+  } else {
+    if (dtype == SPG_BF16) hipLaunchKernelGGL(loss_seg_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred, target, wmap, stats, sums, S, h, w);
+    else hipLaunchKernelGGL(loss_seg_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)pred, target, wmap, stats, sums, S, h, w);
+  }
+  return check_launch("loss_reduce");
+}
+
+extern "C" int spg_loss_finalize(const float* stats, const float* seg_sums, const float* edge_sums, float* out, int B, int S,
+                                 float sw0, float sw1, float sw2, float bce_w, float iou_w, float edge_w, spg_stream_t stream) {
+  LossCfg c{{sw0, sw1, sw2}, bce_w, iou_w, edge_w, 0.f, 0.f};
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, seg_sums, edge_sums, out, B, (long)S * S, c);
+  return check_launch("loss_finalize");
+}
+
+extern "C" int spg_loss_grad(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
+                             const float* sums, const float* grad_out, void* dpred, int B, int S, int h, int w, int edge, float coef,
+                             float bce_w, float iou_w, float alpha, float gamma, spg_stream_t stream) {
+  SPG_REQUIRE(S % h == 0 && S % w == 0, "loss_grad: target size must be a multiple of the prediction size");
+  const long total = (long)B * h * w;
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (edge) {
+    if (dtype == SPG_BF16) hipLaunchKernelGGL((loss_grad_kernel<bf16_t, true>), dim3((int)g), dim3(256), 0, s, (const bf16_t*)pred, target, wmap, stats, sums, grad_out, (bf16_t*)dpred, B, S, h, w, coef, bce_w, iou_w, alpha, gamma);
+    else hipLaunchKernelGGL((loss_grad_kernel<float, true>), dim3((int)g), dim3(256), 0, s, (const float*)pred, target, wmap, stats, sums, grad_out, (float*)dpred, B, S, h, w, coef, bce_w, iou_w, alpha, gamma);
+  } else {
+    if (dtype == SPG_BF16) hipLaunchKernelGGL((loss_grad_kernel<bf16_t, false>), dim3((int)g), dim3(256), 0, s, (const bf16_t*)pred, target, wmap, stats, sums, grad_out, (bf16_t*)dpred, B, S, h, w, coef, bce_w, iou_w, alpha, gamma);
+    else hipLaunchKernelGGL((loss_grad_kernel<float, false>), dim3((int)g), dim3(256), 0, s, (const float*)pred, target, wmap, stats, sums, grad_out, (float*)dpred, B, S, h, w, coef, bce_w, iou_w, alpha, gamma);
+  }
+  return check_launch("loss_grad");
+}

@@ -3,8 +3,9 @@
 Same constructor and the same `forward(predictions[B][scales], edge_pred[B], masks, edges)` contract as the
 reference, plus `forward_batched`, which evaluates the identical formula for a whole batch at once when every
 mask has the same size (the synthetic / fixed-resolution training case) instead of B x ~70 tiny launches.
-Round-1 status: evaluated with stock torch tensor ops on the device (SURVEY.md §8(f) rank 1 keeps the fused HIP
-loss kernel as the next row); it is not part of the C ABI yet.
+`forward_batched` runs on the fused HIP kernels of csrc/loss.hip (weight map, per-scale reductions, analytic
+gradients).  The per-sample `forward` (ragged ground-truth sizes, the reference's contract) and
+`forward_batched_torch` (cross-check) use stock torch tensor ops.
 """
 from __future__ import annotations
 
@@ -13,6 +14,62 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+class _FusedCODLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p1, p2, p3, edge, masks, edges, cfg):
+        from .. import _lib
+        sw, bw, bce_w, iou_w, edge_w, alpha, gamma = cfg
+        B, S = masks.shape[0], masks.shape[-1]
+        assert masks.shape[-2] == S and edges.shape == masks.shape, "fused CODLoss needs square, equal-size ground truth"
+        if not masks.is_cuda:
+            raise RuntimeError("fused CODLoss runs only on an MI355X (HIP) device")
+        dev = masks.device
+        masks = masks.float().contiguous(); edges = edges.float().contiguous()
+        preds = [p.contiguous() for p in (p1, p2, p3, edge)]
+        dt = _lib.SPG_BF16 if preds[0].dtype == torch.bfloat16 else _lib.SPG_F32
+        assert all(p.dtype == preds[0].dtype for p in preds)
+        st = torch.cuda.current_stream().cuda_stream
+        buf = torch.zeros(B * 4 + 4 * B * 3 + 3, dtype=torch.float32, device=dev)
+        stats, seg_sums, edge_sums, out = buf[:B * 4], buf[B * 4:B * 4 + 9 * B], buf[B * 13:B * 16], buf[B * 16:]
+        wmap = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+        _lib.call("spg_loss_weight_map", masks.data_ptr(), edges.data_ptr(), wmap.data_ptr(), stats.data_ptr(), B, S, float(bw), st)
+        for i in range(3):
+            h, w = preds[i].shape[-2:]
+            _lib.call("spg_loss_reduce", dt, preds[i].data_ptr(), masks.data_ptr(), wmap.data_ptr(), stats.data_ptr(),
+                      seg_sums[i * 3 * B:].data_ptr(), B, S, h, w, 0, 0.0, 0.0, st)
+        h, w = preds[3].shape[-2:]
+        _lib.call("spg_loss_reduce", dt, preds[3].data_ptr(), edges.data_ptr(), None, stats.data_ptr(), edge_sums.data_ptr(), B, S, h, w,
+                  1, float(alpha), float(gamma), st)
+        _lib.call("spg_loss_finalize", stats.data_ptr(), seg_sums.data_ptr(), edge_sums.data_ptr(), out.data_ptr(), B, S, float(sw[0]),
+                  float(sw[1]), float(sw[2]), float(bce_w), float(iou_w), float(edge_w), st)
+        ctx.saved = (preds, masks, edges, wmap, stats, seg_sums, edge_sums, cfg, dt)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_seg, g_edge):
+        from .. import _lib
+        preds, masks, edges, wmap, stats, seg_sums, edge_sums, cfg, dt = ctx.saved
+        sw, bw, bce_w, iou_w, edge_w, alpha, gamma = cfg
+        B, S = masks.shape[0], masks.shape[-1]
+        st = torch.cuda.current_stream().cuda_stream
+        go = g_loss.float().contiguous() if g_loss is not None else None
+        grads = []
+        for i in range(3):
+            h, w = preds[i].shape[-2:]
+            d = torch.empty_like(preds[i])
+            _lib.call("spg_loss_grad", dt, preds[i].data_ptr(), masks.data_ptr(), wmap.data_ptr(), stats.data_ptr(),
+                      seg_sums[i * 3 * B:].data_ptr(), go.data_ptr() if go is not None else None, d.data_ptr(), B, S, h, w, 0,
+                      float(sw[i]) / B, float(bce_w), float(iou_w), 0.0, 0.0, st)
+            grads.append(d)
+        h, w = preds[3].shape[-2:]
+        d = torch.empty_like(preds[3])
+        _lib.call("spg_loss_grad", dt, preds[3].data_ptr(), edges.data_ptr(), None, stats.data_ptr(), edge_sums.data_ptr(),
+                  go.data_ptr() if go is not None else None, d.data_ptr(), B, S, h, w, 1, float(edge_w) / B, 0.0, 0.0, float(alpha),
+                  float(gamma), st)
+        grads.append(d)
+        return grads[0], grads[1], grads[2], grads[3], None, None, None
 
 
 class CODLoss(nn.Module):
@@ -63,7 +120,16 @@ class CODLoss(nn.Module):
 
     def forward_batched(self, predictions: Sequence[torch.Tensor], edge: torch.Tensor, masks: torch.Tensor,
                         edges: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """predictions: 3 x [B,1,h,w] logits; edge [B,1,h,w]; masks, edges [B,1,S,S] (all the same size)."""
+        """Fused HIP CODLoss.  predictions: 3 x [B,1,h,w] logits; edge [B,1,h,w]; masks, edges [B,1,S,S] (one size,
+        square, a multiple of every prediction size).  Gradients reach the predictions through `loss` only."""
+        cfg = (tuple(self.scale_weights), self.boundary_weight, self.bce_weight, self.iou_weight, self.edge_weight,
+               self.edge_focal_alpha, self.edge_focal_gamma)
+        loss, seg, edge_l = _FusedCODLoss.apply(predictions[0], predictions[1], predictions[2], edge, masks, edges, cfg)
+        return {'loss': loss, 'seg_loss': seg, 'edge_loss': edge_l}
+
+    def forward_batched_torch(self, predictions: Sequence[torch.Tensor], edge: torch.Tensor, masks: torch.Tensor,
+                              edges: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Same formula with stock torch ops (test cross-check)."""
         size = masks.shape[-2:]
         masks, edges = masks.float(), edges.float()
         w = self._weights(masks)

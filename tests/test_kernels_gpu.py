@@ -408,3 +408,41 @@ def test_small_utils(ops, dt):
     assert torch.equal(y[:, 32:48], x[:, 16:32]) and float(y[:, :32].abs().max()) == 0
     a, b = rnd(64, 40, seed=2).to(dt), rnd(64, 40, seed=3).to(dt)
     check(ops.add(a, b).float(), a.float() + b.float(), tol(dt, 1e-7, 8e-3), "add")
+
+
+# ------------------------------------------------------------------------------------------- fused CODLoss
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("case", ["rand", "zeros", "ones"])
+def test_fused_codloss_matches_torch_formula(dt, case):
+    """csrc/loss.hip against the torch restatement of the same formula (itself pinned to the reference by
+    tests/test_oracle_golden.py through oracle.cod_loss)."""
+    from spegnet_amd.utils.loss_functions import CODLoss
+    from oracle import spegnet_oracle as O
+    B, S = 3, 64
+    g = torch.Generator().manual_seed(5)
+    preds = [(torch.randn(B, 1, S // d, S // d, generator=g) * 2).cuda().to(dt) for d in (4, 2, 1)]
+    edge = (torch.randn(B, 1, S // 8, S // 8, generator=g) * 2).cuda().to(dt)
+    if case == "rand":
+        masks = (torch.rand(B, 1, S, S, generator=g) > 0.7).float().cuda()
+        edges = (torch.rand(B, 1, S, S, generator=g) > 0.95).float().cuda()
+    elif case == "zeros":
+        masks, edges = torch.zeros(B, 1, S, S).cuda(), torch.zeros(B, 1, S, S).cuda()
+    else:
+        masks, edges = torch.ones(B, 1, S, S).cuda(), torch.ones(B, 1, S, S).cuda()
+    crit = CODLoss(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in O.LOSS_DEFAULT_YAML.items()}).cuda()
+    pr = [p.clone().requires_grad_(True) for p in preds]
+    er = edge.clone().requires_grad_(True)
+    ref = crit.forward_batched_torch(pr, er, masks, edges)
+    ref["loss"].backward()
+    pf = [p.clone().requires_grad_(True) for p in preds]
+    ef = edge.clone().requires_grad_(True)
+    out = crit.forward_batched(pf, ef, masks, edges)
+    for k in ("loss", "seg_loss", "edge_loss"):
+        assert abs(float(out[k]) - float(ref[k])) < 2e-5 * max(1.0, abs(float(ref[k]))), (k, float(out[k]), float(ref[k]))
+    (out["loss"] * 1.5).backward()
+    for a, b in zip(pf + [ef], pr + [er]):
+        check(a.grad.float(), 1.5 * b.grad.float(), tol(dt, 2e-4, 1.5e-2), "loss grad")
+    # and against the CPU oracle (reference-pinned) for the fp32 case
+    if dt == torch.float32:
+        o = O.cod_loss([p.cpu() for p in preds], edge.cpu(), [m for m in masks.cpu()], [e for e in edges.cpu()], **O.LOSS_DEFAULT_YAML)
+        assert abs(float(out["loss"]) - float(o["loss"])) < 2e-5 * max(1.0, abs(float(o["loss"])))
