@@ -9,9 +9,9 @@
 // log(n_pad) on its score.  Masked tile slots get -1e30.  This is the same sum, re-ordered.
 //
 // One tile engine serves the three kernels.  A wave keeps 16 "stationary" rows (queries, or keys in the dK/dV
-// kernel) as MFMA B operands in registers; tiles of 64 "streamed" tokens sit in LDS as a row image [token][d]
-// (A operand of the score-type products) and as a transposed image [d][token] (A operand of the products that
-// sum over tokens).  Scores are computed transposed (streamed token on the accumulator row, stationary row on
+// kernel) as MFMA B operands in registers; tiles of 64 "streamed" tokens sit in LDS as ONE row image [token][d]: it
+// is the A operand of the score-type products as is, and the A operand of the products that sum over tokens through the
+// hardware transpose read ds_read_b64_tr_b16 (bf16) / strided reads (f32).  Scores are computed transposed (streamed token on the accumulator row, stationary row on
 // the lane) so the softmax is lane-local and P / dS feed the next MFMA from registers with a permuted k order
 // (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
 #include <type_traits>
@@ -68,11 +68,9 @@ template <typename T, int HD> struct AC {  // attention constants
   static constexpr int NCH = HD / VEC;                               // 16-byte chunks per head row
   static constexpr int DB = (HD + 15) / 16;                          // 16-row d blocks
   static constexpr int KS = sizeof(T) == 2 ? (HD + 31) / 32 : HD / 4;  // k-steps over d
-  static constexpr int DROW = sizeof(T) == 2 ? KS * 32 : HD;         // padded d per row image row
+  static constexpr int DROW = sizeof(T) == 2 ? KS * 32 : DB * 16;    // padded d per row image row (>= 16*DB, zero filled)
   static constexpr int RS = DROW * (int)sizeof(T) + 16;              // row image stride (bytes)
-  static constexpr int TS = 64 * (int)sizeof(T) + 16;                // transposed image stride (bytes)
   static constexpr int ROW_BYTES = 64 * RS;
-  static constexpr int TR_BYTES = DB * 16 * TS;
   using Frag = typename std::conditional<sizeof(T) == 2, bf16x8_t, float>::type;
 };
 
@@ -111,14 +109,18 @@ template <> struct MM<float> {
   }
 };
 
-// acc[db] += Timg[d = 16db + lane&15][token] * vals[token][col = lane&15] summed over the 64 tile tokens,
-// vals given as accumulator-layout registers pv[nb][r] (token = 16nb + 4q + r).
+// acc[db] += sum over the 64 tile tokens of Img[token][d = 16db + lane&15] * vals[token][col = lane&15], with vals given as
+// accumulator-layout registers pv[nb][r] (token = 16nb + 4q + r).  The A operand (rows d, k = tokens) is read from the
+// ROW image [token][d]: bf16 through the hardware transpose read ds_read_b64_tr_b16 (a 16-lane group fetches 4 token rows x
+// 16 d columns and each lane receives one column), f32 through plain strided reads.  No transposed copy of the tile exists.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 template <typename T, int HD>
-__device__ __forceinline__ void mma_over_tokens(const char* timg, const float (&pv)[4][4], int lane,
+__device__ __forceinline__ void mma_over_tokens(const char* rimg, const float (&pv)[4][4], int lane,
                                                 f32x4 (&acc)[AC<T, HD>::DB]) {
-  constexpr int DB = AC<T, HD>::DB, TS = AC<T, HD>::TS;
+  constexpr int DB = AC<T, HD>::DB, RS = AC<T, HD>::RS;
   const int r15 = lane & 15, q = lane >> 4;
   if constexpr (sizeof(T) == 2) {
+    const int qq = r15 >> 2, p = r15 & 3;   // lane 4qq+p of its 16-lane group addresses token row qq, d columns 4p..4p+3
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       u32x4 b = {pack2bf(pv[2 * s][0], pv[2 * s][1]), pack2bf(pv[2 * s][2], pv[2 * s][3]),
@@ -126,10 +128,11 @@ __device__ __forceinline__ void mma_over_tokens(const char* timg, const float (&
       const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b);
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        const char* row = timg + (db * 16 + r15) * TS + (32 * s + 4 * q) * 2;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(row);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(row + 32);
-        u32x4 a = {lo.x, lo.y, hi.x, hi.y};
+        const char* a0 = rimg + (32 * s + 4 * q + qq) * RS + (16 * db + 4 * p) * 2;
+        const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a0);
+        const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 16 * RS));
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        const s16x8_t a = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         acc[db] = MM<T>::mma(__builtin_bit_cast(bf16x8_t, a), bf, acc[db]);
       }
     }
@@ -140,7 +143,7 @@ __device__ __forceinline__ void mma_over_tokens(const char* timg, const float (&
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-          const float a = *reinterpret_cast<const float*>(timg + (db * 16 + r15) * TS + (16 * nb + 4 * q + r) * 4);
+          const float a = *reinterpret_cast<const float*>(rimg + (16 * nb + 4 * q + r) * RS + (16 * db + r15) * 4);
           acc[db] = MM<T>::mma(a, pv[nb][r], acc[db]);
         }
   }
@@ -160,40 +163,15 @@ __device__ __forceinline__ void mma_scores(const char* rimg, const typename AC<T
   }
 }
 
-// ---- staging: 64 token rows (pointers in LDS, null = zero row) -> row image and/or transposed image ----------
-template <typename T, int HD, bool ROW, bool TR>
-__device__ __forceinline__ void stage_tile(const T* const* ptrs, int off, char* rimg, char* timg) {
-  constexpr int VEC = AC<T, HD>::VEC, NCH = AC<T, HD>::NCH, RS = AC<T, HD>::RS, TS = AC<T, HD>::TS;
-  for (int p = threadIdx.x; p < 16 * NCH; p += AT) {
-    const int ch = p % NCH, g = p / NCH;
-    u32x4 rows[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const T* s = ptrs[4 * g + i];
-      rows[i] = s ? ld16(s + off + ch * VEC) : u32x4{0u, 0u, 0u, 0u};
-    }
-    if constexpr (ROW) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(rimg + (4 * g + i) * RS + ch * 16) = rows[i];
-    }
-    if constexpr (TR) {
-      if constexpr (sizeof(T) == 2) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          unsigned e[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const unsigned word = rows[i][j >> 1];
-            e[i] = (j & 1) ? (word >> 16) : (word & 0xffffu);
-          }
-          *reinterpret_cast<u32x2*>(timg + (ch * 8 + j) * TS + g * 8) = u32x2{e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<u32x4*>(timg + (ch * 4 + j) * TS + g * 16) = u32x4{rows[0][j], rows[1][j], rows[2][j], rows[3][j]};
-      }
-    }
+// ---- staging: 64 token rows (pointers in LDS, null = zero row) -> row image [token][d] ----------
+template <typename T, int HD>
+__device__ __forceinline__ void stage_tile(const T* const* ptrs, int off, char* rimg) {
+  constexpr int VEC = AC<T, HD>::VEC, NCH = AC<T, HD>::NCH, RS = AC<T, HD>::RS;
+  for (int p = threadIdx.x; p < 64 * NCH; p += AT) {
+    const int ch = p % NCH, t = p / NCH;
+    const T* s = ptrs[t];
+    const u32x4 v = s ? ld16(s + off + ch * VEC) : u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(rimg + t * RS + ch * 16) = v;
   }
 }
 
@@ -228,8 +206,8 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
-  char* vtimg = kimg + A::ROW_BYTES;
-  const T** kptr = reinterpret_cast<const T**>(vtimg + A::TR_BYTES);
+  char* vimg = kimg + A::ROW_BYTES;
+  const T** kptr = reinterpret_cast<const T**>(vimg + A::ROW_BYTES);
   float* kb = reinterpret_cast<float*>(kptr + 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
   const int head = blockIdx.y;
@@ -242,7 +220,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
   const long qrow = q_row(p, w, qvalid ? qi : 0);
   const T* qptr = qp ? qp + qrow * p.C + head * HD : qkv + qrow * 3 * p.C + head * HD;
 
-  zero_images<T, HD>(smem, A::ROW_BYTES + A::TR_BYTES);
+  zero_images<T, HD>(smem, 2 * A::ROW_BYTES);
   typename A::Frag qf[A::KS];
 #pragma unroll
   for (int s = 0; s < A::KS; ++s) qf[s] = load_row_frag_global<T, HD>(qptr, s, q);
@@ -264,8 +242,8 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
       kptr[tid] = kp; kb[tid] = b;
     }
     __syncthreads();
-    stage_tile<T, HD, true, false>(kptr, 0, kimg, nullptr);
-    stage_tile<T, HD, false, true>(kptr, p.C, nullptr, vtimg);
+    stage_tile<T, HD>(kptr, 0, kimg);
+    stage_tile<T, HD>(kptr, p.C, vimg);
     __syncthreads();
     f32x4 sacc[4];
     mma_scores<T, HD>(kimg, qf, lane, sacc);
@@ -290,7 +268,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
     l = l * alpha + ps;
 #pragma unroll
     for (int db = 0; db < A::DB; ++db) o[db] *= alpha;
-    mma_over_tokens<T, HD>(vtimg, pv, lane, o);
+    mma_over_tokens<T, HD>(vimg, pv, lane, o);
   }
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -310,8 +288,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
   char* vimg = kimg + A::ROW_BYTES;
-  char* ktimg = vimg + A::ROW_BYTES;
-  const T** kptr = reinterpret_cast<const T**>(ktimg + A::TR_BYTES);
+  const T** kptr = reinterpret_cast<const T**>(vimg + A::ROW_BYTES);
   float* kb = reinterpret_cast<float*>(kptr + 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
   const int head = blockIdx.y;
@@ -326,7 +303,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
   const T* doptr = reinterpret_cast<const T*>(p.dout) + qrow * p.C + head * HD;
   const T* optr = reinterpret_cast<const T*>(p.out) + qrow * p.C + head * HD;
 
-  zero_images<T, HD>(smem, 2 * A::ROW_BYTES + A::TR_BYTES);
+  zero_images<T, HD>(smem, 2 * A::ROW_BYTES);
   typename A::Frag qf[A::KS], dof[A::KS];
 #pragma unroll
   for (int s = 0; s < A::KS; ++s) {
@@ -357,8 +334,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
       kptr[tid] = kp; kb[tid] = b;
     }
     __syncthreads();
-    stage_tile<T, HD, true, true>(kptr, 0, kimg, ktimg);
-    stage_tile<T, HD, true, false>(kptr, p.C, vimg, nullptr);
+    stage_tile<T, HD>(kptr, 0, kimg);
+    stage_tile<T, HD>(kptr, p.C, vimg);
     __syncthreads();
     f32x4 sacc[4], pacc[4];
     mma_scores<T, HD>(kimg, qf, lane, sacc);
@@ -373,7 +350,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
         ds[nb][r] = pr * (pacc[nb][r] - delta);
       }
     }
-    mma_over_tokens<T, HD>(ktimg, ds, lane, dq);
+    mma_over_tokens<T, HD>(kimg, ds, lane, dq);
   }
   if (qvalid) {
     T* dst = p.qp ? reinterpret_cast<T*>(p.dqp) + qrow * p.C + head * HD
@@ -391,9 +368,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
   char* doimg = qimg + A::ROW_BYTES;
-  char* qtimg = doimg + A::ROW_BYTES;
-  char* dotimg = qtimg + A::TR_BYTES;
-  const T** qptrs = reinterpret_cast<const T**>(dotimg + A::TR_BYTES);
+  const T** qptrs = reinterpret_cast<const T**>(doimg + A::ROW_BYTES);
   const T** doptrs = qptrs + 64;
   float* lse_s = reinterpret_cast<float*>(doptrs + 64);
   float* delta_s = lse_s + 64;
@@ -411,7 +386,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
   if (c < w.nvalid) { krow = key_row(p, w, c); kp = qkv + krow * 3 * p.C + p.C + head * HD; kbias = 0.f; }
   else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; kbias = __logf((float)w.npad); }
 
-  zero_images<T, HD>(smem, 2 * A::ROW_BYTES + 2 * A::TR_BYTES);
+  zero_images<T, HD>(smem, 2 * A::ROW_BYTES);
   typename A::Frag kf[A::KS], vf[A::KS];
 #pragma unroll
   for (int s = 0; s < A::KS; ++s) {
@@ -439,8 +414,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
       qptrs[tid] = a; doptrs[tid] = b; lse_s[tid] = ls; delta_s[tid] = dl;
     }
     __syncthreads();
-    stage_tile<T, HD, true, true>(qptrs, 0, qimg, qtimg);
-    stage_tile<T, HD, true, true>(doptrs, 0, doimg, dotimg);
+    stage_tile<T, HD>(qptrs, 0, qimg);
+    stage_tile<T, HD>(doptrs, 0, doimg);
     __syncthreads();
     f32x4 sacc[4], pacc[4];
     mma_scores<T, HD>(qimg, kf, lane, sacc);   // S[i][key]
@@ -456,8 +431,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
         ds[nb][r] = pr[nb][r] * (pacc[nb][r] - d4[r]);
       }
     }
-    mma_over_tokens<T, HD>(dotimg, pr, lane, dv);
-    mma_over_tokens<T, HD>(qtimg, ds, lane, dk);
+    mma_over_tokens<T, HD>(doimg, pr, lane, dv);
+    mma_over_tokens<T, HD>(qimg, ds, lane, dk);
   }
   if (c < w.nvalid) {
     T* dst = reinterpret_cast<T*>(p.dqkv) + krow * 3 * p.C + p.C + head * HD;
@@ -485,18 +460,18 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
   using A = AC<T, HD>;
   const int nwin = p.B * p.nwy * p.nwx;
   if (which == 0) {
-    const size_t lds = A::ROW_BYTES + A::TR_BYTES + 64 * 8 + 64 * 4;
+    const size_t lds = 2 * A::ROW_BYTES + 64 * 8 + 64 * 4;
     hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
     return check_launch("attn_fwd");
   }
   {
-    const size_t lds = 2 * A::ROW_BYTES + A::TR_BYTES + 64 * 8 + 64 * 4;
+    const size_t lds = 2 * A::ROW_BYTES + 64 * 8 + 64 * 4;
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
     int rc = check_launch("attn_bwd_dq");
     if (rc) return rc;
   }
   {
-    const size_t lds = 2 * A::ROW_BYTES + 2 * A::TR_BYTES + 2 * 64 * 8 + 2 * 64 * 4;
+    const size_t lds = 2 * A::ROW_BYTES + 2 * 64 * 8 + 2 * 64 * 4;
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
