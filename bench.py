@@ -88,6 +88,7 @@ def main():
     from spegnet_amd.engine.distributed import GradSync, init_process_group_from_env
     rank, world, local = init_process_group_from_env("cuda")
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run"
+    local = local % max(torch.cuda.device_count(), 1)   # (rehearsal mode: several ranks may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -550,9 +550,14 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn_kernel(const T* __restrict__
   const int stid = tid & 255;                  // staging thread id within its operand team
   const bool team_y = WK == 2 || tid < 256;    // stages dY patches
   const bool team_x = WK == 2 || tid >= 256;   // stages X patches
-  const int tk = blockIdx.x % tiles_k, tn = blockIdx.x / tiles_k;
+  // XCD-aware order: workgroups that share blockIdx%8 (one XCD, one L2) take consecutive (split, tile) units, i.e. the k-tiles
+  // (for a 3x3 conv: the 9 taps) that re-read the same dY / X rows -- otherwise every tap re-fetches X from HBM.
+  const int ntile = (int)gridDim.x;
+  const int unit = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), ntile * (int)gridDim.y);
+  const int tile_id = unit % ntile, split_id = unit / ntile;
+  const int tk = tile_id % tiles_k, tn = tile_id / tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
-  const int m_begin = blockIdx.y * m_per_split;
+  const int m_begin = split_id * m_per_split;
   const int m_end = min(M, m_begin + m_per_split);
 
   const int fc = stid % NCH, mg = stid / NCH;  // feature chunk, m-group (4 rows each)

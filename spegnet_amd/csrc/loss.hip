@@ -158,7 +158,9 @@ __global__ void loss_finalize_kernel(const float* __restrict__ stats, const floa
   out[0] = seg + c.edge_w * edge; out[1] = seg; out[2] = edge;
 }
 
-// gradient w.r.t. the low-res prediction: gather over the full-res pixels whose bilinear taps include (yl, xl)
+// gradient w.r.t. the low-res prediction: gather over the full-res pixels whose bilinear taps include (yl, xl).
+// One 64-lane wave per low-res pixel: the lanes split the (3*sy) x (3*sx) candidate window and wave-reduce, so the 48x48
+// edge map (576 candidates per pixel) still launches 18k waves instead of 18k threads.
 template <typename T, bool EDGE>
 __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ pred, const float* __restrict__ tgt,
                                                         const float* __restrict__ wmap, const float* __restrict__ stats,
@@ -169,16 +171,18 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ pr
   const long HW = (long)S * S;
   const int sy = S / h, sx = S / w;
   const float g0 = go ? go[0] : 1.f;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const int lane = threadIdx.x & 63;
+  const long wave0 = (blockIdx.x * 256L + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * 256) >> 6;
+  for (long i = wave0; i < total; i += nwaves) {
     const int xl = (int)(i % w);
     const int yl = (int)((i / w) % h);
     const int b = (int)(i / ((long)w * h));
     const T* p = pred + (long)b * h * w;
-    float pw, k1 = 0.f, k2 = 0.f, k3 = 0.f, invW = 0.f;
+    float pw, k1 = 0.f, k2 = 0.f, invW = 0.f;
     if constexpr (EDGE) {
       pw = pos_weight(stats[b * 4 + 2], (float)HW);
       const float I = sums[b * 3 + 1], Ud = sums[b * 3 + 2] + stats[b * 4 + 2] + 1.f;   // dice = 1 - (2I+1)/Ud
-      k1 = -2.f / Ud;                 // d dice / d I
+      k1 = -2.f / Ud;                    // d dice / d I
       k2 = (2.f * I + 1.f) / (Ud * Ud);  // d dice / d P
     } else {
       pw = pos_weight(stats[b * 4 + 0], (float)HW);
@@ -187,42 +191,41 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ pr
       k1 = -(D + (I + 1.f)) / (D * D);   // d wiou / d I  (dD/dI = -1)
       k2 = (I + 1.f) / (D * D);          // d wiou / d U
     }
-    (void)k3;
-    float acc = 0.f;
     const int Y0 = max(0, (yl - 1) * sy), Y1 = min(S - 1, (yl + 2) * sy);
     const int X0 = max(0, (xl - 1) * sx), X1 = min(S - 1, (xl + 2) * sx);
-    for (int Y = Y0; Y <= Y1; ++Y) {
-      float wy;
+    const int nx = X1 - X0 + 1, ncand = (Y1 - Y0 + 1) * nx;
+    float acc = 0.f;
+    for (int c = lane; c < ncand; c += 64) {
+      const int Y = Y0 + c / nx, X = X0 + c % nx;
+      float wy, wx;
       if (h == S) wy = (Y == yl) ? 1.f : 0.f;
       else { int y0, y1; float ly; bil_src_l(Y, h, S, y0, y1, ly); wy = (y0 == yl ? 1.f - ly : 0.f) + (y1 == yl ? ly : 0.f); }
-      if (wy == 0.f) continue;
-      for (int X = X0; X <= X1; ++X) {
-        float wx;
-        if (w == S) wx = (X == xl) ? 1.f : 0.f;
-        else { int x0, x1; float lx; bil_src_l(X, w, S, x0, x1, lx); wx = (x0 == xl ? 1.f - lx : 0.f) + (x1 == xl ? lx : 0.f); }
-        if (wx == 0.f) continue;
-        const float z = bil_at<T>(p, h, w, S, Y, X);
-        const float t = tgt[b * HW + (long)Y * S + X];
-        const float s = sigmoid_f(z), ds = s * (1.f - s);
-        float g;
-        if constexpr (EDGE) {
-          const float pt = t * s + (1.f - t) * (1.f - s);
-          const float ptc = fmaxf(pt, 1e-7f);
-          const float om = 1.f - pt;
-          // f = -pw*alpha*om^gamma*log(ptc);  df/dpt = -pw*alpha*( -gamma*om^(gamma-1)*log(ptc) + om^gamma/ptc*[pt>1e-7] )
-          const float dfdpt = -pw * alpha * (-gamma * __powf(om, gamma - 1.f) * __logf(ptc) + (pt > 1e-7f ? __powf(om, gamma) / ptc : 0.f));
-          const float dptdz = (2.f * t - 1.f) * ds;
-          g = dfdpt * dptdz / (float)HW + (k1 * t + k2) * ds;
-        } else {
-          const float wv = wmap[b * HW + (long)Y * S + X];
-          const float lw = 1.f + (pw - 1.f) * t;
-          const float dbce = (1.f - t) - lw * (1.f - s);
-          g = bce_w * wv * dbce * invW + iou_w * (k1 * t + k2 * 1.f) * ds * wv;
-        }
-        acc += wy * wx * g;
+      if (w == S) wx = (X == xl) ? 1.f : 0.f;
+      else { int x0, x1; float lx; bil_src_l(X, w, S, x0, x1, lx); wx = (x0 == xl ? 1.f - lx : 0.f) + (x1 == xl ? lx : 0.f); }
+      const float wgt = wy * wx;
+      if (wgt == 0.f) continue;
+      const float z = bil_at<T>(p, h, w, S, Y, X);
+      const float t = tgt[b * HW + (long)Y * S + X];
+      const float s = sigmoid_f(z), ds = s * (1.f - s);
+      float g;
+      if constexpr (EDGE) {
+        const float pt = t * s + (1.f - t) * (1.f - s);
+        const float ptc = fmaxf(pt, 1e-7f);
+        const float om = 1.f - pt;
+        // f = -pw*alpha*om^gamma*log(ptc);  df/dpt = -pw*alpha*( -gamma*om^(gamma-1)*log(ptc) + om^gamma/ptc*[pt>1e-7] )
+        const float dfdpt = -pw * alpha * (-gamma * __powf(om, gamma - 1.f) * __logf(ptc) + (pt > 1e-7f ? __powf(om, gamma) / ptc : 0.f));
+        const float dptdz = (2.f * t - 1.f) * ds;
+        g = dfdpt * dptdz / (float)HW + (k1 * t + k2) * ds;
+      } else {
+        const float wv = wmap[b * HW + (long)Y * S + X];
+        const float lw = 1.f + (pw - 1.f) * t;
+        const float dbce = (1.f - t) - lw * (1.f - s);
+        g = bce_w * wv * dbce * invW + iou_w * (k1 * t + k2) * ds * wv;
       }
+      acc += wgt * g;
     }
-    ST<T>::st(dpred + i, acc * coef * g0);
+    acc = wave_sum(acc);
+    if (lane == 0) ST<T>::st(dpred + i, acc * coef * g0);
   }
 }
 
@@ -265,9 +268,9 @@ extern "C" int spg_loss_grad(int dtype, const void* pred, const float* target, c
                              const float* sums, const float* grad_out, void* dpred, int B, int S, int h, int w, int edge, float coef,
                              float bce_w, float iou_w, float alpha, float gamma, spg_stream_t stream) {
   SPG_REQUIRE(S % h == 0 && S % w == 0, "loss_grad: target size must be a multiple of the prediction size");
-  const long total = (long)B * h * w;
-  long g = (total + 255) / 256;
-  if (g > 4096) g = 4096;
+  const long total = (long)B * h * w;   // one wave per low-res pixel
+  long g = (total + 3) / 4;
+  if (g > 8192) g = 8192;
   hipStream_t s = (hipStream_t)stream;
   if (edge) {
     if (dtype == SPG_BF16) hipLaunchKernelGGL((loss_grad_kernel<bf16_t, true>), dim3((int)g), dim3(256), 0, s, (const bf16_t*)pred, target, wmap, stats, sums, grad_out, (bf16_t*)dpred, B, S, h, w, coef, bce_w, iou_w, alpha, gamma);

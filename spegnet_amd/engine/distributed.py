@@ -26,9 +26,10 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        # "nccl" IS RCCL on ROCm.  SPG_DIST_BACKEND=gloo exists only to rehearse the N>1 code path with several ranks on ONE GPU
+        backend = os.environ.get("SPG_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
