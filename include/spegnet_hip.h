@@ -53,7 +53,8 @@ int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbia
  * spg_unpack_conv3x3_grad: packed f32 grad [Co][tap][Ci] -> torch layout [Co,Ci,3,3] (accumulates: dst += packed). */
 int spg_pack_matrix(int dtype, const float* src, void* dst, int R, int C, int transpose, spg_stream_t stream);
 /* spg_pack_batch: the same for a whole table of matrices in ONE launch.  jobs = device array of
- * struct { const float* src; void* dst; int R, C, transpose, tile0; } (tile0 = prefix sum of ceil(R/32)*ceil(C/32)). */
+ * struct { const float* src; void* dst; void* dst_t; int R, C, tile0, pad; }  -- dst = [R][C] copy or NULL, dst_t = [C][R] or NULL
+ * (tile0 = prefix sum of ceil(R/32)*ceil(C/32)); one read of the fp32 master produces both layouts.              */
 int spg_pack_batch(int dtype, const void* jobs, int njobs, int total_tiles, spg_stream_t stream);
 int spg_pack_conv3x3(int dtype, const float* src, void* dst_fwd, void* dst_dgrad, int Co, int Ci, spg_stream_t stream);
 int spg_unpack_conv3x3_grad(const float* packed, float* dst, int Co, int Ci, spg_stream_t stream);
@@ -171,11 +172,12 @@ int spg_loss_grad(int dtype, const void* pred, const float* target, const float*
 /* ---- optimizer (engine/trainer.py:274-306 param groups, :399-409 clip + AdamW step) over a flat f32 arena ---------
  * sumsq: out[0] += sum x^2.  adamw: step_f[0] += 1, then clip coefficient min(1, clip/(sqrt(gnorm_sq)*grad_scale+1e-6))
  * and a decoupled-weight-decay Adam update; group_of_chunk[i/256] selects lr[g], wd[g] (device arrays, so the
- * scheduler can change them without re-capturing a hipGraph).  Every parameter starts on a 256-element boundary.  */
+ * scheduler can change them without re-capturing a hipGraph).  Every parameter starts on a 256-element boundary.
+ * zero_grad != 0 clears g after use (the next step's kernels accumulate into it), saving a separate memset pass.      */
 int spg_sumsq(const float* x, float* out, long n, spg_stream_t stream);
-int spg_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,
+int spg_adamw(float* p, float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,
               const float* wd, const float* gnorm_sq, float* step_f, float clip, float beta1, float beta2, float eps,
-              float grad_scale, long n, spg_stream_t stream);
+              float grad_scale, int zero_grad, long n, spg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,7 @@ SIGNATURES = {
     "spg_loss_finalize": "pppp" "iiffffffp",
     "spg_loss_grad": "ippppppp" "iiiiifffffp",
     "spg_sumsq": "pp" "lp",
-    "spg_adamw": "ppppppppp" "fffff" "lp",
+    "spg_adamw": "ppppppppp" "fffff" "ilp",
 }
 _OPTIONAL = {}
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F}

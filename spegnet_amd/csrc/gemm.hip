@@ -872,8 +872,9 @@ __global__ void pack_matrix_kernel(const float* __restrict__ src, T* __restrict_
 // a block finds its job by binary search over the tile prefix sums).  Removes ~400 tiny launches per optimizer step.
 struct PackJob {
   const float* src;
-  void* dst;
-  int R, C, transpose, tile0;   // tile0 = first 32x32 tile index of this job
+  void* dst;      // [R][C] copy (may be null)
+  void* dst_t;    // [C][R] transposed copy (may be null)
+  int R, C, tile0, pad;   // tile0 = first 32x32 tile index of this job
 };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
@@ -890,22 +891,19 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
   const int bx = (t % tiles_c) * 32, by = (t / tiles_c) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   T* dst = reinterpret_cast<T*>(jb.dst);
+  T* dst_t = reinterpret_cast<T*>(jb.dst_t);
   const int R = jb.R, C = jb.C;
-  if (!jb.transpose) {
-    for (int j = ty; j < 32; j += 8) {
-      const int r = by + j, c = bx + tx;
-      if (r < R && c < C) ST<T>::st(dst + (long)r * C + c, jb.src[(long)r * C + c]);
-    }
-    return;
-  }
-  for (int j = ty; j < 32; j += 8) {
+  for (int j = ty; j < 32; j += 8) {          // one read of the fp32 master serves both layouts
     const int r = by + j, c = bx + tx;
-    tile[j][tx] = (r < R && c < C) ? jb.src[(long)r * C + c] : 0.f;
+    const float v = (r < R && c < C) ? jb.src[(long)r * C + c] : 0.f;
+    tile[j][tx] = v;
+    if (dst && r < R && c < C) ST<T>::st(dst + (long)r * C + c, v);
   }
+  if (!dst_t) return;
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int c = bx + j, r = by + tx;
-    if (r < R && c < C) ST<T>::st(dst + (long)c * R + r, tile[tx][j]);
+    if (r < R && c < C) ST<T>::st(dst_t + (long)c * R + r, tile[tx][j]);
   }
 }
 

@@ -18,11 +18,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 }
 
 // group_of_chunk[i/256] selects (lr, wd); every parameter starts on a 256-element boundary of the arena.
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const unsigned char* __restrict__ group_of_chunk,
                                                     const float* __restrict__ lr, const float* __restrict__ wd,
                                                     const float* __restrict__ gnorm_sq, const float* __restrict__ step_f,
-                                                    float clip, float b1, float b2, float eps, float grad_scale, long n4) {
+                                                    float clip, float b1, float b2, float eps, float grad_scale, long n4,
+                                                    int zero_grad) {
   float coef = grad_scale;
   if (clip > 0.f) {
     const float tot = sqrtf(gnorm_sq[0]) * grad_scale;
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     *reinterpret_cast<f32x4*>(p + i * 4) = pv;
     *reinterpret_cast<f32x4*>(m + i * 4) = mv;
     *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+    if (zero_grad) *reinterpret_cast<f32x4*>(g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};   // next step accumulates into a clean arena
   }
 }
 
@@ -66,14 +68,14 @@ extern "C" int spg_sumsq(const float* x, float* out, long n, spg_stream_t stream
   return check_launch("sumsq");
 }
 
-extern "C" int spg_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,
+extern "C" int spg_adamw(float* p, float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,
                          const float* wd, const float* gnorm_sq, float* step_f, float clip, float beta1, float beta2, float eps,
-                         float grad_scale, long n, spg_stream_t stream) {
+                         float grad_scale, int zero_grad, long n, spg_stream_t stream) {
   SPG_REQUIRE(n % 256 == 0, "adamw: arena size %ld must be a multiple of 256", n);
   hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_f, 1.0f);
   long gr = (n / 4 + 255) / 256;
   if (gr > 4096) gr = 4096;
   hipLaunchKernelGGL(adamw_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, p, g, m, v, group_of_chunk, lr, wd, gnorm_sq,
-                     step_f, clip, beta1, beta2, eps, grad_scale, n / 4);
+                     step_f, clip, beta1, beta2, eps, grad_scale, n / 4, zero_grad);
   return check_launch("adamw");
 }

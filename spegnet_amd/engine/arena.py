@@ -71,6 +71,7 @@ class Arena:
             prev_key = key
         self.unit_ends.append(off)
         self.m = self.v = None
+        self._clean = True   # arena.g is all zeros
         self.step_f = torch.zeros(1, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.lr = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -90,7 +91,10 @@ class Arena:
         self.lr.copy_(torch.clamp(self.lr * factor, min=min_lr))
 
     def zero_grad(self):
-        self.g.zero_()
+        """Clears the gradient arena unless the previous optimizer step already did (adamw zero_grad=1)."""
+        if not self._clean:
+            self.g.zero_()
+        self._clean = False
 
     def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
         if self.m is None:
@@ -101,7 +105,8 @@ class Arena:
         _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, s)
         _lib.call("spg_adamw", self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                   self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
-                  self.step_f.data_ptr(), float(clip), betas[0], betas[1], eps, float(grad_scale), self.size, s)
+                  self.step_f.data_ptr(), float(clip), betas[0], betas[1], eps, float(grad_scale), 1, self.size, s)
+        self._clean = True
 
     def state_dict(self):
         return {"m": self.m, "v": self.v, "step": self.step_f.clone(), "lr": self.lr.clone(), "wd": self.wd.clone()}

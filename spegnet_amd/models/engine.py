@@ -71,9 +71,8 @@ class Engine:
                 R, C = p.shape[0], p.numel() // p.shape[0]
                 W[name] = torch.empty((R, C), dtype=T, device=p.device)
                 W[name + ":T"] = torch.empty((C, R), dtype=T, device=p.device)
-                for dst, tr in ((W[name], 0), (W[name + ":T"], 1)):
-                    jobs.append(struct.pack("<QQiiii", p.data_ptr(), dst.data_ptr(), R, C, tr, tile0))
-                    tile0 += ((R + 31) // 32) * ((C + 31) // 32)
+                jobs.append(struct.pack("<QQQiiii", p.data_ptr(), W[name].data_ptr(), W[name + ":T"].data_ptr(), R, C, tile0, 0))
+                tile0 += ((R + 31) // 32) * ((C + 31) // 32)
             blob = torch.frombuffer(bytearray(b"".join(jobs)), dtype=torch.uint8).to(next(iter(P.values())).device)
             self._pack_jobs, self._pack_n, self._pack_tiles = blob, len(jobs), tile0
             self._pack_key = tuple(p.data_ptr() for p in P.values())
