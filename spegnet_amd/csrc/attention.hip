@@ -14,6 +14,7 @@
 // hardware transpose read ds_read_b64_tr_b16 (bf16) / strided reads (f32).  Scores are computed transposed (streamed token on the accumulator row, stationary row on
 // the lane) so the softmax is lane-local and P / dS feed the next MFMA from registers with a permuted k order
 // (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
@@ -454,11 +455,293 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
   }
 }
 
+// =====================================================================================================
+// "resident window" variants (bf16, 64 < keys <= 320, queries <= 256: the stage-3 windows and block 44 of Hiera-L).
+// One workgroup of 8 waves per (window, head): the whole window's K and V (forward, dQ) or Q and dO (dK/dV) are staged ONCE
+// into LDS as row images, then every wave walks its own 16-row blocks over all tiles without any further barrier.  The
+// tiled kernels above re-stage each 64-token tile in every query-tile workgroup; here each token is loaded once per head.
+// =====================================================================================================
+constexpr int RES_ROWS = 320;     // max staged rows (5 tiles of 64)
+constexpr int RES_THREADS = 512;
+
+// copies rows (pointer table in LDS, null = zero row) into a row image; `off2 >= 0` also copies the rows at ptr + off2 into
+// rimg2 (K and V share a pointer table).  Unrolled by 5 so that all of a thread's global loads are issued before the first LDS
+// store (a plain runtime loop serialises LDS-pointer read -> global load -> LDS write per item).
+template <typename T, int HD>
+__device__ __forceinline__ void stage_rows(const T* const* ptrs, int nrows, int off, char* rimg, int off2 = -1, char* rimg2 = nullptr) {
+  constexpr int VEC = AC<T, HD>::VEC, NCH = AC<T, HD>::NCH, RS = AC<T, HD>::RS;
+  constexpr int U = 5;
+  const int total = nrows * NCH;
+  for (int base = threadIdx.x; base < total; base += RES_THREADS * U) {
+    u32x4 v[U], v2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = base + u * RES_THREADS;
+      v[u] = u32x4{0u, 0u, 0u, 0u}; v2[u] = u32x4{0u, 0u, 0u, 0u};
+      if (p < total) {
+        const int ch = p % NCH, t = p / NCH;
+        const T* sp = ptrs[t];
+        if (sp) {
+          v[u] = ld16(sp + off + ch * VEC);
+          if (rimg2) v2[u] = ld16(sp + off2 + ch * VEC);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = base + u * RES_THREADS;
+      if (p < total) {
+        const int ch = p % NCH, t = p / NCH;
+        *reinterpret_cast<u32x4*>(rimg + t * RS + ch * 16) = v[u];
+        if (rimg2) *reinterpret_cast<u32x4*>(rimg2 + t * RS + ch * 16) = v2[u];
+      }
+    }
+  }
+}
+template <typename T, int HD> struct ResLds {
+  static constexpr int IMG = RES_ROWS * AC<T, HD>::RS;
+  static constexpr int BYTES = 2 * IMG + RES_ROWS * 8 + 3 * RES_ROWS * 4;
+};
+
+template <typename T, int HD, bool DQ>
+__global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   // forward (DQ=false) or dQ (DQ=true)
+  using A = AC<T, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kimg = smem;
+  char* vimg = kimg + ResLds<T, HD>::IMG;
+  const T** kptr = reinterpret_cast<const T**>(vimg + ResLds<T, HD>::IMG);
+  float* kb = reinterpret_cast<float*>(kptr + RES_ROWS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
+  const int head = blockIdx.x;
+  const Win w = get_win(p, blockIdx.y);
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* qp = reinterpret_cast<const T*>(p.qp);
+  const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
+  const int ntiles = (nkeys + 63) >> 6, nrows = ntiles * 64;
+  for (int i = tid * 16; i < 2 * ResLds<T, HD>::IMG; i += RES_THREADS * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+  for (int c = tid; c < nrows; c += RES_THREADS) {
+    const T* kp = nullptr;
+    float b = NEG_BIG;
+    if (c < w.nvalid) { kp = qkv + key_row(p, w, c) * 3 * p.C + p.C + head * HD; b = 0.f; }
+    else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; b = __logf((float)w.npad); }
+    kptr[c] = kp; kb[c] = b;
+  }
+  __syncthreads();
+  stage_rows<T, HD>(kptr, nrows, 0, kimg, p.C, vimg);
+  __syncthreads();
+
+  for (int rb = wave; rb * 16 < w.nq; rb += RES_THREADS / 64) {
+    const int qi = rb * 16 + r15;
+    const bool qvalid = qi < w.nq;
+    const long qrow = q_row(p, w, qvalid ? qi : 0);
+    const T* qptr = qp ? qp + qrow * p.C + head * HD : qkv + qrow * 3 * p.C + head * HD;
+    typename A::Frag qf[A::KS];
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) qf[s] = load_row_frag_global<T, HD>(qptr, s, q);
+    if constexpr (!DQ) {
+      f32x4 o[A::DB];
+#pragma unroll
+      for (int db = 0; db < A::DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float m = NEG_BIG, l = 0.f;
+      for (int t = 0; t < ntiles; ++t) {
+        f32x4 sacc[4];
+        mma_scores<T, HD>(kimg + t * A::ROW_BYTES, qf, lane, sacc);
+        float pv[4][4];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + t * 64 + nb * 16 + q * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pv[nb][r] = sacc[nb][r] * p.scale + b4[r]; mx = fmaxf(mx, pv[nb][r]); }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __expf(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pv[nb][r] = __expf(pv[nb][r] - mn); ps += pv[nb][r]; }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int db = 0; db < A::DB; ++db) o[db] *= alpha;
+        mma_over_tokens<T, HD>(vimg + t * A::ROW_BYTES, pv, lane, o);
+      }
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      if (qvalid) {
+        T* orow = reinterpret_cast<T*>(p.out) + qrow * p.C + head * HD;
+        store_rows_T<T, HD>(orow, o, 1.f / l, lane);
+        if (q == 0) p.lse[qrow * p.heads + head] = m + __logf(l);
+      }
+    } else {
+      const T* doptr = reinterpret_cast<const T*>(p.dout) + qrow * p.C + head * HD;
+      const T* optr = reinterpret_cast<const T*>(p.out) + qrow * p.C + head * HD;
+      typename A::Frag dof[A::KS];
+#pragma unroll
+      for (int s = 0; s < A::KS; ++s) dof[s] = load_row_frag_global<T, HD>(doptr, s, q);
+      float delta = 0.f;
+      for (int d = q; d < HD; d += 4) delta += ST<T>::ld(doptr + d) * ST<T>::ld(optr + d);
+      delta += __shfl_xor(delta, 16, 64);
+      delta += __shfl_xor(delta, 32, 64);
+      const float lse = qvalid ? p.lse[qrow * p.heads + head] : 0.f;
+      if (qvalid && q == 0) p.delta[qrow * p.heads + head] = delta;
+      f32x4 dq[A::DB];
+#pragma unroll
+      for (int db = 0; db < A::DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < ntiles; ++t) {
+        f32x4 sacc[4], pacc[4];
+        mma_scores<T, HD>(kimg + t * A::ROW_BYTES, qf, lane, sacc);
+        mma_scores<T, HD>(vimg + t * A::ROW_BYTES, dof, lane, pacc);
+        float ds[4][4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + t * 64 + nb * 16 + q * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __expf(sacc[nb][r] * p.scale + b4[r] - lse);
+            ds[nb][r] = pr * (pacc[nb][r] - delta);
+          }
+        }
+        mma_over_tokens<T, HD>(kimg + t * A::ROW_BYTES, ds, lane, dq);
+      }
+      if (qvalid) {
+        T* dst = p.qp ? reinterpret_cast<T*>(p.dqp) + qrow * p.C + head * HD
+                      : reinterpret_cast<T*>(p.dqkv) + qrow * 3 * p.C + head * HD;
+        store_rows_T<T, HD>(dst, dq, p.scale, lane);
+      }
+    }
+  }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p) {
+  using A = AC<T, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qimg = smem;
+  char* doimg = qimg + ResLds<T, HD>::IMG;
+  const T** qptrs = reinterpret_cast<const T**>(doimg + ResLds<T, HD>::IMG);
+  float* lse_s = reinterpret_cast<float*>(qptrs + RES_ROWS);
+  float* delta_s = lse_s + RES_ROWS;
+  long* qrows = nullptr; (void)qrows;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
+  const int head = blockIdx.x;
+  const Win w = get_win(p, blockIdx.y);
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* qp = reinterpret_cast<const T*>(p.qp);
+  const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
+  const int ntq = (w.nq + 63) >> 6, nrows = ntq * 64;
+  for (int i = tid * 16; i < 2 * ResLds<T, HD>::IMG; i += RES_THREADS * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < nrows; i += RES_THREADS) {
+    const T* a = nullptr;
+    float ls = 1.0e30f, dl = 0.f;
+    if (i < w.nq) {
+      const long row = q_row(p, w, i);
+      a = qp ? qp + row * p.C + head * HD : qkv + row * 3 * p.C + head * HD;
+      ls = p.lse[row * p.heads + head];
+      dl = p.delta[row * p.heads + head];
+    }
+    qptrs[i] = a; lse_s[i] = ls; delta_s[i] = dl;
+  }
+  __syncthreads();
+  stage_rows<T, HD>(qptrs, nrows, 0, qimg);
+  __syncthreads();
+  // dO rows: same token rows in the dout tensor -> rebuild the pointer table in place
+  for (int i = tid; i < nrows; i += RES_THREADS) {
+    const T* b = nullptr;
+    if (i < w.nq) b = reinterpret_cast<const T*>(p.dout) + q_row(p, w, i) * p.C + head * HD;
+    qptrs[i] = b;
+  }
+  __syncthreads();
+  stage_rows<T, HD>(qptrs, nrows, 0, doimg);
+  __syncthreads();
+
+  for (int kbk = wave; kbk * 16 < nkeys; kbk += RES_THREADS / 64) {
+    const int c = kbk * 16 + r15;
+    const T* kp = nullptr;
+    float kbias = NEG_BIG;
+    long krow = 0;
+    if (c < w.nvalid) { krow = key_row(p, w, c); kp = qkv + krow * 3 * p.C + p.C + head * HD; kbias = 0.f; }
+    else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; kbias = __logf((float)w.npad); }
+    typename A::Frag kf[A::KS], vf[A::KS];
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) {
+      kf[s] = load_row_frag_global<T, HD>(kp, s, q);
+      vf[s] = load_row_frag_global<T, HD>(kp ? kp + p.C : nullptr, s, q);
+    }
+    f32x4 dk[A::DB], dv[A::DB];
+#pragma unroll
+    for (int db = 0; db < A::DB; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < ntq; ++t) {
+      f32x4 sacc[4], pacc[4];
+      mma_scores<T, HD>(qimg + t * A::ROW_BYTES, kf, lane, sacc);
+      mma_scores<T, HD>(doimg + t * A::ROW_BYTES, vf, lane, pacc);
+      float pr[4][4], ds[4][4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + t * 64 + nb * 16 + q * 4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + t * 64 + nb * 16 + q * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[nb][r] = __expf(sacc[nb][r] * p.scale + kbias - l4[r]);
+          ds[nb][r] = pr[nb][r] * (pacc[nb][r] - d4[r]);
+        }
+      }
+      mma_over_tokens<T, HD>(doimg + t * A::ROW_BYTES, pr, lane, dv);
+      mma_over_tokens<T, HD>(qimg + t * A::ROW_BYTES, ds, lane, dk);
+    }
+    if (c < w.nvalid) {
+      T* dst = reinterpret_cast<T*>(p.dqkv) + krow * 3 * p.C + p.C + head * HD;
+      store_rows_T<T, HD>(dst, dk, p.scale, lane);
+      store_rows_T<T, HD>(dst + p.C, dv, 1.f, lane);
+    } else if (c == w.nvalid && w.npad > 0) {
+      float* db_ = p.dbias + p.C + head * HD;
+#pragma unroll
+      for (int db = 0; db < A::DB; ++db) {
+        const int d = db * 16 + q * 4;
+        if (d < HD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(db_ + d + r, dk[db][r] * p.scale);
+            atomicAdd(db_ + p.C + d + r, dv[db][r]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int HD>
 static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
   using A = AC<T, HD>;
   const int nwin = p.B * p.nwy * p.nwx;
+  static int use_res = -1;
+  if (use_res < 0) { const char* e = getenv("SPG_ATTN"); use_res = (e && strcmp(e, "tiled") == 0) ? 0 : 1; }
+  if constexpr (sizeof(T) == 2 && ResLds<T, HD>::BYTES <= 160 * 1024) {
+    if (use_res && maxk > 65 && maxk <= RES_ROWS && maxq <= 256) {   // multi-tile windows only (stage 3, block 44)
+      constexpr int LDS = ResLds<T, HD>::BYTES;
+      static bool attr = false;
+      if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_q_kernel<T, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_q_kernel<T, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr = true;
+      }
+      const dim3 grid(p.heads, nwin);
+      if (which == 0) {
+        hipLaunchKernelGGL((attn_res_q_kernel<T, HD, false>), grid, dim3(RES_THREADS), LDS, s, p);
+        return check_launch("attn_fwd(res)");
+      }
+      hipLaunchKernelGGL((attn_res_q_kernel<T, HD, true>), grid, dim3(RES_THREADS), LDS, s, p);
+      int rc = check_launch("attn_bwd_dq(res)");
+      if (rc) return rc;
+      hipLaunchKernelGGL((attn_res_dkv_kernel<T, HD>), grid, dim3(RES_THREADS), LDS, s, p);
+      return check_launch("attn_bwd_dkv(res)");
+    }
+  }
   if (which == 0) {
     const size_t lds = 2 * A::ROW_BYTES + 64 * 8 + 64 * 4;
     hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
