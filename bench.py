@@ -115,7 +115,16 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(max(args.warmup, 1)):
-        losses = step(images, masks, edges)
+        try:
+            losses = step(images, masks, edges)
+        except Exception as e:  # graph capture problem (e.g. a collective that cannot be combined with capture): run eager
+            if args.no_graph or i > 0:
+                raise
+            log(f"graph mode failed ({type(e).__name__}: {e}); falling back to eager launches with overlapped all-reduce")
+            torch.cuda.synchronize()
+            args.no_graph = True
+            step = TrainStep(model, crit, arena, grad_clip=1.0, sync=sync, capture=False)
+            losses = step(images, masks, edges)
         if i == 0:
             torch.cuda.synchronize()
             log("first step done (includes hipGraph capture)" if not args.no_graph else "first eager step done")
@@ -174,7 +183,7 @@ def main():
             "config": {"workload": f"SPEGNet (Hiera-L trunk + CFI + EFE + PED) train step: fwd + CODLoss + bwd + clip + AdamW, "
                                    f"batch {args.batch}/GPU @{args.size}x{args.size}, random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph fwd+bwd | RCCL all-reduce | hipGraph optimizer"),
+                       "launch": "eager, bucketed all-reduce overlapped with backward" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph segments (fwd+loss+bwd in 4 pieces) with RCCL all-reduce of finished gradient ranges on a side stream | hipGraph optimizer"),
                        "final_loss": round(loss_val, 5)},
             "roofline": roof, "cpu_baseline": cpu,
         }

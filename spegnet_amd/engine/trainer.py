@@ -34,15 +34,22 @@ class TrainStep:
 
     capture=False : eager launches; with a GradSync the bucketed all-reduce overlaps the trunk backward.
     capture=True  : the step is recorded once into hipGraphs and replayed (removes ~1.5k host launches per step).
-                    world==1: one graph for the whole step.  world>1: graph A = zero-grad + forward + loss + backward,
-                    then ONE eager RCCL all-reduce of the flat gradient arena, then graph B = clip + AdamW + re-pack
-                    (collectives stay outside the graphs; at 8 img/GPU the exposed all-reduce is a few ms)."""
+                    world==1: one graph for the whole step.
+                    world>1 : the backward is written out by hand (no autograd inside) and captured as SEGMENTS --
+                    [forward + loss + head backward + last trunk blocks], [next blocks], ..., [first blocks + embeddings] --
+                    after each segment's replay the gradient range that just became final is all-reduced over RCCL on
+                    a side stream while the next segment runs; a last graph does clip + AdamW + re-pack.  Collectives
+                    stay outside graph capture, yet overlap with backward."""
 
     def __init__(self, model: SPEGNet, criterion: CODLoss, arena: Arena, grad_clip: float = 1.0, sync: Optional[GradSync] = None,
-                 capture: bool = False):
+                 capture: bool = False, force_segmented: bool = False):
         self.model, self.criterion, self.arena, self.clip, self.sync = model, criterion, arena, grad_clip, sync
         self.capture = capture
+        self.force_segmented = force_segmented   # tests: exercise the multi-GPU segmented capture on one rank
         self.graph = self.graph_b = None
+        self.segments = None
+        self.comm_stream = None
+        self.n_segments = 4
         self.static = None
         self.losses = None
         self.world = sync.world if sync is not None else 1
@@ -78,6 +85,101 @@ class TrainStep:
             self._allreduce_flat()
         self._opt(1.0 / self.world)
         return losses
+
+    # ---- hand-written backward in segments (multi-GPU graph mode) ---------------------------------------------------
+    def _segment_plan(self):
+        """[(lo, hi, grad_end_offset)] over trunk blocks, last-to-first; grad_end_offset = arena offset up to which
+        gradients are final after the segment (arena order: head, block L-1, ..., block 0, embeddings)."""
+        nb = len(self.model.engine.blocks)
+        ends = self.arena.unit_ends            # [head, blk L-1, ..., blk 0, embeddings]
+        per = (nb + self.n_segments - 1) // self.n_segments
+        plan, hi = [], nb
+        while hi > 0:
+            lo = max(0, hi - per)
+            done_units = 1 + (nb - lo)         # head + blocks nb-1 .. lo
+            plan.append((lo, hi, ends[done_units - 1] if lo > 0 else ends[-1]))
+            hi = lo
+        return plan
+
+    def _seg_first(self, images, masks, edges, lo, hi):
+        model, eng = self.model, self.model.engine
+        self.arena.zero_grad()
+        feats, tctx = eng.trunk_fwd(images, True, True)
+        out, hctx = eng.head_fwd(feats[1:4], True, True)
+        leaves = [t.detach().requires_grad_(True) for t in out["predictions"] + [out["edge"]]]
+        losses = self.criterion.forward_batched(leaves[:3], leaves[3], masks, edges)
+        grads = torch.autograd.grad(losses["loss"], leaves)     # only the fused-loss node: four tiny kernels
+        d = eng.head_bwd(hctx, list(grads[:3]), grads[3], None)
+        eng.trunk_bwd_begin(tctx, [None] + d)
+        eng.trunk_bwd_blocks(lo, hi)
+        return {k: v.detach() for k, v in losses.items()}
+
+    def _capture_segmented(self, images, masks, edges):
+        model, ar = self.model, self.arena
+        eng = model.engine
+        self.static = (images.clone(), masks.clone(), edges.clone())
+        if ar.m is None:
+            ar.m, ar.v = torch.zeros_like(ar.p), torch.zeros_like(ar.p)
+        plan = self._segment_plan()
+        keep = [ar.p, ar.m, ar.v, ar.step_f] + list(model.buffers())
+        snap = [t.clone() for t in keep]
+
+        def run_all():
+            (lo, hi, _), rest = plan[0], plan[1:]
+            losses = self._seg_first(*self.static, lo, hi)
+            for (l2, h2, _) in rest:
+                eng.trunk_bwd_blocks(l2, h2)
+            eng.trunk_bwd_end()
+            if self.world > 1:
+                self._allreduce_flat()
+            self._opt(1.0 / self.world)
+            return losses
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _i in range(2):
+                run_all()
+        torch.cuda.current_stream().wait_stream(side)
+        for t, c in zip(keep, snap):
+            t.copy_(c)
+        eng.pack()
+        torch.cuda.synchronize()
+        self.comm_stream = torch.cuda.Stream()
+        self.segments = []
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0):
+            self.losses = self._seg_first(*self.static, plan[0][0], plan[0][1])
+        self.segments.append(g0)
+        pool = g0.pool()
+        for k, (lo, hi, _) in enumerate(plan[1:], start=1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                eng.trunk_bwd_blocks(lo, hi)
+                if k == len(plan) - 1:
+                    eng.trunk_bwd_end()
+            self.segments.append(g)
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=pool):
+            self._opt(1.0 / self.world)
+        self._plan = plan
+        self.graph = g0
+
+    def _replay_segmented(self):
+        import torch.distributed as dist
+        start = 0
+        main = torch.cuda.current_stream()
+        for g, (_, _, end) in zip(self.segments, self._plan):
+            g.replay()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.comm_stream.wait_event(ev)
+            if self.world > 1:
+                with torch.cuda.stream(self.comm_stream):
+                    dist.all_reduce(self.arena.g[start:end])
+            start = end
+        main.wait_stream(self.comm_stream)
+        self.graph_b.replay()
 
     # ---- capture --------------------------------------------------------------------------------------------
     def _capture(self, images, masks, edges):
@@ -116,14 +218,17 @@ class TrainStep:
         if not self.capture:
             return self._eager(images, masks, edges)
         if self.graph is None:
-            self._capture(images, masks, edges)
+            if self.world > 1 or self.force_segmented:
+                self._capture_segmented(images, masks, edges)
+            else:
+                self._capture(images, masks, edges)
         for dst, src in zip(self.static, (images, masks, edges)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
-        self.graph.replay()
-        if self.graph_b is not None:
-            self._allreduce_flat()
-            self.graph_b.replay()
+        if self.segments is not None:
+            self._replay_segmented()
+        else:
+            self.graph.replay()
         return self.losses
 
 

@@ -242,25 +242,39 @@ class Engine:
 
     def trunk_bwd(self, ctx, dfeats: List[Optional[Tensor]]):
         """dfeats: gradients w.r.t. the 4 stage maps (NHWC, compute dtype) or None."""
-        e = "encoder.encoder."
-        B = ctx["B"]
-        dx = None
-        unit = 0
+        self.trunk_bwd_begin(ctx, dfeats)
+        self.trunk_bwd_blocks(0, len(self.blocks))
+        self.trunk_bwd_end()
+
+    # The same backward in three callable pieces, so a caller can capture it as several hipGraph segments and start the
+    # gradient all-reduce of finished ranges between them (engine/trainer.py, multi-GPU graph mode).
+    def trunk_bwd_begin(self, ctx, dfeats: List[Optional[Tensor]]):
+        self._bw = dict(ctx=ctx, dfeats=dfeats, dx=None, stage=len(dfeats) - 1, unit=0)
         if self.unit_cb is not None:
             self.unit_cb(0)   # head gradients are final once trunk backward starts
-        stage = len(dfeats) - 1
-        for b, c in zip(reversed(self.blocks), reversed(ctx["blocks"])):
+
+    def trunk_bwd_blocks(self, lo: int, hi: int):
+        """Back-propagates through blocks hi-1, hi-2, ..., lo (must be called with descending, contiguous ranges)."""
+        st = self._bw
+        ctx, B = st["ctx"], st["ctx"]["B"]
+        for idx in range(hi - 1, lo - 1, -1):
+            b, c = self.blocks[idx], ctx["blocks"][idx]
             if b["stage_end"]:
-                d = dfeats[stage]
-                stage -= 1
+                d = st["dfeats"][st["stage"]]
+                st["stage"] -= 1
                 if d is not None:
-                    dx = d if dx is None else ops.add(dx, d.contiguous())
-            if dx is None:
+                    st["dx"] = d if st["dx"] is None else ops.add(st["dx"], d.contiguous())
+            if st["dx"] is None:
                 raise RuntimeError("trunk_bwd: no gradient reaches the last stage")
-            dx = self.block_bwd(b, c, dx, B)
-            unit += 1
+            st["dx"] = self.block_bwd(b, c, st["dx"], B)
+            st["unit"] += 1
             if self.unit_cb is not None:
-                self.unit_cb(unit)
+                self.unit_cb(st["unit"])
+
+    def trunk_bwd_end(self):
+        e = "encoder.encoder."
+        st = self._bw
+        ctx, dx = st["ctx"], st["dx"]
         D = dx.shape[-1]
         d2 = dx.reshape(-1, D)
         pw = torch.zeros((D, PATCH_KPAD), dtype=torch.float32, device=dx.device)
@@ -271,6 +285,7 @@ class Engine:
         ops.gemm_tn(d2, ctx["basis"], gpos)
         self.grad(e + "pos_embed").view(D, n_b).add_(gpos[:, :n_b])
         self.grad(e + "pos_embed_window").view(D, n_w).add_(gpos[:, n_b:n_b + n_w])
+        self._bw = None
 
     # ================================================================================================ head
     def conv3_fwd(self, name: str, x: Tensor, B, H, W, Ci, bias: bool):
