@@ -81,17 +81,17 @@ __device__ __forceinline__ unsigned x_chunk_off(int m, int k0, int ldx, const Co
 }
 
 // wave tile = 64 (n) x 16*MI (m); the wave's first m row inside the block tile is mrow0
-template <typename T, int MI = 4>
+template <typename T, int MI = 4, int NB = 4>
 __device__ __forceinline__ void mma_tile(const char* __restrict__ Ws, const char* __restrict__ Xs, int wn, int wm,
-                                         int lane, f32x4 (&acc)[4][MI]) {
+                                         int lane, f32x4 (&acc)[NB][MI]) {
   using M_ = Mma<T>;
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int s = 0; s < M_::SUB; ++s) {
-    typename M_::Frag a[4], b[MI];
+    typename M_::Frag a[NB], b[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rowa = wn * 64 + i * 16 + r;
+    for (int i = 0; i < NB; ++i) {
+      const int rowa = wn * (16 * NB) + i * 16 + r;
       a[i] = M_::load(Ws + rowa * ROWB, rowa & 7, s, q);
     }
 #pragma unroll
@@ -100,7 +100,7 @@ __device__ __forceinline__ void mma_tile(const char* __restrict__ Ws, const char
       b[i] = M_::load(Xs + rowb * ROWB, rowb & 7, s, q);
     }
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = M_::mma(a[ni], b[mi], acc[ni][mi]);
   }
@@ -291,7 +291,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // DBG: 0 = product kernel; 1 = skip the DMA issue (times MFMA + LDS reads alone); 2 = skip the MFMAs (times the fill
 // pipeline alone).  1 and 2 produce wrong results by construction and are reachable only through SPG_GEMM_DEBUG.
-template <typename T, bool CONV, int DBG = 0, int WM = 2>
+// NB = 16-row n blocks per wave: block tile width BN_ = 32*NB (128 / 96 / 64), so narrow outputs (N = 64 convolutions, N = 576 trunk
+// projections) do not multiply zero rows or strand CUs on too few tiles.
+template <typename T, bool CONV, int DBG = 0, int WM = 2, int NB = 4>
 __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                                  T* __restrict__ C, NtEpi epi, int M, int N, int K, int ldx,
                                                                  int ldc, ConvGeom g, int tiles_n, int ntiles,
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
   constexpr int NW = 2 * WM;            // waves per workgroup
   constexpr int NP = 16 / NW;           // DMA pieces (1 KiB) per operand per wave per stage
   constexpr int STAGES = WM == 2 ? DMA_STAGES : 3;
+  constexpr int BN_ = 32 * NB;          // tile width in n
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
       is_j = j;
       const int tile = first + j * G;
       const int tn = tile % tiles_n, tm = tile / tiles_n;
-      is_m0 = tm * BM; is_n0 = tn * BN;
+      is_m0 = tm * BM; is_n0 = tn * BN_;
       if constexpr (CONV) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -347,18 +350,19 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
       const bool kin = k0 < K;
       const unsigned xo = x_chunk_off<T, CONV>(is_m0 + row, k0, ldx, g, py[i], px[i]);
       const unsigned wo = (unsigned)(((long)(is_n0 + row) * K + k0) * (long)sizeof(T));
+      const bool win = kin && row < BN_;            // rows >= BN_ of the 128-row W area are never read: zero fill, no traffic
       if constexpr (DBG != 1) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + prow * ROWB), 16, kin ? xo : OOB, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * ROWB + prow * ROWB), 16, kin ? wo : OOB, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * ROWB + prow * ROWB), 16, win ? wo : OOB, 0, 0, 0);
       } else {
         asm volatile("" :: "v"(xo), "v"(wo));
       }
     }
   };
 
-  f32x4 acc[4][MI];
+  f32x4 acc[NB][MI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -392,16 +396,16 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
     __builtin_amdgcn_sched_barrier(0);
     if (gi < total) { issue(gi); ++gi; }
     const char* st = smem + (gc % STAGES) * DMA_STAGE_BYTES;
-    if constexpr (DBG != 2) mma_tile<T, MI>(st + BM * ROWB, st, wn, wm, lane, acc);
+    if constexpr (DBG != 2) mma_tile<T, MI, NB>(st + BM * ROWB, st, wn, wm, lane, acc);
     if (++kt == nkt) {
       // ---- epilogue of tile j (per-wave slab, no block barrier: waves run ahead into the next tile independently)
       const int tile = first + j * G;
       const int tn = tile % tiles_n, tm = tile / tiles_n;
-      const int m0 = tm * BM, n0 = tn * BN;
+      const int m0 = tm * BM, n0 = tn * BN_;
 #pragma unroll
       for (int quarter = 0; quarter < MI; ++quarter) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NB; ++ni) {
           *reinterpret_cast<f32x4*>(slab + r15 * EPS + ni * 16 + q * 4) = acc[ni][quarter];
           acc[ni][quarter] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -411,8 +415,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
         for (int jj = 0; jj < 2; ++jj) {
           const int row = (lane >> 3) + 8 * jj, ch = lane & 7;
           const int m = m0 + wm * (16 * MI) + quarter * 16 + row;
-          const int n = n0 + wn * 64 + ch * 8;
-          if (m < M && n < N) {
+          const int n = n0 + wn * (16 * NB) + ch * 8;
+          if (m < M && n < N && ch * 8 < 16 * NB) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8 + 4);
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -988,16 +992,32 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
       constexpr int LDS8 = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
       static bool attr8 = false;
       if (!attr8) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, true, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+#define SPG_SET_ATTR(C_, NB_) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, C_, 0, 4, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8)
+        SPG_SET_ATTR(true, 4); SPG_SET_ATTR(false, 4); SPG_SET_ATTR(true, 3); SPG_SET_ATTR(false, 3); SPG_SET_ATTR(true, 2); SPG_SET_ATTR(false, 2);
+#undef SPG_SET_ATTR
         attr8 = true;
       }
-      if (conv)
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, true, 0, 4>), dim3(grid), dim3(512), LDS8, s, (const T*)X, (const T*)W,
-                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-      else
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 0, 4>), dim3(grid), dim3(512), LDS8, s, (const T*)X, (const T*)W,
-                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      // tile width: minimise rounds(tiles / CUs) x per-tile cost (MFMA work ~ NB, X fill + fixed cost ~ 1.5)
+      static int force_nb = -1;
+      if (force_nb < 0) { const char* e = getenv("SPG_GEMM_NB"); force_nb = e ? atoi(e) : 0; }
+      int nb = 4;
+      if (force_nb >= 2 && force_nb <= 4) nb = force_nb;
+      else {
+        float best = 1e30f;
+        for (int c = 4; c >= 2; --c) {
+          const long t = (long)cdiv(N, 32 * c) * tiles_m;
+          const float cost = (float)cdiv(t, num_cus()) * ((float)c + 1.5f);
+          if (cost < best * 0.999f) { best = cost; nb = c; }
+        }
+      }
+      const int tn_ = cdiv(N, 32 * nb);
+      const int nwg_ = tn_ * tiles_m;
+      const int grid8 = nwg_ < num_cus() ? nwg_ : num_cus();
+#define SPG_LAUNCH8(C_, NB_) hipLaunchKernelGGL((gemm_nt_dma_kernel<T, C_, 0, 4, NB_>), dim3(grid8), dim3(512), LDS8, s, (const T*)X, (const T*)W, \
+                           (T*)C, epi, M, N, K, ldx, ldc, g, tn_, nwg_, (unsigned)xb, (unsigned)wb)
+      if (conv) { if (nb == 4) SPG_LAUNCH8(true, 4); else if (nb == 3) SPG_LAUNCH8(true, 3); else SPG_LAUNCH8(true, 2); }
+      else { if (nb == 4) SPG_LAUNCH8(false, 4); else if (nb == 3) SPG_LAUNCH8(false, 3); else SPG_LAUNCH8(false, 2); }
+#undef SPG_LAUNCH8
       return check_launch("gemm_nt(dma8)");
     }
     if (conv)
