@@ -44,8 +44,12 @@ const char* spg_last_error(void);
 int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, void* C2, const float* bias,
                 const void* residual, const void* gelu_h, int M, int N, int K, int ldx, int ldc, int act,
                 int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream);
-int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy,
-                int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream);
+int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, void* workspace, long workspace_bytes,
+                int M, int N, int K, int ldy, int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci,
+                spg_stream_t stream);
+/* bytes of caller-owned scratch that lets the M-splits of spg_gemm_tn write partial slabs with plain stores (+ one reduce
+ * launch) instead of f32 atomics; 0 = not split.  workspace may be NULL (atomics are used).                             */
+long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K);
 
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
  * spg_pack_matrix: dst[r][c] = src[r][c] (transpose=0) or dst[c][r] = src[r][c] (transpose=1), src f32 [R,C].

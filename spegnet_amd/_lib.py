@@ -19,7 +19,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 # name -> argument type string (p pointer, i int, l long, f float); every function returns int
 SIGNATURES = {
     "spg_gemm_nt": "ipppppppiiiiiiiiiiip",
-    "spg_gemm_tn": "ippppiiiiiiiiiiip",
+    "spg_gemm_tn": "ipppppliiiiiiiiiiip",
     "spg_pack_matrix": "ippiiip",
     "spg_pack_batch": "ipiip",
     "spg_pack_conv3x3": "ipppiip",
@@ -79,6 +79,8 @@ def load() -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH)
     lib.spg_last_error.restype = ctypes.c_char_p
     lib.spg_version.restype = _I
+    lib.spg_gemm_tn_workspace_bytes.restype = _L
+    lib.spg_gemm_tn_workspace_bytes.argtypes = [_I, _I, _I, _I]
     for table, required in ((SIGNATURES, True), (_OPTIONAL, False)):
         for name, sig in table.items():
             try:

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
       const unsigned xo = x_chunk_off<T, CONV>(is_m0 + row, k0, ldx, g, py[i], px[i]);
       const unsigned wo = (unsigned)(((long)(is_n0 + row) * K + k0) * (long)sizeof(T));
       const bool win = kin && row < BN_;            // rows >= BN_ of the 128-row W area are never read: zero fill, no traffic
-      if constexpr (DBG != 1) {
+      if constexpr (DBG != 1 && DBG != 3 && DBG != 4) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + prow * ROWB), 16, kin ? xo : OOB, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * ROWB + prow * ROWB), 16, win ? wo : OOB, 0, 0, 0);
       } else {
@@ -398,6 +398,17 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
     const char* st = smem + (gc % STAGES) * DMA_STAGE_BYTES;
     if constexpr (DBG != 2) mma_tile<T, MI, NB>(st + BM * ROWB, st, wn, wm, lane, acc);
     if (++kt == nkt) {
+      if constexpr (DBG == 3) {  // ablation: no fill, no epilogue (the never-true store keeps the MFMAs live)
+#pragma unroll
+        for (int quarter = 0; quarter < MI; ++quarter)
+#pragma unroll
+          for (int ni = 0; ni < NB; ++ni) {
+            if (M < 0) *reinterpret_cast<f32x4*>(slab + r15 * EPS + ni * 16 + q * 4) = acc[ni][quarter];
+            acc[ni][quarter] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        kt = 0; ++j;
+        continue;
+      }
       // ---- epilogue of tile j (per-wave slab, no block barrier: waves run ahead into the next tile independently)
       const int tile = first + j * G;
       const int tn = tile % tiles_n, tm = tile / tiles_n;
@@ -452,8 +463,12 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rr[e];
               }
-              if constexpr (sizeof(T) == 2) st16(C + o, pack16<T>(v));
-              else { st16(C + o, pack16<T>(v)); st16(C + o + 4, pack16<T>(v + 4)); }
+              if (DBG != 4 || M < 0) {  // DBG 4: whole epilogue except the output store
+                if constexpr (sizeof(T) == 2) st16(C + o, pack16<T>(v));
+                else { st16(C + o, pack16<T>(v)); st16(C + o + 4, pack16<T>(v + 4)); }
+              } else {
+                asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+              }
             } else {
               for (int e = 0; e < 8 && n + e < N; ++e) {
                 float x = v[e];
@@ -541,7 +556,8 @@ template <typename T, bool CONV, int WK = 2>
 __global__ __launch_bounds__(128 * WK) void gemm_tn_kernel(const T* __restrict__ dY, const T* __restrict__ X,
                                                              float* __restrict__ dW, int M, int N, int K, int ldy,
                                                              int ldx, int ldw, ConvGeom g, int tiles_k, int m_per_split,
-                                                             unsigned ybytes, unsigned xbytes, float* __restrict__ dbias) {
+                                                             unsigned ybytes, unsigned xbytes, float* __restrict__ dbias,
+                                                             float* __restrict__ slabs) {
   constexpr int VEC = ST<T>::VEC;
   constexpr int MSTEP = ROWB / (int)sizeof(T);  // m rows per LDS tile: 64 (bf16) / 32 (f32)
   constexpr int NCH = 128 / VEC;                // feature chunks per tile row: 16 / 32
@@ -662,7 +678,12 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn_kernel(const T* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int n = n0 + wn * 64 + ni * 16 + q * 4 + e;
-        if (n < N) atomicAdd(dW + (long)n * ldw + k, acc[ni][ki][e]);
+        if (n < N) {
+          // split-M partials: plain stores into this split's slab (full store bandwidth; a reduce kernel folds the slabs into
+          // the gradient) instead of f32 atomics (chip-wide ~1.3 TB/s: MI355X_MICROARCH.md "Global float atomics")
+          if (slabs) slabs[((long)split_id * N + n) * K + k] = acc[ni][ki][e];
+          else atomicAdd(dW + (long)n * ldw + k, acc[ni][ki][e]);
+        }
       }
     }
 }
@@ -703,6 +724,22 @@ template <> struct TnFrag<bf16_t> {
     const s16x8_t v = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
     return __builtin_bit_cast(bf16x8_t, v);
   }
+  // loop-invariant per-lane byte offsets of the two transpose reads of a fragment (precomputed once per kernel)
+  __device__ static __forceinline__ void offsets(int s, int col0, int lane, int& o0, int& o1) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const int row0 = 32 * s + 8 * g + q, row1 = row0 + 4;
+    const int c = (col0 >> 3) + (p >> 1);
+    const int within = (p & 1) * 8;
+    o0 = row0 * 256 + ((((c >> 1) ^ tnd_swz(row0)) << 1 | (c & 1)) << 4) + within;
+    o1 = row1 * 256 + ((((c >> 1) ^ tnd_swz(row1)) << 1 | (c & 1)) << 4) + within;
+  }
+  __device__ static __forceinline__ Frag load_at(const char* tile, int o0, int o1) {
+    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + o0));
+    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + o1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
 };
 template <> struct TnFrag<float> {
   static constexpr int SUB = 8;                   // 4-row k-steps per 32-row tile
@@ -711,13 +748,17 @@ template <> struct TnFrag<float> {
     return *reinterpret_cast<const float*>(tile + (4 * s + (lane >> 4)) * 512 + (col0 + (lane & 15)) * 4);
   }
   __device__ static __forceinline__ Frag ones() { return 1.f; }
+  __device__ static __forceinline__ void offsets(int s, int col0, int lane, int& o0, int& o1) {
+    o0 = (4 * s + (lane >> 4)) * 512 + (col0 + (lane & 15)) * 4; o1 = 0;
+  }
+  __device__ static __forceinline__ Frag load_at(const char* tile, int o0, int) { return *reinterpret_cast<const float*>(tile + o0); }
 };
 
 template <typename T, bool CONV>
 __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ dY, const T* __restrict__ X, float* __restrict__ dW,
                                                           int M, int N, int K, int ldy, int ldx, int ldw, ConvGeom g, int tiles_k,
                                                           int tiles, int splits, int m_per_split, unsigned ybytes,
-                                                          unsigned xbytes, float* __restrict__ dbias) {
+                                                          unsigned xbytes, float* __restrict__ dbias, float* __restrict__ slabs) {
   constexpr int VEC = ST<T>::VEC;
   constexpr int RB = 128 * (int)sizeof(T);          // tile row bytes (256 / 512)
   constexpr int RPP = 1024 / RB;                    // rows per 1-KiB DMA piece (4 / 2)
@@ -739,14 +780,21 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
   const __amdgpu_buffer_rsrc_t yr = make_rsrc(dY, ybytes), xr = make_rsrc(X, xbytes);
 
   const int lrow = lane / CPR, lpc = lane % CPR;
-  auto issue = [&](int gs) {
-    const int j = gs / nsteps, st_i = gs - j * nsteps;
+  // issue-stream state: unit geometry is recomputed only when the stream enters a new unit (integer divisions are ~40 VALU ops)
+  int is_step = 0, is_j = 0, is_n0 = 0, is_k0 = 0, is_mbase = 0, is_mend = 0;
+  auto enter_unit = [&](int j, int& n0, int& k0, int& mbase, int& mend) {
     const int u = first + j * G;
     const int tile = u % tiles, split = u / tiles;
     const int tk = tile % tiles_k, tn = tile / tiles_k;
-    const int n0 = tn * 128, k0 = tk * 128;
-    const int m_begin = split * m_per_split + st_i * MSTEP;
-    const int m_end = min(M, (split + 1) * m_per_split);
+    n0 = tn * 128; k0 = tk * 128;
+    mbase = split * m_per_split;
+    mend = min(M, (split + 1) * m_per_split);
+  };
+  enter_unit(0, is_n0, is_k0, is_mbase, is_mend);
+  auto issue = [&](int gs) {
+    const int n0 = is_n0, k0 = is_k0;
+    const int m_begin = is_mbase + is_step * MSTEP;
+    const int m_end = is_mend;
     char* st = smem + (gs % STAGES) * STAGE_B;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {                               // 16 pieces per operand / 8 waves
@@ -775,6 +823,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + 16384 + piece * 1024), 16, xin ? xo : OOB, 0, 0, 0);
     }
+    if (++is_step == nsteps) { is_step = 0; ++is_j; if (is_j < my_units) enter_unit(is_j, is_n0, is_k0, is_mbase, is_mend); }
   };
 
   f32x4 acc[4][2], accb[4];
@@ -785,7 +834,22 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
   int gi = 0;
   for (; gi < STAGES - 1 && gi < total; ++gi) issue(gi);
   const int r15 = lane & 15, q = lane >> 4;
+  // fragment read offsets are lane constants: bf16 keeps all 2 x 6 x 2 of them in registers, f32 (8 k-steps) recomputes
+  constexpr int NS = TnFrag<T>::SUB;
+  constexpr bool PRE = sizeof(T) == 2;
+  int oa[PRE ? NS : 1][4][2], ob[PRE ? NS : 1][2][2];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) TnFrag<T>::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) TnFrag<T>::offsets(s2, wk * 32 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
+    }
+  }
   int st_i = 0, j = 0;
+  int c_n0, c_k0, c_mb, c_me;
+  enter_unit(0, c_n0, c_k0, c_mb, c_me);
   for (int gc = 0; gc < total; ++gc) {
     {
       const int ahead = gi - gc - 1;      // younger DMA groups (4 pieces per wave each)
@@ -796,17 +860,21 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
     __builtin_amdgcn_sched_barrier(0);
     if (gi < total) { issue(gi); ++gi; }
     const char* st = smem + (gc % STAGES) * STAGE_B;
-    const int u = first + j * G;
-    const int tile = u % tiles;
-    const int tk = tile % tiles_k, tn = tile / tiles_k;
-    const bool bias_unit = (dbias != nullptr) && (tk == 0) && (wk == 0);
+    const bool bias_unit = (dbias != nullptr) && (c_k0 == 0) && (wk == 0);
 #pragma unroll
     for (int s = 0; s < TnFrag<T>::SUB; ++s) {
       typename TnFrag<T>::Frag a[4], b[2];
+      if constexpr (PRE) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = TnFrag<T>::load(st, s, wn * 64 + i * 16, lane);
+        for (int i = 0; i < 4; ++i) a[i] = TnFrag<T>::load_at(st, oa[s][i][0], oa[s][i][1]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) b[i] = TnFrag<T>::load(st + 16384, s, wk * 32 + i * 16, lane);
+        for (int i = 0; i < 2; ++i) b[i] = TnFrag<T>::load_at(st + 16384, ob[s][i][0], ob[s][i][1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = TnFrag<T>::load(st, s, wn * 64 + i * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b[i] = TnFrag<T>::load(st + 16384, s, wk * 32 + i * 16, lane);
+      }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         acc[ni][0] = Mma<T>::mma(a[ni], b[0], acc[ni][0]);
@@ -819,7 +887,8 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
       }
     }
     if (++st_i == nsteps) {
-      const int n0 = tn * 128, k0 = tk * 128;
+      const int n0 = c_n0, k0 = c_k0;
+      const int split_id = (first + j * G) / tiles;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
@@ -828,7 +897,10 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int n = n0 + wn * 64 + ni * 16 + q * 4 + e;
-            if (k < K && n < N) atomicAdd(dW + (long)n * ldw + k, acc[ni][ki][e]);
+            if (k < K && n < N) {
+              if (slabs) slabs[((long)split_id * N + n) * K + k] = acc[ni][ki][e];
+              else atomicAdd(dW + (long)n * ldw + k, acc[ni][ki][e]);
+            }
           }
           acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -842,6 +914,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
         accb[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       st_i = 0; ++j;
+      if (j < my_units) enter_unit(j, c_n0, c_k0, c_mb, c_me);
     }
   }
 }
@@ -974,17 +1047,25 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     const int grid = nwg < num_cus() ? nwg : num_cus();
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("SPG_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if (dbg == 1 && !conv) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 1>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
-                         (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-      return check_launch("gemm_nt(dbg1)");
-    }
-    if (dbg == 2 && !conv) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 2>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
-                         (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-      return check_launch("gemm_nt(dbg2)");
+    if ((dbg >= 1 && dbg <= 4) && !conv) {  // ablations of the 8-wave kernel (wrong results by construction)
+      constexpr int LDSD = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 1, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
+      if (dbg == 4) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 4, 4, 4>), dim3(grid), dim3(512), LDSD, s, (const T*)X, (const T*)W,
+                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      } else if (dbg == 3) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 3, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 3, 4, 4>), dim3(grid), dim3(512), LDSD, s, (const T*)X, (const T*)W,
+                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      } else if (dbg == 1)
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 1, 4, 4>), dim3(grid), dim3(512), LDSD, s, (const T*)X, (const T*)W,
+                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      else
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 2, 4, 4>), dim3(grid), dim3(512), LDSD, s, (const T*)X, (const T*)W,
+                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
+      return check_launch("gemm_nt(dbg)");
     }
     static int waves = -1;
     if (waves < 0) { const char* e = getenv("SPG_GEMM_WAVES"); waves = e ? atoi(e) : 8; }
@@ -1038,20 +1119,44 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
   return check_launch("gemm_nt");
 }
 
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int splits, long nk4,
+                                                        int K, int ldw) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nk4; i += (long)gridDim.x * 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(slabs + i * 4);
+    for (int sidx = 1; sidx < splits; ++sidx) a += *reinterpret_cast<const f32x4*>(slabs + ((long)sidx * nk4 + i) * 4);
+    const long e = i * 4;
+    float* d = dW + (e / K) * ldw + (e % K);      // K % 4 == 0, so the 4 elements stay inside one row
+    f32x4 o = *reinterpret_cast<f32x4*>(d);
+    *reinterpret_cast<f32x4*>(d) = o + a;
+  }
+}
+
+template <typename T>
+static void tn_split_plan(int M, int N, int K, int* splits, int* m_per_split) {
+  constexpr int MSTEP = ROWB / (int)sizeof(T);
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  static int target = 0;
+  if (target == 0) { const char* e = getenv("SPG_TN_TARGET"); target = e ? atoi(e) : 384; }
+  int sp = cdiv(target, tiles);  // blocks ~ target
+  const int max_splits = cdiv(M, 4 * MSTEP);
+  if (sp > max_splits) sp = max_splits;
+  if (sp < 1) sp = 1;
+  const int mps = cdiv(cdiv(M, sp), MSTEP) * MSTEP;
+  *m_per_split = mps;
+  *splits = cdiv(M, mps);
+}
+
 template <typename T>
 static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx, int ldw, int conv,
-                     ConvGeom g, hipStream_t s, float* dbias) {
+                     ConvGeom g, hipStream_t s, float* dbias, float* ws, size_t ws_bytes) {
   constexpr int MSTEP = ROWB / (int)sizeof(T);
   const int tiles_n = cdiv(N, 128), tiles_k = cdiv(K, 128);
   const int tiles = tiles_n * tiles_k;
-  static int target = 0;
-  if (target == 0) { const char* e = getenv("SPG_TN_TARGET"); target = e ? atoi(e) : 384; }
-  int splits = cdiv(target, tiles);  // blocks ~ target; every split adds a 64 KB f32 atomic epilogue per tile
   const int max_splits = cdiv(M, 4 * MSTEP);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int m_per_split = cdiv(cdiv(M, splits), MSTEP) * MSTEP;
-  splits = cdiv(M, m_per_split);
+  int splits, m_per_split;
+  tn_split_plan<T>(M, N, K, &splits, &m_per_split);
+  float* slabs = nullptr;
+  if (ws && splits > 1 && ws_bytes >= (size_t)splits * N * K * sizeof(float)) slabs = ws;
   const size_t lds = 4 * 128 * ROWB;
   const long yb = (long)M * ldy * (long)sizeof(T), xb = (conv ? (long)M * g.Ci : (long)M * ldx) * (long)sizeof(T);
   if (xb >= 0xFFFFFFF0L || yb >= 0xFFFFFFF0L) {
@@ -1067,6 +1172,7 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
     if (splits < 1) splits = 1;
     m_per_split = cdiv(cdiv(M, splits), MSTEP) * MSTEP;
     splits = cdiv(M, m_per_split);
+    slabs = (ws && splits > 1 && ws_bytes >= (size_t)splits * N * K * sizeof(float)) ? ws : nullptr;
     const int units = tiles * splits;
     const int grid = units < num_cus() ? units : num_cus();
     constexpr int LDS = 3 * 32768;
@@ -1078,30 +1184,42 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
     }
     if (conv)
       hipLaunchKernelGGL((gemm_tn_dma_kernel<T, true>), dim3(grid), dim3(512), LDS, s, (const T*)dY, (const T*)X, dW, M, N, K, ldy, ldx,
-                         ldw, g, tiles_k, tiles, splits, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
+                         ldw, g, tiles_k, tiles, splits, m_per_split, (unsigned)yb, (unsigned)xb, dbias, slabs);
     else
       hipLaunchKernelGGL((gemm_tn_dma_kernel<T, false>), dim3(grid), dim3(512), LDS, s, (const T*)dY, (const T*)X, dW, M, N, K, ldy, ldx,
-                         ldw, g, tiles_k, tiles, splits, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
-    return check_launch("gemm_tn(dma)");
+                         ldw, g, tiles_k, tiles, splits, m_per_split, (unsigned)yb, (unsigned)xb, dbias, slabs);
+    int rc = check_launch("gemm_tn(dma)");
+    if (rc || !slabs) return rc;
+    const long nk4 = (long)N * K / 4;
+    long gr = (nk4 + 255) / 256;
+    if (gr > 2048) gr = 2048;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, slabs, dW, splits, nk4, K, ldw);
+    return check_launch("gemm_tn(dma reduce)");
   }
   static int waves = -1;
   if (waves < 0) { const char* e = getenv("SPG_TN_WAVES"); waves = e ? atoi(e) : 4; }
   if (waves == 8) {
     if (conv)
       hipLaunchKernelGGL((gemm_tn_kernel<T, true, 4>), dim3(tiles, splits), dim3(512), lds, s, (const T*)dY,
-                         (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
+                         (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias, nullptr);
     else
       hipLaunchKernelGGL((gemm_tn_kernel<T, false, 4>), dim3(tiles, splits), dim3(512), lds, s, (const T*)dY,
-                         (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
+                         (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias, nullptr);
     return check_launch("gemm_tn(8w)");
   }
   if (conv)
     hipLaunchKernelGGL((gemm_tn_kernel<T, true>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
-                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
+                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias, slabs);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<T, false>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
-                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias);
-  return check_launch("gemm_tn");
+                       (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias, slabs);
+  int rc = check_launch("gemm_tn");
+  if (rc || !slabs) return rc;
+  const long nk4 = (long)N * K / 4;
+  long gr = (nk4 + 255) / 256;
+  if (gr > 2048) gr = 2048;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, slabs, dW, splits, nk4, K, ldw);
+  return check_launch("gemm_tn(reduce)");
 }
 
 }  // namespace spg
@@ -1128,8 +1246,19 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
                            : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s);
 }
 
-extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy,
-                           int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream) {
+extern "C" long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {
+  int splits, mps;
+  if (dtype == SPG_BF16) tn_split_plan<bf16_t>(M, N, K, &splits, &mps);
+  else tn_split_plan<float>(M, N, K, &splits, &mps);
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  int alt = num_cus() / tiles;                       // the persistent (dma) variant's plan
+  if (alt > splits) splits = alt;
+  return splits > 1 ? (long)(splits + 1) * N * K * (long)sizeof(float) : 0;
+}
+
+extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, void* workspace, long workspace_bytes,
+                           int M, int N, int K, int ldy, int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci,
+                           spg_stream_t stream) {
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "gemm_tn: bad dtype %d", dtype);
   SPG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem");
@@ -1141,8 +1270,8 @@ extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, 
     SPG_REQUIRE(ldx % vec == 0 && ldx >= K, "gemm_tn: bad ldx=%d", ldx);
   }
   hipStream_t s = (hipStream_t)stream;
-  return dtype == SPG_BF16 ? launch_tn<bf16_t>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias)
-                           : launch_tn<float>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias);
+  return dtype == SPG_BF16 ? launch_tn<bf16_t>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias, (float*)workspace, (size_t)workspace_bytes)
+                           : launch_tn<float>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias, (float*)workspace, (size_t)workspace_bytes);
 }
 
 extern "C" int spg_pack_matrix(int dtype, const float* src, void* dst, int R, int C, int transpose, spg_stream_t stream) {

@@ -171,8 +171,12 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ pr
   const long HW = (long)S * S;
   const int sy = S / h, sx = S / w;
   const float g0 = go ? go[0] : 1.f;
-  const int lane = threadIdx.x & 63;
-  const long wave0 = (blockIdx.x * 256L + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * 256) >> 6;
+  // identity scale (prediction already at the target resolution): one THREAD per pixel; otherwise one wave per pixel
+  const bool ident = (h == S && w == S);
+  const int lane = ident ? 0 : (threadIdx.x & 63);
+  const int lstep = ident ? 1 : 64;
+  const long wave0 = ident ? (blockIdx.x * 256L + threadIdx.x) : ((blockIdx.x * 256L + threadIdx.x) >> 6);
+  const long nwaves = ident ? ((long)gridDim.x * 256) : (((long)gridDim.x * 256) >> 6);
   for (long i = wave0; i < total; i += nwaves) {
     const int xl = (int)(i % w);
     const int yl = (int)((i / w) % h);
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ pr
     const int X0 = max(0, (xl - 1) * sx), X1 = min(S - 1, (xl + 2) * sx);
     const int nx = X1 - X0 + 1, ncand = (Y1 - Y0 + 1) * nx;
     float acc = 0.f;
-    for (int c = lane; c < ncand; c += 64) {
+    for (int c = lane; c < ncand; c += lstep) {
       const int Y = Y0 + c / nx, X = X0 + c % nx;
       float wy, wx;
       if (h == S) wy = (Y == yl) ? 1.f : 0.f;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ pr
       }
       acc += wgt * g;
     }
-    acc = wave_sum(acc);
+    if (!ident) acc = wave_sum(acc);
     if (lane == 0) ST<T>::st(dpred + i, acc * coef * g0);
   }
 }
@@ -268,8 +272,8 @@ extern "C" int spg_loss_grad(int dtype, const void* pred, const float* target, c
                              const float* sums, const float* grad_out, void* dpred, int B, int S, int h, int w, int edge, float coef,
                              float bce_w, float iou_w, float alpha, float gamma, spg_stream_t stream) {
   SPG_REQUIRE(S % h == 0 && S % w == 0, "loss_grad: target size must be a multiple of the prediction size");
-  const long total = (long)B * h * w;   // one wave per low-res pixel
-  long g = (total + 3) / 4;
+  const long total = (long)B * h * w;   // one wave per low-res pixel (one thread when h == S)
+  long g = (h == S && w == S) ? (total + 255) / 256 : (total + 3) / 4;
   if (g > 8192) g = 8192;
   hipStream_t s = (hipStream_t)stream;
   if (edge) {

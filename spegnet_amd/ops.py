@@ -93,8 +93,10 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
         assert B * H * W == M and x.numel() == M * Ci
         ldx = Ci
     assert dw.dtype == torch.float32 and dw.numel() == N * K, (dw.shape, N, K)
-    _lib.call("spg_gemm_tn", dcode(x), _p(_c(dy)), _p(_c(x)), _p(_c(dw)), _p(dbias), M, N, K, N, ldx, K, 1 if conv else 0, B, H, W,
-              Ci, _stream())
+    wsb = _lib.load().spg_gemm_tn_workspace_bytes(dcode(x), M, N, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
+    _lib.call("spg_gemm_tn", dcode(x), _p(_c(dy)), _p(_c(x)), _p(_c(dw)), _p(dbias), _p(ws), wsb, M, N, K, N, ldx, K,
+              1 if conv else 0, B, H, W, Ci, _stream())
 
 
 def pack_matrix(src: Tensor, dtype: torch.dtype, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:

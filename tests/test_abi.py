@@ -12,7 +12,7 @@ def parse_header():
     src = open(os.path.join(ROOT, "include", "spegnet_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\bint\s+(spg_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long)\s+(spg_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         name, args = m.group(1), m.group(2).strip()
         sig = ""
         if args != "void":
@@ -50,7 +50,7 @@ def test_ctypes_signatures_match_header():
     table = dict(_lib.SIGNATURES)
     table.update(_lib._OPTIONAL)
     for name, sig in decls.items():
-        if name in ("spg_version",):
+        if name in ("spg_version", "spg_gemm_tn_workspace_bytes"):
             continue
         assert name in table, f"{name} has no ctypes signature"
         assert table[name] == sig, f"{name}: ctypes {table[name]} != header {sig}"
