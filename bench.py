@@ -163,7 +163,7 @@ def main():
             fl, sec, n = tot[want]
             ach = fl / sec / 1e12
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-            roof = {"bound": "mfma", "kernel": "gemm_nt_dma_kernel<%s,dense,8 waves>" % args.dtype, "achieved": round(ach, 2), "peak": peak,
+            roof = {"bound": "mfma", "kernel": "gemm_nt_pipe_kernel<%s,dense> (all gemm_nt launches)" % args.dtype, "achieved": round(ach, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": n,
                     "avg_launch_us": round(sec / n * 1e6, 2), "flop_per_launch_avg": fl / n,
                     "other": {f"{k[0]}": {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "launches": v[2], "avg_us": round(v[1] / v[2] * 1e6, 2)}

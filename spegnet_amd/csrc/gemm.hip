@@ -14,6 +14,7 @@
 // MFMA operand roles: "A" = weight rows (n), "B" = activation rows (m)  =>  D[n][m]: a lane holds 4
 // consecutive n for one m, so the epilogue reads bias / writes C as 8- or 16-byte vectors.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace spg {
@@ -81,11 +82,37 @@ __device__ __forceinline__ unsigned x_chunk_off(int m, int k0, int ldx, const Co
 }
 
 // wave tile = 64 (n) x 16*MI (m); the wave's first m row inside the block tile is mrow0
-template <typename T, int MI = 4, int NB = 4>
+template <typename T, int MI = 4, int NB = 4, bool PREFETCH = false>
 __device__ __forceinline__ void mma_tile(const char* __restrict__ Ws, const char* __restrict__ Xs, int wn, int wm,
                                          int lane, f32x4 (&acc)[NB][MI]) {
   using M_ = Mma<T>;
   const int r = lane & 15, q = lane >> 4;
+  if constexpr (sizeof(T) == 2 && PREFETCH) {
+    // every fragment of the step is requested before the first MFMA: one exposed LDS latency per step instead of one per
+    // operand group (the reads return in order, so the MFMAs start as soon as the first k-half has arrived)
+    typename M_::Frag a[2][NB], b[2][MI];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int rowb = wm * (16 * MI) + i * 16 + r;
+        b[s][i] = M_::load(Xs + rowb * ROWB, rowb & 7, s, q);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int rowa = wn * (16 * NB) + i * 16 + r;
+        a[s][i] = M_::load(Ws + rowa * ROWB, rowa & 7, s, q);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = M_::mma(a[s][ni], b[s][mi], acc[ni][mi]);
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < M_::SUB; ++s) {
     typename M_::Frag a[NB], b[MI];
@@ -396,7 +423,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
     __builtin_amdgcn_sched_barrier(0);
     if (gi < total) { issue(gi); ++gi; }
     const char* st = smem + (gc % STAGES) * DMA_STAGE_BYTES;
-    if constexpr (DBG != 2) mma_tile<T, MI, NB>(st + BM * ROWB, st, wn, wm, lane, acc);
+    if constexpr (DBG != 2) mma_tile<T, MI, NB, (WM == 4)>(st + BM * ROWB, st, wn, wm, lane, acc);
     if (++kt == nkt) {
       if constexpr (DBG == 3) {  // ablation: no fill, no epilogue (the never-true store keeps the MFMAs live)
 #pragma unroll
@@ -492,6 +519,426 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_nt_pipe_kernel: the default bf16 NT kernel.  8 waves (4 m x 2 n, wave tile 32 m x 16*NB n), persistent over tiles,
+// LDS-DMA fill 2 steps ahead into a 4-stage ring.  What it adds over the plain DMA kernel above:
+//   * fragments are double-buffered in registers: step k+1's ds_reads are issued in the shadows of step k's MFMAs;
+//   * the step body is ONE basic block whose order is pinned group by group (an MFMA, then in its shadow a fragment read and a slice
+//     of the DMA issue): both waves of a SIMD are phase-locked by the per-step barrier, so whatever is not inside an MFMA shadow
+//     leaves the matrix pipe idle (measured: 0.54 -> 0.45 us per step with the fill and epilogue switched off);
+//   * the epilogue is branch-free: activation mode is a template parameter; bias, residual, gelu_h and both outputs go through
+//     bounds-checked buffer descriptors (zero-sized when the operand is absent: loads return 0, stores are dropped), and its operand
+//     loads are issued at the top of the tile's last step, ahead of that step's DMA pieces, so the in-order vmcnt never makes them
+//     wait for a fresh fill.
+// (A deferred variant that parked the finished accumulators and drained them inside the next tile's MFMA shadows was measured and
+// dropped: its steps ran 1.8-2.4x a plain step -- VGPR spills at NB = 4 and operand waits queued behind the previous DMA group.)
+// LDS: 4 x 32 KiB stages + 8 x 4 KiB swizzled slabs = 160 KiB (one workgroup per CU).
+// vmcnt bookkeeping: VMEM ops retire in order, so the wait for stage k+1 may leave outstanding exactly the younger ops: the
+// 4 pieces of group k+2 plus the epilogue stores of the last two steps (every store instruction executes: lanes are masked by
+// out-of-range offsets, not by EXEC).
+// ------------------------------------------------------------------------------------------------
+constexpr int PIPE_STAGES = 4;
+constexpr int PIPE_SLAB_BYTES = 16 * 64 * 4;
+constexpr int PIPE_LDS_BYTES = PIPE_STAGES * DMA_STAGE_BYTES + 8 * PIPE_SLAB_BYTES;
+enum { PIPE_ACT_NONE = 0, PIPE_ACT_GELU = 1, PIPE_ACT_HH = 2 };   // none | C2 = preact, C = gelu(.) | C = (.) * gelu'(gelu_h)
+
+__device__ __forceinline__ void wait_vm(int n) {  // s_waitcnt vmcnt(<= n), n wave-uniform, n >= 8
+  if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+__device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const u32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(bufvec_t{v.x, v.y, v.z, v.w}, r, byte_off, 0, 0);
+}
+
+template <typename T, int NB> struct NtFrags {
+  typename Mma<T>::Frag a[Mma<T>::SUB][NB], b[Mma<T>::SUB][2];
+};
+template <typename T, int NB>
+__device__ __forceinline__ void load_frags(const char* __restrict__ st, int wn, int wm, int lane, NtFrags<T, NB>& f) {
+  using M_ = Mma<T>;
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < M_::SUB; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rowb = wm * 32 + i * 16 + r;
+      f.b[s][i] = M_::load(st + rowb * ROWB, rowb & 7, s, q);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int rowa = wn * (16 * NB) + i * 16 + r;
+      f.a[s][i] = M_::load(st + BM * ROWB + rowa * ROWB, rowa & 7, s, q);
+    }
+  }
+}
+
+struct PipeEpi {   // byte sizes of the optional epilogue operands (0 = absent)
+  unsigned c_bytes, c2_bytes, r_bytes, h_bytes, bias_bytes;
+};
+
+template <typename T, bool CONV, int ACT, int NB, bool DEFER = false, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ C,
+                                                            NtEpi epi, PipeEpi pe, int M, int N, int K, int ldx, int ldc,
+                                                            ConvGeom g, int tiles_n, int ntiles, unsigned xbytes, unsigned wbytes) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  using M_ = Mma<T>;
+  constexpr int VEC = ST<T>::VEC;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int NP = 2;                  // DMA pieces (1 KiB) per operand per wave per stage
+  // DEFER parks finished tiles in LDS (8 KiB per wave), paid for with one fill stage: 3 x 32 + 8 x 8 = 160 KiB as well
+  constexpr int STAGES = DEFER ? PIPE_STAGES - 1 : PIPE_STAGES;
+  constexpr int SLAB_BYTES = DEFER ? 2 * PIPE_SLAB_BYTES : PIPE_SLAB_BYTES;
+  constexpr int BN_ = 32 * NB;
+  constexpr bool NO_DMA = DBG == 1 || DBG == 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int nkt = (K + BK - 1) / BK;
+  const int G = (int)gridDim.x;
+  const int first = xcd_remap(blockIdx.x, G);
+  if (first >= ntiles) return;
+  const int my_tiles = (ntiles - first + G - 1) / G;
+  const int total = my_tiles * nkt;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, xbytes), wr = make_rsrc(W, wbytes);
+  const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, pe.c_bytes), c2r = make_rsrc(epi.C2, pe.c2_bytes);
+  const __amdgpu_buffer_rsrc_t rr = make_rsrc(epi.residual, pe.r_bytes), hr = make_rsrc(epi.gelu_h, pe.h_bytes);
+  const __amdgpu_buffer_rsrc_t br = make_rsrc(epi.bias, pe.bias_bytes);
+
+  // ---- DMA issue stream (2 steps ahead of the fragment reads, 3 ahead of the MFMAs)
+  const int lrow = lane >> 3, lp = lane & 7;
+  int is_kt = 0, is_tile = first, is_m0, is_n0, is_slot = 0;
+  bool is_live = true;     // false once the stream has run past this workgroup's last tile: pieces become OOB no-ops
+  int py[NP], px[NP];
+  auto enter_tile = [&]() __attribute__((always_inline)) {
+    const int tn = is_tile % tiles_n, tm = is_tile / tiles_n;
+    is_m0 = tm * BM; is_n0 = tn * BN_;
+    if constexpr (CONV) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int m = is_m0 + 64 * i + wave * 8 + lrow;
+        const int hw = g.H * g.W;
+        const int b = m / hw, rem = m - b * hw;
+        py[i] = rem / g.W; px[i] = rem - py[i] * g.W;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) { py[i] = 0; px[i] = 0; }
+    }
+  };
+  enter_tile();
+  // branch-free: every step issues exactly 2*NP pieces (a fixed vmcnt cost the waits rely on), split in address / go halves so
+  // the step body can drop each half into a different MFMA shadow
+  unsigned dxo[NP], dwo[NP];
+  auto dma_addr = [&](int i) __attribute__((always_inline)) {
+    const int row = 64 * i + wave * 8 + lrow;
+    const int k0 = is_kt * BK + ((lp ^ (row & 7)) * VEC);
+    const bool kin = is_live && k0 < K;
+    const unsigned xo = x_chunk_off<T, CONV>(is_m0 + row, k0, ldx, g, py[i], px[i]);
+    const unsigned wo = (unsigned)(((long)(is_n0 + row) * K + k0) * (long)sizeof(T));
+    dxo[i] = kin ? xo : OOB;
+    dwo[i] = (kin && row < BN_) ? wo : OOB;
+  };
+  auto dma_go = [&](int i, int which) __attribute__((always_inline)) {
+    char* st = smem + is_slot * DMA_STAGE_BYTES;
+    const int prow = 64 * i + wave * 8;
+    if constexpr (!NO_DMA) {
+      if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + prow * ROWB), 16, dxo[i], 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * ROWB + prow * ROWB), 16, dwo[i], 0, 0, 0);
+    } else {
+      asm volatile("" :: "v"(dxo[i]), "v"(dwo[i]));
+    }
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+    if (++is_kt == nkt) {
+      is_kt = 0; is_tile += G;
+      if (is_tile < ntiles) enter_tile(); else is_live = false;
+    }
+  };
+
+  f32x4 acc[NB][2];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float* slab = reinterpret_cast<float*>(smem + STAGES * DMA_STAGE_BYTES + wave * SLAB_BYTES);
+  const int r15 = lane & 15, q = lane >> 4;
+  const int erow = lane >> 3, ech = lane & 7;    // epilogue role: row within an 8-row half, 8-column group
+  const bool ch_in = ech * 8 < 16 * NB;
+
+  // ---- epilogue of the tile that ends with the current step: branch-free (absent operands have zero-sized descriptors, lanes are
+  // masked by out-of-range offsets).  Its operand loads are issued at the top of the tile's last step, ahead of that step's DMA
+  // pieces, so waiting for them never waits for a fresh fill.
+  int tile = first, pm0 = 0, pn0 = 0;
+  unsigned eo[2][2];              // [m block][row half]: byte offset of this lane's 8 outputs (OOB = masked)
+  u32x4 er[2][2], eh[2][2];       // residual / gelu_h operands
+  f32x4 eb0, eb1;                 // bias
+  auto epi_request = [&]() __attribute__((always_inline)) {
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    pm0 = tm * BM; pn0 = tn * BN_;
+    const int n = pn0 + wn * (16 * NB) + ech * 8;
+    const bool nin = ch_in && n < N;           // N % 8 == 0 here: n < N <=> all 8 columns inside
+    const unsigned nb_ = ch_in ? (unsigned)(n * 4) : OOB;
+    const bufvec_t b0 = __builtin_amdgcn_raw_buffer_load_b128(br, nb_, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(br, nb_ + 16, 0, 0);
+    eb0 = f32x4{__uint_as_float(b0[0]), __uint_as_float(b0[1]), __uint_as_float(b0[2]), __uint_as_float(b0[3])};
+    eb1 = f32x4{__uint_as_float(b1[0]), __uint_as_float(b1[1]), __uint_as_float(b1[2]), __uint_as_float(b1[3])};
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int m = pm0 + wm * 32 + qt * 16 + erow + 8 * jj;
+        eo[qt][jj] = (nin && m < M) ? (unsigned)(((long)m * ldc + n) * 2) : OOB;
+        er[qt][jj] = bload16(rr, eo[qt][jj]);
+        if constexpr (ACT == PIPE_ACT_HH) eh[qt][jj] = bload16(hr, eo[qt][jj]);
+      }
+  };
+  auto epi_run = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      // transpose 16 rows through the wave's slab (LDS executes one wave's operations in order: no wait between write and read)
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) {
+        *reinterpret_cast<f32x4*>(slab + r15 * 64 + (((ni * 4 + q) ^ r15) << 2)) = acc[ni][qt];
+        acc[ni][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      f32x4 ea[2][2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int row = erow + 8 * jj;
+        ea[jj][0] = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * ech) ^ row) << 2));
+        ea[jj][1] = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * ech + 1) ^ row) << 2));
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        float ev[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ev[e] = ea[jj][0][e] + eb0[e]; ev[4 + e] = ea[jj][1][e] + eb1[e]; }
+        if constexpr (ACT == PIPE_ACT_GELU) {
+          if constexpr (DBG != 4) bstore16(c2r, eo[qt][jj], pack16<T>(ev));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ev[e] = gelu_f(ev[e]);
+        }
+        if constexpr (ACT == PIPE_ACT_HH) {
+          float h[8];
+          unpack16<T>(eh[qt][jj], h);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ev[e] *= gelu_grad_f(h[e]);
+        }
+        float rres[8];
+        unpack16<T>(er[qt][jj], rres);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ev[e] += rres[e];
+        if constexpr (DBG != 4) bstore16(cr, eo[qt][jj], pack16<T>(ev));
+        else asm volatile("" :: "v"(ev[0]), "v"(ev[1]), "v"(ev[2]), "v"(ev[3]), "v"(ev[4]), "v"(ev[5]), "v"(ev[6]), "v"(ev[7]));
+      }
+    }
+  };
+  // DEFER: the same epilogue cut into pieces that ride in the MFMA shadows of the NEXT tile's first two steps (16 rows each).  The
+  // pieces contain no VMEM loads (the operands were requested a tile ago), so nothing in them waits on the fill pipeline.
+  f32x4 ca[2];
+  float cv[8];
+  auto chunk_piece = [&](auto QT_, int pc) __attribute__((always_inline)) {
+    constexpr int qt = decltype(QT_)::value;
+    if (pc == 2 || pc == 6) {          // read back one row half of the parked tile
+      const int row = erow + 8 * (pc == 6);
+      ca[0] = *reinterpret_cast<const f32x4*>(slab + (qt * 16 + row) * 64 + (((2 * ech) ^ row) << 2));
+      ca[1] = *reinterpret_cast<const f32x4*>(slab + (qt * 16 + row) * 64 + (((2 * ech + 1) ^ row) << 2));
+    } else if (pc == 3 || pc == 7) {
+      const int jj = pc == 7;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cv[e] = ca[0][e] + eb0[e]; cv[4 + e] = ca[1][e] + eb1[e]; }
+      if constexpr (ACT == PIPE_ACT_GELU) {
+        bstore16(c2r, eo[qt][jj], pack16<T>(cv));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv[e] = gelu_f(cv[e]);
+      }
+      if constexpr (ACT == PIPE_ACT_HH) {
+        float h[8];
+        unpack16<T>(eh[qt][jj], h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv[e] *= gelu_grad_f(h[e]);
+      }
+    } else if (pc == 4 || pc == 8) {
+      const int jj = pc == 8;
+      if constexpr (ACT == PIPE_ACT_GELU) {
+#pragma unroll
+        for (int e = 4; e < 8; ++e) cv[e] = gelu_f(cv[e]);
+      }
+      if constexpr (ACT == PIPE_ACT_HH) {
+        float h[8];
+        unpack16<T>(eh[qt][jj], h);
+#pragma unroll
+        for (int e = 4; e < 8; ++e) cv[e] *= gelu_grad_f(h[e]);
+      }
+    } else if (pc == 5 || pc == 9) {
+      const int jj = pc == 9;
+      float rres[8];
+      unpack16<T>(er[qt][jj], rres);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cv[e] += rres[e];
+      bstore16(cr, eo[qt][jj], pack16<T>(cv));
+    }
+  };
+  constexpr int stores_per_chunk = (ACT == PIPE_ACT_GELU ? 4 : 2);
+  constexpr int stores_per_tile = (ACT == PIPE_ACT_GELU ? 8 : 4);
+
+  // ---- prologue: 4 groups in flight, stage 0 landed, its fragments requested.  Because a stage's fragments sit in registers one
+  // step before they are multiplied, its LDS slot is free again at the top of that step: group k+4 goes into stage k's slot, i.e.
+  // three groups (96 KiB per CU) stay in flight behind the one being read.
+  for (int i = 0; i < STAGES; ++i) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { dma_addr(j); dma_go(j, 0); dma_go(j, 1); }
+    issue_advance();
+  }
+  if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  NtFrags<T, NB> fa, fb;
+  load_frags<T, NB>(smem, wn, wm, lane, fa);
+
+  int kt = 0, rd_slot = 1;   // rd_slot: the stage whose fragments the current step reads ahead
+  int pend = 0;              // DEFER: chunks of the parked tile still to drain (2 -> rows 0..15 next, 1 -> rows 16..31)
+  int st1 = 0, st2 = 0;      // epilogue stores issued during the previous step and the one before
+  // the pinned block: MFMA i, then in its shadow fragment read i of the next step and a slice of the DMA issue (addresses after
+  // MFMAs 0 and 3, the four pieces after MFMAs 1, 2, 4, 5); on a tile's last step the epilogue operand requests ride in shadow 0
+  auto mma_block = [&](NtFrags<T, NB>& cur, NtFrags<T, NB>& nxt, auto MODE_) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(MODE_)::value;   // 0 plain step, 1 a tile's last step, 2 / 3 first / second step after a parked tile
+    constexpr bool LAST = MODE == 1;
+    constexpr int dma_mode = DBG == 8 ? 1 : (DBG == 9 ? 2 : 0);   // experiment: 1 = burst before the block, 2 = late in the block
+    if constexpr (dma_mode == 1) {
+      if constexpr (LAST) epi_request();
+#pragma unroll
+      for (int j = 0; j < NP; ++j) { dma_addr(j); dma_go(j, 0); dma_go(j, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int NM = 2 * NB * 2, NR = 2 * (NB + 2);
+    const char* rst = smem + rd_slot * DMA_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      if constexpr (DBG != 2) {
+        const int ms = i / (NB * 2), mr = i % (NB * 2), ni = mr >> 1, mi = mr & 1;
+        acc[ni][mi] = M_::mma(cur.a[ms][ni], cur.b[ms][mi], acc[ni][mi]);
+      }
+      if constexpr (LAST && DBG != 3 && dma_mode != 1) {
+        if (i == 0) epi_request();
+      }
+      if (i < NR) {
+        const int rs = i / (NB + 2), rr_ = i % (NB + 2);
+        if (rr_ < 2) {
+          const int rowb = wm * 32 + rr_ * 16 + r15;
+          nxt.b[rs][rr_] = M_::load(rst + rowb * ROWB, rowb & 7, rs, q);
+        } else {
+          const int rowa = wn * (16 * NB) + (rr_ - 2) * 16 + r15;
+          nxt.a[rs][rr_ - 2] = M_::load(rst + BM * ROWB + rowa * ROWB, rowa & 7, rs, q);
+        }
+      }
+      if (dma_mode == 0) {
+        if (i == 0) dma_addr(0);
+        if (i == 1) dma_go(0, 0);
+        if (i == 2) dma_go(0, 1);
+        if (i == 3) dma_addr(1);
+        if (i == 4) dma_go(1, 0);
+        if (i == 5) dma_go(1, 1);
+      } else if (dma_mode == 2) {   // late: behind the fragment reads
+        if (i == NM - 6) dma_addr(0);
+        if (i == NM - 5) dma_go(0, 0);
+        if (i == NM - 4) dma_go(0, 1);
+        if (i == NM - 3) dma_addr(1);
+        if (i == NM - 2) dma_go(1, 0);
+        if (i == NM - 1) dma_go(1, 1);
+      }
+      if constexpr (DEFER && MODE >= 2) {   // 10 chunk pieces spread over the block
+#pragma unroll
+        for (int pc = 0; pc < 10; ++pc)
+          if (pc * NM / 10 == i) chunk_piece(std::integral_constant<int, MODE - 2>{}, pc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto step = [&](NtFrags<T, NB>& cur, NtFrags<T, NB>& nxt) __attribute__((always_inline)) {
+    // stage gc+1 has landed (this wave's pieces): younger than it are groups gc+2 and gc+3 (8 ops) and the last two steps' epilogue
+    // stores (STAGES - 2 groups in general).  lgkmcnt(0): this wave's reads of stage gc (issued during the previous step) have returned, so after the barrier
+    // nobody still reads the slot that group gc+4 is about to overwrite.
+    if constexpr (STAGES == 4) {
+      if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else { wait_vm(8 + st1 + st2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    } else {   // 3 stages: one group (gc+2) younger than the awaited one
+      if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if (st1 + st2 >= 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                       // ... and everyone's
+    __builtin_amdgcn_sched_barrier(0);
+    st2 = st1; st1 = 0;
+    // (the counters are updated by value selects after the branch: symmetric "+=" in both arms gets merged into one store through a
+    // selected pointer, which pins both variables in scratch memory and puts a vmcnt(0) reload at the top of every step)
+    const bool last = __builtin_amdgcn_readfirstlane(kt + 1) == nkt;
+    int ran_chunk = 0;
+    if (DEFER && pend == 2) { mma_block(cur, nxt, std::integral_constant<int, 2>{}); ran_chunk = 1; }
+    else if (DEFER && pend == 1) { mma_block(cur, nxt, std::integral_constant<int, 3>{}); ran_chunk = 1; }
+    else if (last) {
+      mma_block(cur, nxt, std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DBG == 3) {
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            if (M < 0) *reinterpret_cast<f32x4*>(slab + r15 * 64 + ni * 4) = acc[ni][mi];
+            acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      } else if constexpr (DEFER) {   // park in the wave's slab, transposed on the way (tiles have >= 3 steps here: the two chunk
+                                      // steps never coincide with a last step, and the slab is long drained before the next park)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            *reinterpret_cast<f32x4*>(slab + (mi * 16 + r15) * 64 + (((ni * 4 + q) ^ r15) << 2)) = acc[ni][mi];
+            acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      } else {
+        epi_run();
+        st1 = stores_per_tile;
+      }
+    } else {
+      mma_block(cur, nxt, std::integral_constant<int, 0>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DEFER) {
+      st1 = ran_chunk ? stores_per_chunk : st1;
+      pend = ran_chunk ? pend - 1 : (last && DBG != 3 ? 2 : pend);
+    }
+    kt = last ? 0 : kt + 1;
+    tile = last ? tile + G : tile;
+    issue_advance();
+    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
+  };
+  for (int gc = 0; gc < total; gc += 2) {
+    step(fa, fb);
+    if (gc + 1 < total) step(fb, fa);
+  }
+  if constexpr (DEFER) {   // the last tile's parked accumulators
+    if (pend == 2) {
+#pragma unroll
+      for (int pc = 0; pc < 10; ++pc) chunk_piece(std::integral_constant<int, 0>{}, pc);
+      pend = 1;
+    }
+    if (pend == 1) {
+#pragma unroll
+      for (int pc = 0; pc < 10; ++pc) chunk_piece(std::integral_constant<int, 1>{}, pc);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing no-op pieces
+}
+
 // TN: dW[n][k] += sum_m dY[m][n] * X[m][k].  LDS rows are output features (n for the dY operand, k for the
 // X operand), 128 bytes of consecutive m per row; register transpose of 4(m) x 16-byte patches.
 // swizzle for these images: sw(f) = (f ^ (f >> 4)) & 7 -> fragment reads conflict free, patch writes 2-way.
@@ -1047,7 +1494,7 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     const int grid = nwg < num_cus() ? nwg : num_cus();
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("SPG_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if ((dbg >= 1 && dbg <= 4) && !conv) {  // ablations of the 8-wave kernel (wrong results by construction)
+    if ((dbg >= 1 && dbg <= 4) && !conv && getenv("SPG_GEMM_PIPE") && atoi(getenv("SPG_GEMM_PIPE")) == 0) {  // ablations of the plain 8-wave DMA kernel
       constexpr int LDSD = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
       hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 1, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
       hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
@@ -1069,6 +1516,74 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     }
     static int waves = -1;
     if (waves < 0) { const char* e = getenv("SPG_GEMM_WAVES"); waves = e ? atoi(e) : 8; }
+    static int pipe = -1;
+    if (pipe < 0) { const char* e = getenv("SPG_GEMM_PIPE"); pipe = e ? atoi(e) : 1; }
+    if constexpr (sizeof(T) == 2) {
+      // pipelined kernel: bf16, >= 2 K steps per tile, 8-element-aligned rows, operands addressable by 32-bit offsets, and an
+      // epilogue it has an instance for (ReLU, or GELU together with gelu_h, go to the plain DMA kernel below)
+      const long cb = ((long)(M - 1) * ldc + N) * 2;
+      const int pact = epi.gelu_h ? PIPE_ACT_HH : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : PIPE_ACT_NONE);
+      const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE) && (epi.C2 == nullptr || pact == PIPE_ACT_GELU) &&
+                          !(conv && pact != PIPE_ACT_NONE);
+      if (waves == 8 && pipe && K > ROWB / (int)sizeof(T) && N % 8 == 0 && ldc % 8 == 0 && cb < 0xFFFFFFF0L && epi_ok) {
+        static int force_nb = -1;
+        if (force_nb < 0) { const char* e = getenv("SPG_GEMM_NB"); force_nb = e ? atoi(e) : 0; }
+        int nb = 4;
+        if (force_nb >= 2 && force_nb <= 4) nb = force_nb;
+        else {
+          float best = 1e30f;
+          for (int c = 4; c >= 2; --c) {
+            const long t = (long)cdiv(N, 32 * c) * tiles_m;
+            const float cost = (float)cdiv(t, num_cus()) * ((float)c + 1.5f);
+            if (cost < best * 0.999f) { best = cost; nb = c; }
+          }
+        }
+        const int tn_ = cdiv(N, 32 * nb);
+        const int nwg_ = tn_ * tiles_m;
+        const int gridp = nwg_ < num_cus() ? nwg_ : num_cus();
+        PipeEpi pe;
+        pe.c_bytes = (unsigned)cb;
+        pe.c2_bytes = epi.C2 ? (unsigned)cb : 0u;
+        pe.r_bytes = epi.residual ? (unsigned)cb : 0u;
+        pe.h_bytes = epi.gelu_h ? (unsigned)cb : 0u;
+        pe.bias_bytes = epi.bias ? (unsigned)N * 4u : 0u;
+#define SPG_LAUNCHP(C_, A_, NB_, F_, D_)                                                                                                      \
+  do {                                                                                                                                     \
+    static bool attr_ = false;                                                                                                             \
+    if (!attr_) {                                                                                                                          \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pipe_kernel<T, C_, A_, NB_, F_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          PIPE_LDS_BYTES);                                                                                                 \
+      attr_ = true;                                                                                                                        \
+    }                                                                                                                                      \
+    hipLaunchKernelGGL((gemm_nt_pipe_kernel<T, C_, A_, NB_, F_, D_>), dim3(gridp), dim3(512), PIPE_LDS_BYTES, s, (const T*)X, (const T*)W,     \
+                       (T*)C, epi, pe, M, N, K, ldx, ldc, g, tn_, nwg_, (unsigned)xb, (unsigned)wb);                                       \
+  } while (0)
+#define SPG_LAUNCHP_NB(C_, A_, F_)                                                                                  \
+  do {                                                                                                              \
+    if (nb == 4) SPG_LAUNCHP(C_, A_, 4, F_, 0); else if (nb == 3) SPG_LAUNCHP(C_, A_, 3, F_, 0); else SPG_LAUNCHP(C_, A_, 2, F_, 0); \
+  } while (0)
+        // deferred epilogue (experimental, SPG_GEMM_DEFER=1; needs >= 3 K steps per tile): measured slower than the immediate one --
+        // the LDS it parks tiles in costs a fill stage, and the shallower lookahead loses more than the hidden epilogue gains
+        static int defer_on = -1;
+        if (defer_on < 0) { const char* e = getenv("SPG_GEMM_DEFER"); defer_on = e ? atoi(e) : 0; }
+        const bool defer = defer_on && K > 2 * (ROWB / (int)sizeof(T));
+        if ((dbg == 1 || dbg == 3 || dbg == 4 || dbg == 8 || dbg == 9) && !conv && nb == 4 && pact == PIPE_ACT_NONE) {
+          if (dbg == 1) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 1); else if (dbg == 3) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 3);
+          else if (dbg == 8) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 8); else if (dbg == 9) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 9);
+          else SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 4);
+        } else if (conv) { if (defer) SPG_LAUNCHP_NB(true, PIPE_ACT_NONE, true); else SPG_LAUNCHP_NB(true, PIPE_ACT_NONE, false); }
+        else if (pact == PIPE_ACT_GELU) { if (defer) SPG_LAUNCHP_NB(false, PIPE_ACT_GELU, true); else SPG_LAUNCHP_NB(false, PIPE_ACT_GELU, false); }
+        else if (pact == PIPE_ACT_HH) {   // the 128-wide gelu' instance would spill with the deferred epilogue's live operands
+          if (defer && nb == 3) SPG_LAUNCHP(false, PIPE_ACT_HH, 3, true, 0);
+          else if (defer && nb == 2) SPG_LAUNCHP(false, PIPE_ACT_HH, 2, true, 0);
+          else SPG_LAUNCHP_NB(false, PIPE_ACT_HH, false);
+        }
+        else { if (defer) SPG_LAUNCHP_NB(false, PIPE_ACT_NONE, true); else SPG_LAUNCHP_NB(false, PIPE_ACT_NONE, false); }
+#undef SPG_LAUNCHP_NB
+#undef SPG_LAUNCHP
+        return check_launch("gemm_nt(pipe)");
+      }
+    }
     if (waves == 8) {
       constexpr int LDS8 = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
       static bool attr8 = false;

@@ -254,11 +254,12 @@ def test_segmented_graph_step_equals_eager_step():
         m.mark_params_changed()
         arena.set_hyper(1e-3, 1e-2, 0.5)
         step = TrainStep(m, CODLoss().cuda(), arena, grad_clip=1.0, capture=seg, force_segmented=seg)
-        losses = []
+        losses, gnorms = [], []
         for it in range(2):   # Adam at lr 1e-3 amplifies float-atomic noise step by step; two steps stay comparable
             x, masks, edges = O.synthetic_batch(4, 128, seed=60 + it)
             losses.append(float(step(x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda())["loss"]))
-        res.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, float(arena.gnorm_sq)))
+            gnorms.append(float(arena.gnorm_sq))
+        res.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, gnorms))
         if seg:
             plan = step._plan
             assert len(step.segments) == len(plan) == 4 and plan[-1][0] == 0 and plan[-1][2] == arena.size
@@ -266,7 +267,10 @@ def test_segmented_graph_step_equals_eager_step():
     (l0, s0, g0), (l1, s1, g1) = res
     for a, b in zip(l0, l1):
         assert abs(a - b) < 2e-3 * abs(a), (l0, l1)
-    assert abs(g0 - g1) < 3e-2 * g0
+    # step 1 runs on identical parameters: the two backward implementations must agree up to float-atomic ordering.  Step 2 comes
+    # after an Adam update (first step ~ lr * sign(g): near-zero gradients flip sign on that noise), so its norm is only loosely tied.
+    assert abs(g0[0] - g1[0]) < 5e-3 * g0[0], (g0, g1)
+    assert abs(g0[1] - g1[1]) < 0.5 * g0[1], (g0, g1)
     tot = bad = 0
     sd0 = O.init_state_dict(seed=3, cfg=O.HIERA_TINY_TEST)
     for k in s0:
