@@ -67,6 +67,23 @@ __device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned byte
 }
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
+// LDS-DMA through inline asm: the compiler then knows of no LDS writes in flight and does not guard later LDS reads with
+// s_waitcnt vmcnt(0) (it does exactly that before ds_read_b64_tr_b16 when the DMA is issued through the builtin, draining the whole
+// fill pipeline every step).  Ordering is the kernel's job: counted vmcnt waits + barriers, as documented at each call site.
+typedef __attribute__((ext_vector_type(4))) unsigned rsrc_words_t;
+__device__ __forceinline__ rsrc_words_t make_rsrc_words(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  rsrc_words_t r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void dma16_asm(rsrc_words_t rsrc, unsigned lds_addr, unsigned voff) {   // 64 lanes x 16 B -> LDS[lds_addr ..+1024)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
 // byte offset of the 16-byte chunk (row m, K offset k0) of the (possibly gathered) X operand; OOB when outside.
 template <typename T, bool CONV>
 __device__ __forceinline__ unsigned x_chunk_off(int m, int k0, int ldx, const ConvGeom& g, int py, int px) {
@@ -1367,6 +1384,197 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_tn_pipe_kernel (bf16, dense X): the weight-gradient GEMM with the recipe of gemm_nt_pipe_kernel.
+//   slab[split][n][k] = sum_{m in split} dY[m][n] * X[m][k]         (a reduce kernel folds the slabs into dW)
+// Persistent over (128 x 128 tile, M split) units, 8 waves (2 n x 4 k, wave tile 64 n x 32 k).  Row-major [64 m][128] tiles of dY and
+// X stream in by LDS-DMA (4-stage ring, three groups in flight, offsets advanced incrementally: no divisions in the loop); MFMA
+// fragments come from ds_read_b64_tr_b16 transpose reads (no register transposes), double-buffered in registers one step ahead; the
+// step body is one basic block with the order pinned per group (MFMA, then in its shadow two transpose reads and a slice of the DMA
+// issue).  MFMA operand roles are (X fragment, dY fragment), so a lane owns 4 consecutive k of one n: the unit's result leaves as
+// 16-byte stores.  The bias gradient (column sums of dY) is taken from the dY fragments already in registers with v_dot2_f32_bf16
+// against ones, one n block per k-wave so the extra VALU work is spread evenly and nobody issues extra MFMAs.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+template <typename T, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__ dY, const T* __restrict__ X, int M, int N, int K, int ldy,
+                                                           int ldx, int tiles_k, int tiles, int splits, int m_per_split,
+                                                           unsigned ybytes, unsigned xbytes, float* __restrict__ dbias,
+                                                           float* __restrict__ slabs, unsigned slab_bytes) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  using F = TnFrag<T>;
+  constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;                      // wave tile: n [64*wn, +64), k [32*wk, +32)
+  const int G = (int)gridDim.x;
+  const int first = xcd_remap(blockIdx.x, G);
+  const int units = tiles * splits;
+  if (first >= units) return;
+  const int my_units = (units - first + G - 1) / G;
+  const int nsteps = m_per_split / MSTEP;
+  const int total = my_units * nsteps;
+  const rsrc_words_t yr = make_rsrc_words(dY, ybytes), xr = make_rsrc_words(X, xbytes);
+  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
+
+  // ---- DMA issue stream: a wave moves pieces {wave, wave + 8} (4 rows x 256 B each) of both operands per step
+  const int lrow = lane >> 4, lpc = lane & 15;
+  const int prow0 = wave * 4 + lrow;                              // row of piece 0 inside the stage tile (piece 1: + 32, same swizzle)
+  const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;   // logical feature column stored at physical chunk lpc
+  int is_step = 0, is_unit = first, is_slot = 0;
+  bool is_live = true, is_yin = false, is_xin = false;
+  unsigned yoff = 0, xoff = 0;                                    // byte offsets of piece 0 for the current step
+  const unsigned ystride = (unsigned)(MSTEP * ldy * 2), xstride = (unsigned)(MSTEP * ldx * 2);
+  const unsigned y32 = (unsigned)(32 * ldy * 2), x32 = (unsigned)(32 * ldx * 2);
+  auto enter_unit = [&]() __attribute__((always_inline)) {
+    const int tile = is_unit % tiles, split = is_unit / tiles;
+    const int tk = tile % tiles_k, tn = tile / tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const long m0 = (long)split * m_per_split + prow0;
+    yoff = (unsigned)((m0 * ldy + n0 + fcol) * 2);
+    xoff = (unsigned)((m0 * ldx + k0 + fcol) * 2);
+    is_yin = n0 + fcol < N; is_xin = k0 + fcol < K;
+  };
+  enter_unit();
+  unsigned dyo[2], dxo[2];
+  auto dma_addr = [&]() __attribute__((always_inline)) {    // rows past M fall outside the descriptors: hardware zero fill
+    dyo[0] = (is_live && is_yin) ? yoff : OOB; dyo[1] = (is_live && is_yin) ? yoff + y32 : OOB;
+    dxo[0] = (is_live && is_xin) ? xoff : OOB; dxo[1] = (is_live && is_xin) ? xoff + x32 : OOB;
+  };
+  auto dma_go = [&](int i, int which) __attribute__((always_inline)) {
+    const unsigned st = smem_base + is_slot * STAGE_B + (i * 8 + wave) * 1024;
+    if constexpr (DBG != 1) {
+      if (which == 0) dma16_asm(yr, st, dyo[i]);
+      else dma16_asm(xr, st + 16384, dxo[i]);
+    } else {
+      asm volatile("" :: "v"(dyo[i]), "v"(dxo[i]));
+    }
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+    const bool wrap = is_step + 1 == nsteps;
+    yoff += ystride; xoff += xstride;
+    is_step = wrap ? 0 : is_step + 1;
+    is_unit = wrap ? is_unit + G : is_unit;
+    if (wrap) { if (is_unit < units) enter_unit(); else is_live = false; }
+  };
+
+  // ---- fragment read offsets (lane constants) and registers
+  int oa[2][4][2], ob[2][2][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) F::offsets(s2, wk * 32 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
+  }
+  struct Frags { typename F::Frag a[2][4], b[2][2]; };
+  Frags fa, fb;
+  auto read_frag = [&](Frags& f, const char* st, int idx) __attribute__((always_inline)) {   // idx 0..11: per k-half {b0, b1, a0..a3}
+    const int sx = idx / 6, r = idx % 6;
+    if (r < 2) f.b[sx][r] = F::load_at(st + 16384, ob[sx][r][0], ob[sx][r][1]);
+    else f.a[sx][r - 2] = F::load_at(st, oa[sx][r - 2][0], oa[sx][r - 2][1]);
+  };
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  float bsum = 0.f;                                               // bias partial: column 64*wn + 16*wk + (lane & 15), this lane's m rows
+  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+
+  // ---- prologue
+  for (int i = 0; i < STAGES; ++i) {
+    dma_addr();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dma_go(j, 0); dma_go(j, 1); }
+    issue_advance();
+  }
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 12; ++i) read_frag(fa, smem, i);
+
+  int st_i = 0, unit = first, rd_slot = 1, st1 = 0, st2 = 0;
+  const int r15 = lane & 15, q = lane >> 4;
+  auto mma_block = [&](Frags& cur, Frags& nxt, auto BIAS_) __attribute__((always_inline)) {
+    constexpr bool BIAS = decltype(BIAS_)::value;
+    const char* rst = smem + rd_slot * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if constexpr (DBG != 2) {
+        const int ms = i >> 3, r = i & 7, ni = r >> 1, ki = r & 1;
+        acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);     // D[k][n]: 4 consecutive k per lane
+      }
+      if (i < 12) read_frag(nxt, rst, i);
+      if (i == 0) dma_addr();
+      if (i == 1) dma_go(0, 0);
+      if (i == 2) dma_go(0, 1);
+      if (i == 4) dma_go(1, 0);
+      if (i == 5) dma_go(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (BIAS) {
+      // column sums from the fragments just multiplied (wave-uniform choice of n block; the selects are on whole registers)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        const typename F::Frag v = wk == 0 ? cur.a[ms][0] : (wk == 1 ? cur.a[ms][1] : (wk == 2 ? cur.a[ms][2] : cur.a[ms][3]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2_t pr = {v[2 * e], v[2 * e + 1]};
+          bsum = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum, false);
+        }
+      }
+    }
+  };
+  auto step = [&](Frags& cur, Frags& nxt) __attribute__((always_inline)) {
+    if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else { wait_vm(8 + st1 + st2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    st2 = st1; st1 = 0;
+    const int tile = unit % tiles;                       // (scalar divisions once per step; the DMA stream itself has none)
+    const int tk = tile % tiles_k, tn = tile / tiles_k;
+    const bool bias_unit = dbias != nullptr && tk == 0;
+    if (bias_unit) mma_block(cur, nxt, std::true_type{}); else mma_block(cur, nxt, std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    const bool last = __builtin_amdgcn_readfirstlane(st_i + 1) == nsteps;
+    if (last) {
+      const int split = unit / tiles;
+      const int n0 = tn * 128 + wn * 64, k0 = tk * 128 + wk * 32;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+          const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
+          const unsigned o = (n < N && k < K) ? (unsigned)((((long)split * N + n) * K + k) * 4) : OOB;   // K % 4 == 0
+          if constexpr (DBG != 3) bstore16(sr, o, u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
+                                                        __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
+          acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      st1 = 8;
+      if (bias_unit) {   // fold the 4 m groups of a column (lanes l, l+16, l+32, l+48), then one atomic per column
+        float b = bsum;
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        const int n = n0 + wk * 16 + r15;
+        if (q == 0 && n < N) atomicAdd(dbias + n, b);
+      }
+      bsum = 0.f;
+    }
+    st_i = last ? 0 : st_i + 1;
+    unit = last ? unit + G : unit;
+    issue_advance();
+    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
+  };
+  for (int gc = 0; gc < total; gc += 2) {
+    step(fa, fb);
+    if (gc + 1 < total) step(fb, fa);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1679,7 +1887,39 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
     return SPG_ERR_UNSUPPORTED;
   }
   static int tnv = -1;
-  if (tnv < 0) { const char* e = getenv("SPG_GEMM_TN"); tnv = (e && strcmp(e, "dma") == 0) ? 1 : 0; }  // staged is faster on the model's shapes
+  if (tnv < 0) {   // default: pipelined kernel where it applies; SPG_GEMM_TN=staged / dma select the older variants for A/B runs
+    const char* e = getenv("SPG_GEMM_TN");
+    tnv = (e && strcmp(e, "dma") == 0) ? 1 : ((e && strcmp(e, "staged") == 0) ? 0 : 2);
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (tnv == 2 && !conv && K % 4 == 0 && ws) {
+      int sp = num_cus() / tiles;                      // one unit per workgroup is the balanced case
+      if (sp > max_splits) sp = max_splits;
+      if (sp < 1) sp = 1;
+      const int mps = cdiv(cdiv(M, sp), MSTEP) * MSTEP;
+      sp = cdiv(M, mps);
+      const size_t need = (size_t)sp * N * K * sizeof(float);
+      if (ws_bytes >= need && need < 0xFFFFFFF0UL) {
+        const int units = tiles * sp;
+        const int grid = units < num_cus() ? units : num_cus();
+        constexpr int LDSP = 4 * 32768;
+        static bool attrp = false;
+        if (!attrp) {
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+          attrp = true;
+        }
+        hipLaunchKernelGGL((gemm_tn_pipe_kernel<T, 0>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, tiles_k,
+                           tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
+        int rc = check_launch("gemm_tn(pipe)");
+        if (rc) return rc;
+        const long nk4 = (long)N * K / 4;
+        long gr = (nk4 + 255) / 256;
+        if (gr > 2048) gr = 2048;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, ws, dW, sp, nk4, K, ldw);
+        return check_launch("gemm_tn(pipe reduce)");
+      }
+    }
+  }
   if (tnv == 1) {
     // persistent kernel: one (tile, M-split) unit per workgroup is the balanced case -> as many splits as fit in the CU count
     splits = num_cus() / tiles;
@@ -1768,7 +2008,8 @@ extern "C" long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {
   const int tiles = cdiv(N, 128) * cdiv(K, 128);
   int alt = num_cus() / tiles;                       // the persistent (dma) variant's plan
   if (alt > splits) splits = alt;
-  return splits > 1 ? (long)(splits + 1) * N * K * (long)sizeof(float) : 0;
+  if (splits < 1) splits = 1;   // the pipelined bf16 kernel always goes through a slab, also unsplit
+  return (dtype == SPG_BF16 || splits > 1) ? (long)(splits + 1) * N * K * (long)sizeof(float) : 0;
 }
 
 extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, void* workspace, long workspace_bytes,
