@@ -1396,9 +1396,18 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
-template <typename T, int DBG = 0>
+// floor(m / d) for 0 <= m < 2^24 from a float reciprocal, corrected to exact (the conv gather's per-step pixel coordinates)
+__device__ __forceinline__ int div_small(int m, int d, float rd) {
+  int qq = (int)((float)m * rd);
+  const int r = m - qq * d;
+  qq += (r >= d) ? 1 : 0;
+  qq -= (r < 0) ? 1 : 0;
+  return qq;
+}
+
+template <typename T, bool CONV, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__ dY, const T* __restrict__ X, int M, int N, int K, int ldy,
-                                                           int ldx, int tiles_k, int tiles, int splits, int m_per_split,
+                                                           int ldx, ConvGeom g, int tiles_k, int tiles, int splits, int m_per_split,
                                                            unsigned ybytes, unsigned xbytes, float* __restrict__ dbias,
                                                            float* __restrict__ slabs, unsigned slab_bytes) {
   static_assert(sizeof(T) == 2, "bf16 only");
@@ -1428,20 +1437,43 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
   unsigned yoff = 0, xoff = 0;                                    // byte offsets of piece 0 for the current step
   const unsigned ystride = (unsigned)(MSTEP * ldy * 2), xstride = (unsigned)(MSTEP * ldx * 2);
   const unsigned y32 = (unsigned)(32 * ldy * 2), x32 = (unsigned)(32 * ldx * 2);
+  // conv gather (X is the NHWC input of a 3x3 / pad 1 convolution, K = 9 * Ci): per-unit lane constants of the tap this lane's 8
+  // channels belong to, and the lane's current row index m (advanced with the stream)
+  int cv_dy = 0, cv_dx = 0, cv_m = 0;
+  long cv_delta = 0;
+  const int cv_hw = g.H * g.W;
+  const float cv_rhw = 1.f / (float)(CONV ? cv_hw : 1), cv_rw = 1.f / (float)(CONV ? g.W : 1);
   auto enter_unit = [&]() __attribute__((always_inline)) {
     const int tile = is_unit % tiles, split = is_unit / tiles;
     const int tk = tile % tiles_k, tn = tile / tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
     const long m0 = (long)split * m_per_split + prow0;
     yoff = (unsigned)((m0 * ldy + n0 + fcol) * 2);
-    xoff = (unsigned)((m0 * ldx + k0 + fcol) * 2);
     is_yin = n0 + fcol < N; is_xin = k0 + fcol < K;
+    if constexpr (!CONV) {
+      xoff = (unsigned)((m0 * ldx + k0 + fcol) * 2);
+    } else {
+      const int kk = k0 + fcol;
+      const int tap = kk / g.Ci, ci = kk - tap * g.Ci;
+      cv_dy = tap / 3 - 1; cv_dx = tap - (tap / 3) * 3 - 1;
+      cv_delta = ((long)(cv_dy * g.W + cv_dx) * g.Ci + ci) * 2;
+      cv_m = (int)m0;
+    }
   };
   enter_unit();
   unsigned dyo[2], dxo[2];
-  auto dma_addr = [&]() __attribute__((always_inline)) {    // rows past M fall outside the descriptors: hardware zero fill
-    dyo[0] = (is_live && is_yin) ? yoff : OOB; dyo[1] = (is_live && is_yin) ? yoff + y32 : OOB;
-    dxo[0] = (is_live && is_xin) ? xoff : OOB; dxo[1] = (is_live && is_xin) ? xoff + x32 : OOB;
+  auto dma_addr = [&](int i) __attribute__((always_inline)) {    // rows past M fall outside the descriptors: hardware zero fill
+    dyo[i] = (is_live && is_yin) ? yoff + (i ? y32 : 0u) : OOB;
+    if constexpr (!CONV) {
+      dxo[i] = (is_live && is_xin) ? xoff + (i ? x32 : 0u) : OOB;
+    } else {
+      const int m = cv_m + 32 * i;
+      const int bimg = div_small(m, cv_hw, cv_rhw);
+      const int pix = m - bimg * cv_hw;
+      const int y = div_small(pix, g.W, cv_rw), x = pix - y * g.W;
+      const bool ok = is_live && is_xin && m < M && (unsigned)(y + cv_dy) < (unsigned)g.H && (unsigned)(x + cv_dx) < (unsigned)g.W;
+      dxo[i] = ok ? (unsigned)((long)m * g.Ci * 2 + cv_delta) : OOB;
+    }
   };
   auto dma_go = [&](int i, int which) __attribute__((always_inline)) {
     const unsigned st = smem_base + is_slot * STAGE_B + (i * 8 + wave) * 1024;
@@ -1455,7 +1487,7 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
   auto issue_advance = [&]() __attribute__((always_inline)) {
     is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
     const bool wrap = is_step + 1 == nsteps;
-    yoff += ystride; xoff += xstride;
+    yoff += ystride; xoff += xstride; cv_m += MSTEP;
     is_step = wrap ? 0 : is_step + 1;
     is_unit = wrap ? is_unit + G : is_unit;
     if (wrap) { if (is_unit < units) enter_unit(); else is_live = false; }
@@ -1485,9 +1517,8 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
 
   // ---- prologue
   for (int i = 0; i < STAGES; ++i) {
-    dma_addr();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { dma_go(j, 0); dma_go(j, 1); }
+    for (int j = 0; j < 2; ++j) { dma_addr(j); dma_go(j, 0); dma_go(j, 1); }
     issue_advance();
   }
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -1507,9 +1538,10 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
         acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);     // D[k][n]: 4 consecutive k per lane
       }
       if (i < 12) read_frag(nxt, rst, i);
-      if (i == 0) dma_addr();
+      if (i == 0) dma_addr(0);
       if (i == 1) dma_go(0, 0);
       if (i == 2) dma_go(0, 1);
+      if (i == 3) dma_addr(1);
       if (i == 4) dma_go(1, 0);
       if (i == 5) dma_go(1, 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -1892,7 +1924,7 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
     tnv = (e && strcmp(e, "dma") == 0) ? 1 : ((e && strcmp(e, "staged") == 0) ? 0 : 2);
   }
   if constexpr (sizeof(T) == 2) {
-    if (tnv == 2 && !conv && K % 4 == 0 && ws) {
+    if (tnv == 2 && K % 4 == 0 && ws && (!conv || M < (1 << 24))) {
       int sp = num_cus() / tiles;                      // one unit per workgroup is the balanced case
       if (sp > max_splits) sp = max_splits;
       if (sp < 1) sp = 1;
@@ -1905,11 +1937,16 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
         constexpr int LDSP = 4 * 32768;
         static bool attrp = false;
         if (!attrp) {
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe_kernel<T, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe_kernel<T, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
           attrp = true;
         }
-        hipLaunchKernelGGL((gemm_tn_pipe_kernel<T, 0>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, tiles_k,
-                           tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
+        if (conv)
+          hipLaunchKernelGGL((gemm_tn_pipe_kernel<T, true, 0>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, g,
+                             tiles_k, tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
+        else
+          hipLaunchKernelGGL((gemm_tn_pipe_kernel<T, false, 0>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, g,
+                             tiles_k, tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
         int rc = check_launch("gemm_tn(pipe)");
         if (rc) return rc;
         const long nk4 = (long)N * K / 4;
