@@ -53,6 +53,9 @@ class TrainStep:
         self.static = None
         self.losses = None
         self.world = sync.world if sync is not None else 1
+        # forked weight-gradient stream (models/engine.py), opt-in with SPG_WGRAD_ASYNC=1: measured SLOWER on one MI355X (226.0 vs 232.2
+        # img/s on the B=8@384 graph step) -- both branches are chip-sized persistent kernels, so they contend instead of packing
+        model.engine.wgrad_async = ((sync is None) or capture) and os.environ.get("SPG_WGRAD_ASYNC", "0") == "1"
         if sync is not None and not capture:
             ends = arena.unit_ends
             model.engine.unit_cb = lambda k: sync.ready(ends[k])

@@ -37,6 +37,15 @@ class Engine:
         self.P: Dict[str, Tensor] = {}
         self.W: Dict[str, Tensor] = {}      # packed T copies
         self.unit_cb = None   # called with the index of each finished backward unit (head=0, then blocks last-to-first)
+        # Weight-gradient GEMMs feed nothing but the optimizer, and the persistent GEMM kernels rarely fill all 256 CUs (tile / split
+        # quantisation, ramp-up and tail of each launch).  With wgrad_async they are forked onto a second HIP stream -- inside a
+        # captured step that is a parallel branch of the graph -- so their workgroups could pack into CUs the dgrad chain leaves idle.
+        # Operands are held until join_wgrad(), which every backward piece calls before it returns.  Off by default: on one MI355X
+        # the two chip-sized branches contend (226.0 vs 232.2 img/s, see engine/trainer.py).
+        self.wgrad_async = False
+        self._side = None
+        self._held = []
+        self._forked = False
         self.refresh_params()
 
     # ------------------------------------------------------------------------------------------------
@@ -112,11 +121,31 @@ class Engine:
         return ops.bn_bwd(dy, st.x, st.ss, st.mi, self.P[st.prefix + "weight"], self.grad(st.prefix + "weight"),
                           self.grad(st.prefix + "bias"), st.C, st.relu)
 
+    # ------------------------------------------------------------------------------------------------ forked weight gradients
+    def _wgrad(self, launch, *keep) -> None:
+        if not self.wgrad_async or self.unit_cb is not None:
+            launch()
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())   # the producers of dy / x
+        with torch.cuda.stream(self._side):
+            launch()
+        self._held.extend(keep)
+        self._forked = True
+
+    def join_wgrad(self) -> None:
+        if self._forked:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._held.clear()
+            self._forked = False
+
     # ------------------------------------------------------------------------------------------------ linear helpers
     def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
                 residual: Optional[Tensor] = None, bias: bool = True) -> Optional[Tensor]:
         """dW += dy^T x, db += colsum(dy), returns dx = dy W (optionally * gelu'(h), + residual)."""
-        ops.gemm_tn(dy, x, self.grad(name + ".weight").view(dy.shape[-1], -1), dbias=self.grad(name + ".bias") if bias else None)
+        gw, gb = self.grad(name + ".weight").view(dy.shape[-1], -1), (self.grad(name + ".bias") if bias else None)
+        self._wgrad(lambda: ops.gemm_tn(dy, x, gw, dbias=gb), dy, x)
         if not need_dx:
             return None
         return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual)
@@ -270,6 +299,7 @@ class Engine:
             st["unit"] += 1
             if self.unit_cb is not None:
                 self.unit_cb(st["unit"])
+        self.join_wgrad()
 
     def trunk_bwd_end(self):
         e = "encoder.encoder."
@@ -286,15 +316,20 @@ class Engine:
         self.grad(e + "pos_embed").view(D, n_b).add_(gpos[:, :n_b])
         self.grad(e + "pos_embed_window").view(D, n_w).add_(gpos[:, n_b:n_b + n_w])
         self._bw = None
+        self.join_wgrad()
 
     # ================================================================================================ head
     def conv3_fwd(self, name: str, x: Tensor, B, H, W, Ci, bias: bool):
         return ops.gemm_nt(x, self.W[name + ".weight"], bias=self.P[name + ".bias"] if bias else None, conv=(B, H, W, Ci))
 
     def conv3_bwd(self, name: str, dy: Tensor, x: Tensor, B, H, W, Ci, Co, bias: bool, need_dx: bool = True):
-        gp = torch.zeros((Co, 9 * Ci), dtype=torch.float32, device=dy.device)
-        ops.gemm_tn(dy, x, gp, conv=(B, H, W, Ci), dbias=self.grad(name + ".bias") if bias else None)
-        ops.unpack_conv3x3_grad(gp, self.grad(name + ".weight"))
+        gw, gb = self.grad(name + ".weight"), (self.grad(name + ".bias") if bias else None)
+
+        def launch():
+            gp = torch.zeros((Co, 9 * Ci), dtype=torch.float32, device=dy.device)
+            ops.gemm_tn(dy, x, gp, conv=(B, H, W, Ci), dbias=gb)
+            ops.unpack_conv3x3_grad(gp, gw)
+        self._wgrad(launch, dy, x)
         if not need_dx:
             return None
         return ops.gemm_nt(dy, self.W[name + ".weight:dgrad"], conv=(B, H, W, Co))
