@@ -144,7 +144,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     M = x.numel() // C
     dx = torch.empty_like(x)
     _lib.call("spg_layernorm_bwd", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(gamma)), _p(mean), _p(rstd), _p(dres), _p(dx),
-              _p(f32(dgamma)), _p(f32(dbeta)), M, C, _stream())
+              _p(f32(dgamma) if dgamma is not None else None), _p(f32(dbeta) if dbeta is not None else None), M, C, _stream())
     return dx
 
 
