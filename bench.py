@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches (bucketed all-reduce overlaps backward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--infer", action="store_true",
+                    help="BASELINE config 3 instead of the train step: eval-mode forward under one hipGraph (use --batch 64); "
+                         "not the headline metric, never the default")
     args = ap.parse_args()
 
     from spegnet_amd.engine.distributed import GradSync, init_process_group_from_env
@@ -97,6 +100,46 @@ def main():
     from spegnet_amd.engine.trainer import TrainStep
     from spegnet_amd.models import SPEGNet
     from spegnet_amd.utils.loss_functions import CODLoss
+
+    if args.infer:
+        log(f"rank {rank}/{world} building model (inference)")
+        model = SPEGNet({"encoder": {"variant": "large"}, "compute_dtype": args.dtype, "init_seed": 0}).to(dev).eval()
+        images = synthetic(args.batch, args.size, dev, seed=1000 * rank)[0]
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(images)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = model(images)
+            for _ in range(max(args.warmup, 1)):
+                graph.replay()
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t)
+        assert bool(torch.isfinite(out["predictions"][2].float()).all()), "non-finite logits"
+        if rank == 0:
+            print(json.dumps({
+                "metric": f"img/s inference @{args.size}x{args.size} {args.dtype}", "value": round(world * args.batch * args.steps / dt, 3),
+                "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"SPEGNet eval-mode forward (Hiera-L trunk + CFI + EFE + PED), batch {args.batch}/GPU "
+                                       f"@{args.size}x{args.size}, random-init weights, one hipGraph replay per step",
+                           "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}", "launch": "hipGraph"}}))
+        return
 
     log(f"rank {rank}/{world} building model")
     model = SPEGNet({"encoder": {"variant": "large"}, "compute_dtype": args.dtype, "init_seed": 0}).to(dev).train()
