@@ -20,6 +20,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.nn.functional as F
 
+from .. import ops
 from ..models.spegnet import SPEGNet
 from ..utils.loss_functions import CODLoss
 from .arena import Arena
@@ -62,6 +63,7 @@ class TrainStep:
 
     # ---- pieces -------------------------------------------------------------------------------------------
     def _fwd_bwd(self, images, masks, edges):
+        ops.begin_zero_pool(images.device)   # one fill for the step's zero-initialised scratch (ops.zeros_f32)
         self.arena.zero_grad()
         out = self.model(images)
         losses = self.criterion.forward_batched(out['predictions'], out['edge'], masks, edges)
@@ -106,6 +108,7 @@ class TrainStep:
 
     def _seg_first(self, images, masks, edges, lo, hi):
         model, eng = self.model, self.model.engine
+        ops.begin_zero_pool(images.device)
         self.arena.zero_grad()
         feats, tctx = eng.trunk_fwd(images, True, True)
         out, hctx = eng.head_fwd(feats[1:4], True, True)

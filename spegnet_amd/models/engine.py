@@ -82,6 +82,13 @@ class Engine:
                 W[name + ":T"] = torch.empty((C, R), dtype=T, device=p.device)
                 jobs.append(struct.pack("<QQQiiii", p.data_ptr(), W[name].data_ptr(), W[name + ":T"].data_ptr(), R, C, tile0, 0))
                 tile0 += ((R + 31) // 32) * ((C + 31) // 32)
+            # the per-block qkv biases the attention kernels read in the compute dtype ride in the same launch (1 x C "matrices")
+            for b in self.blocks:
+                n = f"encoder.encoder.blocks.{b['idx']}.attn.qkv.bias"
+                p = P[n]
+                W[n] = torch.empty(p.shape, dtype=T, device=p.device)
+                jobs.append(struct.pack("<QQQiiii", p.data_ptr(), W[n].data_ptr(), 0, 1, p.numel(), tile0, 0))
+                tile0 += (p.numel() + 31) // 32
             blob = torch.frombuffer(bytearray(b"".join(jobs)), dtype=torch.uint8).to(next(iter(P.values())).device)
             self._pack_jobs, self._pack_n, self._pack_tiles = blob, len(jobs), tile0
             self._pack_key = tuple(p.data_ptr() for p in P.values())
@@ -94,9 +101,6 @@ class Engine:
         w2 = torch.zeros((pw.shape[0], PATCH_KPAD), dtype=torch.float32, device=pw.device)
         w2[:, :147] = pw.detach().reshape(pw.shape[0], 147)
         W[e] = ops.pack_matrix(w2, T, out=W.get(e))
-        for b in self.blocks:
-            n = f"encoder.encoder.blocks.{b['idx']}.attn.qkv.bias"
-            W[n] = P[n].detach().to(T)
 
     # ------------------------------------------------------------------------------------------------ BN
     def bn_fwd(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool):
@@ -307,11 +311,11 @@ class Engine:
         ctx, dx = st["ctx"], st["dx"]
         D = dx.shape[-1]
         d2 = dx.reshape(-1, D)
-        pw = torch.zeros((D, PATCH_KPAD), dtype=torch.float32, device=dx.device)
+        pw = ops.zeros_f32((D, PATCH_KPAD), dx.device)
         ops.gemm_tn(d2, ctx["cols"], pw, dbias=self.grad(e + "patch_embed.proj.bias"))
         self.grad(e + "patch_embed.proj.weight").view(D, 147).add_(pw[:, :147])
         n_b, n_w, Kp = self._basis_dims
-        gpos = torch.zeros((D, Kp), dtype=torch.float32, device=dx.device)
+        gpos = ops.zeros_f32((D, Kp), dx.device)
         ops.gemm_tn(d2, ctx["basis"], gpos)
         self.grad(e + "pos_embed").view(D, n_b).add_(gpos[:, :n_b])
         self.grad(e + "pos_embed_window").view(D, n_w).add_(gpos[:, n_b:n_b + n_w])
@@ -326,7 +330,7 @@ class Engine:
         gw, gb = self.grad(name + ".weight"), (self.grad(name + ".bias") if bias else None)
 
         def launch():
-            gp = torch.zeros((Co, 9 * Ci), dtype=torch.float32, device=dy.device)
+            gp = ops.zeros_f32((Co, 9 * Ci), dy.device)
             ops.gemm_tn(dy, x, gp, conv=(B, H, W, Ci), dbias=gb)
             ops.unpack_conv3x3_grad(gp, gw)
         self._wgrad(launch, dy, x)

@@ -43,6 +43,36 @@ def f32(t: Tensor) -> Tensor:
     return _c(t)
 
 
+# ---- zero-initialised f32 scratch (atomic accumulators, packed weight gradients) -------------------------------
+# A train step needs ~50 small zeroed buffers; each torch.zeros is its own fill launch.  TrainStep opens a pool at the start of
+# the step: ONE fill (inside a captured step: one memset node), slices handed out in order.  Without a pool (inference, tests
+# calling ops directly) or when it is exhausted, plain torch.zeros.
+_ZPOOL = None   # [tensor, offset_in_floats]
+
+
+def begin_zero_pool(device, nfloats: int = 8 << 20) -> None:
+    global _ZPOOL
+    _ZPOOL = [torch.zeros(nfloats, dtype=torch.float32, device=device), 0]
+
+
+def end_zero_pool() -> None:
+    global _ZPOOL
+    _ZPOOL = None
+
+
+def zeros_f32(shape, device) -> Tensor:
+    shape = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (int(shape),)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if _ZPOOL is not None and _ZPOOL[0].device == torch.device(device):
+        off = _ZPOOL[1]
+        if off + n <= _ZPOOL[0].numel():
+            _ZPOOL[1] = off + ((n + 63) // 64) * 64          # keep 256-byte alignment
+            return _ZPOOL[0][off:off + n].view(shape)
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 # ---- optional live kernel timing (bench.py roofline leg): HIP events on the launch stream -----------------------
 PROFILE = None  # set to a list -> every gemm_nt appends (kind, flops, start_event, end_event)
 
@@ -195,13 +225,13 @@ def colsum(x: Tensor, out: Tensor) -> None:
 
 
 def gap_sum(x: Tensor, B: int, HW: int, C: int) -> Tensor:
-    out = torch.zeros((B, C), dtype=torch.float32, device=x.device)
+    out = zeros_f32((B, C), x.device)
     _lib.call("spg_gap_sum", dcode(x), _p(_c(x)), _p(out), B, HW, C, _stream())
     return out
 
 
 def chan_prod_sum(a: Tensor, b: Tensor, B: int, HW: int, C: int) -> Tensor:
-    out = torch.zeros((B, C), dtype=torch.float32, device=a.device)
+    out = zeros_f32((B, C), a.device)
     _lib.call("spg_chan_prod_sum", dcode(a), _p(_c(a)), _p(_c(b)), _p(out), B, HW, C, _stream())
     return out
 
@@ -219,7 +249,7 @@ def copy_channels(x: Tensor, y: Tensor, M: int, C: int, ldx: int, cx0: int, ldy:
 
 # ---- BatchNorm ------------------------------------------------------------------------------------------
 def bn_stats(x: Tensor, C: int) -> Tensor:
-    stats = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+    stats = zeros_f32(2 * C, x.device)
     _lib.call("spg_bn_stats", dcode(x), _p(_c(x)), _p(stats), x.numel() // C, C, _stream())
     return stats
 
@@ -243,7 +273,7 @@ def bn_apply(x: Tensor, ss: Tensor, C: int, relu: bool, out: Optional[Tensor] = 
 
 def bn_bwd(dy: Tensor, x: Tensor, ss: Tensor, mi: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor, C: int, relu: bool) -> Tensor:
     M = x.numel() // C
-    sums = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+    sums = zeros_f32(2 * C, x.device)
     _lib.call("spg_bn_bwd_reduce", dcode(x), _p(_c(dy)), _p(_c(x)), _p(ss), _p(mi), _p(sums), M, C, 1 if relu else 0, _stream())
     dx = torch.empty_like(x)
     _lib.call("spg_bn_bwd_apply", dcode(x), _p(dy), _p(x), _p(ss), _p(mi), _p(f32(gamma)), _p(sums), _p(dx), _p(f32(dgamma)),
