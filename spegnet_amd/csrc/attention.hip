@@ -98,6 +98,15 @@ __device__ __forceinline__ typename AC<T, HD>::Frag load_row_frag_lds(const char
   }
 }
 
+// dot product of two row fragments (the lane's slice of a row); f32 accumulation
+__device__ __forceinline__ float frag_dot(bf16x8_t a, bf16x8_t b, float acc) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(bf2{a[2 * e], a[2 * e + 1]}, bf2{b[2 * e], b[2 * e + 1]}, acc, false);
+  return acc;
+}
+__device__ __forceinline__ float frag_dot(float a, float b, float acc) { return acc + a * b; }
+
 template <typename T> struct MM;
 template <> struct MM<bf16_t> {
   __device__ static __forceinline__ f32x4 mma(bf16x8_t a, bf16x8_t b, f32x4 c) {
@@ -312,8 +321,9 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
     dof[s] = load_row_frag_global<T, HD>(doptr, s, q);
   }
   // delta: each of the 4 lanes sharing a row sums a quarter of d
-  float delta = 0.f;
-  for (int d = q; d < HD; d += 4) delta += ST<T>::ld(doptr + d) * ST<T>::ld(optr + d);
+  float delta = 0.f;   // from 16-byte fragment loads (dO's is already in registers), not element loads
+#pragma unroll
+  for (int s = 0; s < A::KS; ++s) delta = frag_dot(dof[s], load_row_frag_global<T, HD>(optr, s, q), delta);
   delta += __shfl_xor(delta, 16, 64);
   delta += __shfl_xor(delta, 32, 64);
   const float lse = qvalid ? p.lse[qrow * p.heads + head] : 0.f;
@@ -582,8 +592,9 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
       typename A::Frag dof[A::KS];
 #pragma unroll
       for (int s = 0; s < A::KS; ++s) dof[s] = load_row_frag_global<T, HD>(doptr, s, q);
-      float delta = 0.f;
-      for (int d = q; d < HD; d += 4) delta += ST<T>::ld(doptr + d) * ST<T>::ld(optr + d);
+      float delta = 0.f;   // from 16-byte fragment loads (dO's is already in registers), not element loads
+#pragma unroll
+      for (int s = 0; s < A::KS; ++s) delta = frag_dot(dof[s], load_row_frag_global<T, HD>(optr, s, q), delta);
       delta += __shfl_xor(delta, 16, 64);
       delta += __shfl_xor(delta, 32, 64);
       const float lse = qvalid ? p.lse[qrow * p.heads + head] : 0.f;
