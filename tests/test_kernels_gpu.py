@@ -42,7 +42,9 @@ def rnd(*shape, seed=0, scale=1.0):
 
 # ------------------------------------------------------------------------------------------- GEMM NT
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 144), (77, 432, 144), (1000, 576, 2304), (64, 16, 32)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 144), (77, 432, 144), (1000, 576, 2304), (64, 16, 32),
+                                   # > 256 tiles with ragged M / N edges: persistent workgroups walk several tiles each
+                                   (4645, 2304, 576), (5000, 1000, 200), (33000, 144, 576)])
 def test_gemm_nt_dense(ops, dt, M, N, K):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     xq, wq = x.to(dt), w.to(dt)
@@ -73,7 +75,7 @@ def test_gemm_nt_identity_asymmetric(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 9, 7, 16, 24), (1, 16, 16, 64, 64), (2, 12, 12, 40, 136)])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 9, 7, 16, 24), (1, 16, 16, 64, 64), (2, 12, 12, 40, 136), (4, 128, 128, 32, 40)])
 def test_conv3x3_fwd_dgrad_wgrad(ops, dt, B, H, W, Ci, Co):
     x = rnd(B, Ci, H, W, seed=1).to(dt).float().requires_grad_(True)
     w = rnd(Co, Ci, 3, 3, seed=2, scale=(9 * Ci) ** -0.5).to(dt).float().requires_grad_(True)
@@ -98,7 +100,9 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dt, B, H, W, Ci, Co):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 200, 144), (4608, 576, 288), (50, 16, 32)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 200, 144), (4608, 576, 288), (50, 16, 32),
+                                   # more (tile, split) units than CUs, and an M that is no multiple of the 64-row step
+                                   (300, 4608, 1152), (4645, 2304, 576)])
 def test_gemm_tn(ops, dt, M, N, K):
     dy, x = rnd(M, N, seed=1).to(dt), rnd(M, K, seed=2).to(dt)
     dw = torch.zeros(N, K, device="cuda")
