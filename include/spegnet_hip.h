@@ -50,6 +50,16 @@ int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbia
 /* bytes of caller-owned scratch that lets the M-splits of spg_gemm_tn write partial slabs with plain stores (+ one reduce
  * launch) instead of f32 atomics; 0 = not split.  workspace may be NULL (atomics are used).                             */
 long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K);
+/* Up to 8 dense bf16 weight-gradient problems with the same row count M in one launch: dW[i][N,K] += dY[i][M,N]^T . X[i][M,K],
+ * dbias[i][N] += colsum(dY[i]) (dbias, or single entries of it, may be NULL).  Every CU gets the same number of 64-row steps: whole
+ * 128x128 tiles first (accumulated straight into dW), then an even share of the remaining tiles' steps, whose partial sums go
+ * through the workspace (spg_gemm_tn_group_workspace_bytes(), caller-owned) and a small second kernel.  Pointer / int arrays are
+ * HOST arrays of njobs entries.  Replaces the per-layer wgrad calls of a trunk block (reference: autograd of the four nn.Linear
+ * of sam2's MultiScaleBlock).                                                                                                     */
+int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias,
+                      int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, void* workspace,
+                      long workspace_bytes, spg_stream_t stream);
+long spg_gemm_tn_group_workspace_bytes(void);
 
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
  * spg_pack_matrix: dst[r][c] = src[r][c] (transpose=0) or dst[c][r] = src[r][c] (transpose=1), src f32 [R,C].

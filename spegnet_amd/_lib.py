@@ -20,6 +20,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 SIGNATURES = {
     "spg_gemm_nt": "ipppppppiiiiiiiiiiip",
     "spg_gemm_tn": "ipppppliiiiiiiiiiip",
+    "spg_gemm_tn_group": "ii" "pppp" "i" "ppppp" "plp",
     "spg_pack_matrix": "ippiiip",
     "spg_pack_batch": "ipiip",
     "spg_pack_conv3x3": "ipppiip",
@@ -81,6 +82,8 @@ def load() -> ctypes.CDLL:
     lib.spg_version.restype = _I
     lib.spg_gemm_tn_workspace_bytes.restype = _L
     lib.spg_gemm_tn_workspace_bytes.argtypes = [_I, _I, _I, _I]
+    lib.spg_gemm_tn_group_workspace_bytes.restype = _L
+    lib.spg_gemm_tn_group_workspace_bytes.argtypes = []
     for table, required in ((SIGNATURES, True), (_OPTIONAL, False)):
         for name, sig in table.items():
             try:

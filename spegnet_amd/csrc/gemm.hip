@@ -1607,6 +1607,288 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_tn_group_kernel (bf16, dense): up to 8 weight-gradient problems with the same row count M in ONE launch, balanced over the CUs.
+// All 128 x 128 tiles of all problems form one list (T tiles, S = ceil(M / 64) steps each).  Persistent workgroup c (logical index
+// after the XCD remap) first multiplies W = floor(T / G) WHOLE tiles (c W .. c W + W - 1) and adds each straight into dW (load + add +
+// store: one owner, no race), then an equal contiguous share of the steps of the remaining R = T - W G tiles; those partial sums go
+// to the workgroup's two slab slots (slot 0: the tile was begun by an earlier workgroup, slot 1: it is finished by a later one)
+// and tn_group_reduce_kernel folds them into dW.  Why: a stage-3 trunk block has four wgrads of 25-90 tiles each; launched one by
+// one they fill 70-88 % of the CUs and each pays a launch ramp and a reduce over 2-3 full-size slabs.  Grouped, every CU gets the
+// same number of steps and only the R remainder tiles (19 of 275 for that block) pass through slabs.
+// Inner loop = gemm_tn_pipe_kernel's (LDS-DMA through inline asm, transpose-read fragments double-buffered in registers, pinned
+// MFMA / read / DMA interleave, dot2 bias sums).
+// ------------------------------------------------------------------------------------------------
+constexpr int TN_GROUP_MAX = 8;
+constexpr int TN_SLOT_FLOATS = 128 * 128;
+struct TnJob {
+  const void* dY; const void* X; float* dW; float* dbias;
+  int N, K, ldy, ldx, ldw;
+  int tiles_k, tiles, tile0;  // tile0 = index of this problem's first tile in the group's tile list
+};
+struct TnGroup {
+  TnJob job[TN_GROUP_MAX];
+  int njobs, M, S, T;         // S = 64-row steps per tile, T = tiles in all
+  int W, RS;                  // whole tiles per workgroup; steps of the remainder tiles (shared evenly)
+};
+
+__device__ __forceinline__ void tn_locate_tile(const TnGroup& g, int gt, int& j, int& tile) {
+  j = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.njobs; ++i) if (gt >= g.job[i].tile0) j = i;
+  tile = gt - g.job[j].tile0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  using F = TnFrag<T>;
+  constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  const int G = (int)gridDim.x;
+  const int c = xcd_remap(blockIdx.x, G);
+  const int S = g.S;
+  const int WS = g.W * S;                                                   // steps of this workgroup's whole tiles
+  const int rb = (int)((long)c * g.RS / G), re = (int)((long)(c + 1) * g.RS / G);   // its share of the remainder steps
+  const int total = WS + (re - rb);
+  if (total <= 0) return;
+  const int gt_first = WS > 0 ? c * g.W : g.W * G + rb / S;                 // first tile / step of the sequence
+  const int m_first = WS > 0 ? 0 : rb % S;
+  const int gt_rem = g.W * G + rb / S, m_rem = rb % S;                      // where the remainder share starts
+  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
+
+  // ---- DMA issue stream
+  const int lrow = lane >> 4, lpc = lane & 15;
+  const int prow0 = wave * 4 + lrow;
+  const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;
+  int is_job = -1, is_gt = gt_first, is_tile, is_mstep = m_first, is_ls = 0, is_slot = 0;
+  bool is_live = true, is_yin = false, is_xin = false;
+  unsigned yoff = 0, xoff = 0, ystride = 0, xstride = 0, y32 = 0, x32 = 0;
+  rsrc_words_t yr, xr;
+  auto is_enter_tile = [&]() __attribute__((always_inline)) {   // (also switches descriptors when the tile belongs to another problem)
+    int j;
+    tn_locate_tile(g, is_gt, j, is_tile);
+    const TnJob& jb = g.job[j];
+    if (j != is_job) {
+      is_job = j;
+      yr = make_rsrc_words(jb.dY, (unsigned)((long)g.M * jb.ldy * 2));
+      xr = make_rsrc_words(jb.X, (unsigned)((long)g.M * jb.ldx * 2));
+      ystride = (unsigned)(MSTEP * jb.ldy * 2); xstride = (unsigned)(MSTEP * jb.ldx * 2);
+      y32 = (unsigned)(32 * jb.ldy * 2); x32 = (unsigned)(32 * jb.ldx * 2);
+    }
+    const int tk = is_tile % jb.tiles_k, tn = is_tile / jb.tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const long m0 = (long)is_mstep * MSTEP + prow0;
+    yoff = (unsigned)((m0 * jb.ldy + n0 + fcol) * 2);
+    xoff = (unsigned)((m0 * jb.ldx + k0 + fcol) * 2);
+    is_yin = n0 + fcol < jb.N; is_xin = k0 + fcol < jb.K;
+  };
+  is_enter_tile();
+  unsigned dyo[2], dxo[2];
+  auto dma_addr = [&](int i) __attribute__((always_inline)) {    // rows past M fall outside the descriptors: hardware zero fill
+    dyo[i] = (is_live && is_yin) ? yoff + (i ? y32 : 0u) : OOB;
+    dxo[i] = (is_live && is_xin) ? xoff + (i ? x32 : 0u) : OOB;
+  };
+  auto dma_go = [&](int i, int which) __attribute__((always_inline)) {
+    const unsigned st = smem_base + is_slot * STAGE_B + (i * 8 + wave) * 1024;
+    if (which == 0) dma16_asm(yr, st, dyo[i]);
+    else dma16_asm(xr, st + 16384, dxo[i]);
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+    yoff += ystride; xoff += xstride;
+    ++is_ls;
+    const bool tile_end = is_mstep + 1 == S;
+    if (is_ls >= total) is_live = false;
+    else if (is_ls == WS) { is_gt = gt_rem; is_mstep = m_rem; is_enter_tile(); }        // whole tiles done: jump to the remainder share
+    else if (tile_end) { is_gt = is_gt + 1; is_mstep = 0; is_enter_tile(); }
+    else is_mstep = is_mstep + 1;
+  };
+
+  // ---- fragments
+  int oa[2][4][2], ob[2][2][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) F::offsets(s2, wk * 32 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
+  }
+  struct Frags { typename F::Frag a[2][4], b[2][2]; };
+  Frags fa, fb;
+  auto read_frag = [&](Frags& f, const char* st, int idx) __attribute__((always_inline)) {
+    const int sx = idx / 6, r = idx % 6;
+    if (r < 2) f.b[sx][r] = F::load_at(st + 16384, ob[sx][r][0], ob[sx][r][1]);
+    else f.a[sx][r - 2] = F::load_at(st, oa[sx][r - 2][0], oa[sx][r - 2][1]);
+  };
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  float bsum = 0.f;
+  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+
+  // ---- prologue
+  for (int i = 0; i < STAGES; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dma_addr(j); dma_go(j, 0); dma_go(j, 1); }
+    issue_advance();
+  }
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 12; ++i) read_frag(fa, smem, i);
+
+  // ---- compute cursor
+  int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;   // seg0: m step at which this workgroup entered the current tile
+  int cj, ctile;
+  tn_locate_tile(g, cgt, cj, ctile);
+  int rd_slot = 1, st1 = 0, st2 = 0;
+  const int r15 = lane & 15, q = lane >> 4;
+  auto mma_block = [&](Frags& cur, Frags& nxt, auto BIAS_) __attribute__((always_inline)) {
+    constexpr bool BIAS = decltype(BIAS_)::value;
+    const char* rst = smem + rd_slot * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ms = i >> 3, r = i & 7, ni = r >> 1, ki = r & 1;
+      acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);
+      if (i < 12) read_frag(nxt, rst, i);
+      if (i == 0) dma_addr(0);
+      if (i == 1) dma_go(0, 0);
+      if (i == 2) dma_go(0, 1);
+      if (i == 3) dma_addr(1);
+      if (i == 4) dma_go(1, 0);
+      if (i == 5) dma_go(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        const typename F::Frag v = wk == 0 ? cur.a[ms][0] : (wk == 1 ? cur.a[ms][1] : (wk == 2 ? cur.a[ms][2] : cur.a[ms][3]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2_t pr = {v[2 * e], v[2 * e + 1]};
+          bsum = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum, false);
+        }
+      }
+    }
+  };
+  auto step = [&](Frags& cur, Frags& nxt) __attribute__((always_inline)) {
+    if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else { wait_vm(8 + st1 + st2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    st2 = st1; st1 = 0;
+    const TnJob& jb = g.job[cj];
+    const int tk = ctile % jb.tiles_k, tn = ctile / jb.tiles_k;
+    const bool bias_tile = jb.dbias != nullptr && tk == 0;
+    if (bias_tile) mma_block(cur, nxt, std::true_type{}); else mma_block(cur, nxt, std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
+    const bool range_end = cls + 1 == total;
+    if (tile_end || range_end) {
+      const int n0 = tn * 128 + wn * 64, k0 = tk * 128 + wk * 32;
+      if (seg0 == 0 && tile_end) {
+        // the whole tile was multiplied here: accumulate into the gradient (single owner)
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(jb.dW, (unsigned)((long)jb.N * jb.ldw * 4));
+        u32x4 old[4][2];
+        unsigned o[4][2];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int ki = 0; ki < 2; ++ki) {
+            const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
+            o[ni][ki] = (n < jb.N && k < jb.K) ? (unsigned)(((long)n * jb.ldw + k) * 4) : OOB;   // K % 4 == 0
+            old[ni][ki] = bload16(wr, o[ni][ki]);
+          }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int ki = 0; ki < 2; ++ki) {
+            const f32x4 v = acc[ni][ki] + f32x4{__uint_as_float(old[ni][ki].x), __uint_as_float(old[ni][ki].y),
+                                                __uint_as_float(old[ni][ki].z), __uint_as_float(old[ni][ki].w)};
+            bstore16(wr, o[ni][ki], u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
+            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      } else {
+        const int slot = seg0 != 0 ? 0 : 1;
+        const unsigned base = (unsigned)(((long)c * 2 + slot) * TN_SLOT_FLOATS * 4);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int ki = 0; ki < 2; ++ki) {
+            const int nl = wn * 64 + ni * 16 + r15, kl = wk * 32 + ki * 16 + q * 4;
+            bstore16(sr, base + (unsigned)((nl * 128 + kl) * 4), u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
+                                                                      __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
+            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+      st1 = 8;
+      if (bias_tile) {   // partial column sums of this segment: float atomics straight into the bias gradient
+        float b = bsum;
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        const int n = n0 + wk * 16 + r15;
+        if (q == 0 && n < jb.N) atomicAdd(jb.dbias + n, b);
+      }
+      bsum = 0.f;
+    }
+    // advance the compute cursor (value selects: see gemm_nt_pipe_kernel on symmetric updates)
+    const int nls = cls + 1;
+    const bool jump = nls == WS && nls < total;          // whole tiles done: on to the remainder share
+    const bool moved = (jump || tile_end) && !range_end;
+    cgt = jump ? gt_rem : (tile_end ? cgt + 1 : cgt);
+    cm = jump ? m_rem : (tile_end ? 0 : cm + 1);
+    seg0 = jump ? m_rem : (tile_end ? 0 : seg0);
+    cls = nls;
+    if (moved) tn_locate_tile(g, cgt, cj, ctile);
+    issue_advance();
+    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
+  };
+  for (int gc = 0; gc < total; gc += 2) {
+    step(fa, fb);
+    if (gc + 1 < total) step(fb, fa);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Folds the partial sums of the remainder tiles cut by share boundaries into dW.  Block b looks at boundary c = b + 1 (between the
+// remainder shares of logical workgroups c-1 and c); it acts only if that boundary falls inside a tile AND is the first one inside.
+__global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g, const float* __restrict__ slabs, int G) {
+  const int c = blockIdx.x + 1;
+  const int S = g.S;
+  const int b = (int)((long)c * g.RS / G);
+  if (b >= g.RS) return;
+  const int mstep = b % S;
+  if (mstep == 0) return;                                   // the tile starts exactly at the boundary: not cut here
+  const int tile_start = b - mstep;
+  if ((int)((long)(c - 1) * g.RS / G) > tile_start) return;      // an earlier boundary already lies inside this tile
+  int j, tile;
+  tn_locate_tile(g, g.W * G + b / S, j, tile);
+  const TnJob& jb = g.job[j];
+  const int tile_endg = tile_start + S;
+  int clast = c;                                             // last workgroup touching the tile
+  while (clast + 1 < G && (int)((long)(clast + 1) * g.RS / G) < tile_endg) ++clast;
+  const int tk = tile % jb.tiles_k, tn = tile / jb.tiles_k;
+  // gridDim.y blocks share the tile's 4096 float4 (a remainder tile can be cut into a dozen pieces: one block alone would walk them
+  // all at a single CU's bandwidth)
+  const int per = (TN_SLOT_FLOATS / 4) / (int)gridDim.y;
+  for (int v = blockIdx.y * per + threadIdx.x; v < (blockIdx.y + 1) * per; v += 256) {
+    const int nl = v >> 5, kl = (v & 31) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + ((long)(c - 1) * 2 + 1) * TN_SLOT_FLOATS + v * 4);
+#pragma unroll 4
+    for (int cc = c; cc <= clast; ++cc) s += *reinterpret_cast<const f32x4*>(slabs + ((long)cc * 2 + 0) * TN_SLOT_FLOATS + v * 4);
+    const int n = tn * 128 + nl, k = tk * 128 + kl;
+    if (n < jb.N && k < jb.K) {
+      float* d = jb.dW + (long)n * jb.ldw + k;
+      *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -2036,6 +2318,54 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
   hipStream_t s = (hipStream_t)stream;
   return dtype == SPG_BF16 ? launch_nt<bf16_t>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s)
                            : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s);
+}
+
+extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus() * 2 * TN_SLOT_FLOATS * (long)sizeof(float); }
+
+extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW,
+                                 float* const* dbias, int M, const int* N, const int* K, const int* ldy, const int* ldx,
+                                 const int* ldw, void* workspace, long workspace_bytes, spg_stream_t stream) {
+  SPG_REQUIRE(dtype == SPG_BF16, "gemm_tn_group: bf16 only (dtype %d)", dtype);
+  SPG_REQUIRE(njobs >= 1 && njobs <= TN_GROUP_MAX, "gemm_tn_group: 1..%d problems, got %d", TN_GROUP_MAX, njobs);
+  SPG_REQUIRE(M > 0, "gemm_tn_group: empty M");
+  TnGroup g;
+  long tiles = 0;
+  for (int i = 0; i < njobs; ++i) {
+    SPG_REQUIRE(N[i] > 0 && K[i] > 0, "gemm_tn_group: empty problem %d", i);
+    SPG_REQUIRE(N[i] % 8 == 0 && K[i] % 8 == 0 && ldy[i] % 8 == 0 && ldx[i] % 8 == 0 && ldw[i] % 4 == 0 && ldy[i] >= N[i] && ldx[i] >= K[i] &&
+                    ldw[i] >= K[i],
+                "gemm_tn_group: problem %d: N, K, ldy, ldx must be multiples of 8 (ldw of 4) and leading dimensions >= extents", i);
+    SPG_REQUIRE((long)M * ldy[i] * 2 < 0xFFFFFFF0L && (long)M * ldx[i] * 2 < 0xFFFFFFF0L && (long)N[i] * ldw[i] * 4 < 0xFFFFFFF0L,
+                "gemm_tn_group: problem %d: operand larger than 4 GiB", i);
+    TnJob& jb = g.job[i];
+    jb.dY = dY[i]; jb.X = X[i]; jb.dW = dW[i]; jb.dbias = dbias ? dbias[i] : nullptr;
+    jb.N = N[i]; jb.K = K[i]; jb.ldy = ldy[i]; jb.ldx = ldx[i]; jb.ldw = ldw[i];
+    jb.tiles_k = cdiv(K[i], 128); jb.tiles = cdiv(N[i], 128) * jb.tiles_k;
+    jb.tile0 = (int)tiles;
+    tiles += jb.tiles;
+  }
+  for (int i = njobs; i < TN_GROUP_MAX; ++i) g.job[i] = g.job[njobs - 1];
+  const int S = cdiv(M, 64);
+  SPG_REQUIRE(tiles * S < 0x7FFFFFFFL, "gemm_tn_group: too many steps");
+  g.njobs = njobs; g.M = M; g.S = S; g.T = (int)tiles;
+  const long total_steps = tiles * S;
+  const int G = total_steps < num_cus() ? (int)total_steps : num_cus();
+  g.W = (int)(tiles / G);
+  g.RS = (int)((tiles - (long)g.W * G) * S);
+  const long need = (long)G * 2 * TN_SLOT_FLOATS * (long)sizeof(float);
+  SPG_REQUIRE(workspace && workspace_bytes >= need, "gemm_tn_group: workspace of %ld bytes needed (got %ld)", need, workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int LDSG = 4 * 32768;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  int rc = check_launch("gemm_tn_group");
+  if (rc || G < 2 || g.RS == 0) return rc;
+  hipLaunchKernelGGL(tn_group_reduce_kernel, dim3(G - 1, 8), dim3(256), 0, s, g, (const float*)workspace, G);
+  return check_launch("gemm_tn_group(reduce)");
 }
 
 extern "C" long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {

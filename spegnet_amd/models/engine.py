@@ -12,6 +12,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
 import torch
 import torch.nn.functional as F
 
@@ -43,6 +44,8 @@ class Engine:
         # Operands are held until join_wgrad(), which every backward piece calls before it returns.  Off by default: on one MI355X
         # the two chip-sized branches contend (226.0 vs 232.2 img/s, see engine/trainer.py).
         self.wgrad_async = False
+        self.group_wgrads = os.environ.get("SPG_TN_GROUP", "1") != "0"   # trunk blocks: one grouped wgrad launch per block
+        self._wg_jobs = None
         self._side = None
         self._held = []
         self._forked = False
@@ -149,7 +152,12 @@ class Engine:
                 residual: Optional[Tensor] = None, bias: bool = True) -> Optional[Tensor]:
         """dW += dy^T x, db += colsum(dy), returns dx = dy W (optionally * gelu'(h), + residual)."""
         gw, gb = self.grad(name + ".weight").view(dy.shape[-1], -1), (self.grad(name + ".bias") if bias else None)
-        self._wgrad(lambda: ops.gemm_tn(dy, x, gw, dbias=gb), dy, x)
+        if self._wg_jobs is not None:
+            # inside a trunk block: the weight gradient is only collected here; block_bwd issues the block's four wgrads as ONE
+            # grouped, CU-balanced launch (ops.gemm_tn_group) once the last of them is known
+            self._wg_jobs.append((dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]), gw, gb))
+        else:
+            self._wgrad(lambda: ops.gemm_tn(dy, x, gw, dbias=gb), dy, x)
         if not need_dx:
             return None
         return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual)
@@ -250,6 +258,7 @@ class Engine:
         hd = do // heads
         H, Wd = c["H"], c["W"]
         dx2 = dx2.reshape(-1, do)
+        self._wg_jobs = [] if self.group_wgrads else None
         # MLP
         dh = self.lin_bwd(p + "mlp.layers.1", dx2, c["g"], gelu_h=c["h"])
         dln2 = self.lin_bwd(p + "mlp.layers.0", dh, c["ln2"])
@@ -269,6 +278,9 @@ class Engine:
             dres = None
         else:
             dres = dx1
+        if self._wg_jobs is not None:
+            jobs, self._wg_jobs = self._wg_jobs, None
+            ops.gemm_tn_group(jobs)
         dx = ops.layernorm_bwd(dln1, c["x"], P[p + "norm1.weight"], c["mean1"], c["rstd1"], G(p + "norm1.weight"),
                                G(p + "norm1.bias"), dres=dres)
         return dx.view(B, H, Wd, dim)

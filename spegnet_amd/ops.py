@@ -129,6 +129,36 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
               1 if conv else 0, B, H, W, Ci, _stream())
 
 
+TN_GROUP_MAX = 8
+
+
+def gemm_tn_group(jobs) -> None:
+    """jobs: list of (dy[M,N], x[M,K], dw[N,K] f32, dbias[N] f32 or None), all dense.  dw += dy^T x and dbias += colsum(dy) for every
+    job; bf16 jobs sharing M go out as grouped, CU-balanced launches of up to 8 problems (spg_gemm_tn_group), anything else one by one."""
+    import ctypes
+    groups = {}
+    for dy, x, dw, db in jobs:
+        N, K = dy.shape[-1], x.shape[-1]
+        ok = (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and dy.is_contiguous() and
+              x.is_contiguous() and dw.is_contiguous() and dw.dtype == torch.float32 and dw.numel() == N * K)
+        if ok:
+            groups.setdefault(dy.numel() // N, []).append((dy, x, dw, db, N, K))
+        else:
+            gemm_tn(dy, x, dw, dbias=db)
+    if not groups:
+        return
+    wsb = _lib.load().spg_gemm_tn_group_workspace_bytes()
+    for M, group in groups.items():
+        for i in range(0, len(group), TN_GROUP_MAX):
+            part = group[i:i + TN_GROUP_MAX]
+            n = len(part)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=part[0][0].device)
+            P, I = ctypes.c_void_p * n, ctypes.c_int * n
+            Ns, Ks = I(*[j[4] for j in part]), I(*[j[5] for j in part])
+            _lib.call("spg_gemm_tn_group", SPG_BF16, n, P(*[_p(j[0]) for j in part]), P(*[_p(j[1]) for j in part]),
+                      P(*[_p(j[2]) for j in part]), P(*[_p(j[3]) for j in part]), M, Ns, Ks, Ns, Ks, Ks, _p(ws), wsb, _stream())
+
+
 def pack_matrix(src: Tensor, dtype: torch.dtype, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:
     R, C = src.shape
     if out is None:

@@ -114,6 +114,30 @@ def test_gemm_tn(ops, dt, M, N, K):
     check(db, dy.float().sum(0), tol(dt, 2e-5, 1e-4), "tn fused colsum")
 
 
+@pytest.mark.parametrize("shapes", [
+    [(4608, 576, 2304), (4608, 2304, 576), (4608, 576, 576), (4608, 1728, 576)],     # a stage-3 trunk block's four wgrads
+    [(300, 200, 144)],                                                                # one small ragged problem, fewer steps than CUs * 2
+    [(1000, 136, 72), (77, 432, 144), (5000, 1000, 200), (64, 16, 32), (130, 8, 8)],   # ragged N / K / M, tiles cut several times
+    [(9000, 128, 128)],                                                               # one tile shared by many workgroups
+])
+def test_gemm_tn_group(ops, shapes):
+    """Grouped stream-K wgrad: every problem's dW / dbias must match the per-problem reference, accumulating on top of what is there."""
+    dt = torch.bfloat16
+    jobs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, x = rnd(M, N, seed=10 + i).to(dt), rnd(M, K, seed=20 + i).to(dt)
+        dw0, db0 = rnd(N, K, seed=30 + i), rnd(N, seed=40 + i)
+        dw, db = dw0.clone(), (db0.clone() if i % 2 == 0 else None)
+        jobs.append((dy, x, dw, db))
+        refs.append((dw0 + dy.float().t() @ x.float(), (db0 + dy.float().sum(0)) if db is not None else None))
+    ops.gemm_tn_group(jobs)
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (rw, rb), shp in zip(jobs, refs, shapes):
+        check(dw, rw, tol(dt, 2e-5, 1e-2), f"group dW {shp}")
+        if db is not None:
+            check(db, rb, tol(dt, 2e-5, 1e-4), f"group dbias {shp}")
+
+
 def test_pack_matrix(ops):
     w = rnd(37, 53, seed=1)
     assert torch.equal(ops.pack_matrix(w, torch.float32), w)
