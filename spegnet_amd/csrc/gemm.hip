@@ -559,7 +559,9 @@ constexpr int PIPE_LDS_BYTES = PIPE_STAGES * DMA_STAGE_BYTES + 8 * PIPE_SLAB_BYT
 enum { PIPE_ACT_NONE = 0, PIPE_ACT_GELU = 1, PIPE_ACT_HH = 2 };   // none | C2 = preact, C = gelu(.) | C = (.) * gelu'(gelu_h)
 
 __device__ __forceinline__ void wait_vm(int n) {  // s_waitcnt vmcnt(<= n), n wave-uniform, n >= 8
-  if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if (n >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
   else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -1638,11 +1640,11 @@ __device__ __forceinline__ void tn_locate_tile(const TnGroup& g, int gt, int& j,
   tile = gt - g.job[j].tile0;
 }
 
-template <typename T>
+template <typename T, int DBG = 0>   // DBG 2: no MFMAs (times the fill + read pipeline alone; wrong results by construction)
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
   static_assert(sizeof(T) == 2, "bf16 only");
   using F = TnFrag<T>;
-  constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;
+  constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;   // (a 5th stage, 4 groups in flight, was measured: no gain -- the fill is bandwidth-, not latency-bound)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1753,7 +1755,8 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ms = i >> 3, r = i & 7, ni = r >> 1, ki = r & 1;
-      acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);
+      if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);
+      else asm volatile("" :: "v"(cur.b[ms][ki]), "v"(cur.a[ms][ni]));
       if (i < 12) read_frag(nxt, rst, i);
       if (i == 0) dma_addr(0);
       if (i == 1) dma_go(0, 0);
@@ -2361,6 +2364,12 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     attr = true;
   }
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("SPG_TN_GROUP_DEBUG"); dbg = e ? atoi(e) : 0; }
+  if (dbg == 2) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else
   hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   int rc = check_launch("gemm_tn_group");
   if (rc || G < 2 || g.RS == 0) return rc;
