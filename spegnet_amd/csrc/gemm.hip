@@ -1892,6 +1892,321 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_tn_wide_kernel: the grouped wgrad kernel with 256 x 128 (n x k) or 128 x 256 macro-tiles, chosen per problem on the host.
+// The grouped 128 x 128 kernel is fill-bound (81 of 99 us without any MFMA): a macro-tile moves 48 KiB per 64-row
+// step for twice the FLOPs of a 32 KiB 128 x 128 step, i.e. 0.75x the LDS-fill and panel re-read bytes per FLOP.
+// Stage = three [64 m][128] sub-tiles (48 KiB): wide-n: dY cols n0..+127, dY cols n0+128..+255, X cols k0..+127;
+//                                                wide-k: dY cols n0..+127, X cols k0..+127, X cols k0+128..+255.
+// 3 stages (144 KiB), two groups in flight; 8 waves as 4 (n) x 2 (k) or 2 x 4, wave tile 64 x 64 (32 MFMAs, 16 fragments per step).
+// MEASURED (tools/tn_group_bench.py): not faster than the 128 x 128 kernel where it matters -- its fill pipeline alone (no MFMAs)
+// takes 87.7 us for 484 MB on a stage-3 block against 81 us for 633 MB: with only two 48 KiB groups in flight per CU the sustained
+// fill rate drops (5.5 vs 7.8 TB/s aggregate), so fewer bytes per FLOP do not become less time.  Kept opt-in.  One lane offset per fragment: its second transpose read (+4 rows) and its second k-half
+// (+32 rows) keep the row swizzle, so they are immediates (+1 KiB, +8 KiB).  Schedule, slabs and reduce as in gemm_tn_group_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int TNW_SLOT_FLOATS = 256 * 128;
+struct TnwJob {
+  const void* dY; const void* X; float* dW; float* dbias;
+  int N, K, ldy, ldx, ldw;
+  int wide_n;                 // 1: 256 (n) x 128 (k) macro-tiles, 0: 128 x 256
+  int tiles_k, tiles, tile0;
+};
+struct TnwGroup {
+  TnwJob job[TN_GROUP_MAX];
+  int njobs, M, S, T, W, RS;
+};
+__device__ __forceinline__ void tnw_locate_tile(const TnwGroup& g, int gt, int& j, int& tile) {
+  j = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.njobs; ++i) if (gt >= g.job[i].tile0) j = i;
+  tile = gt - g.job[j].tile0;
+}
+
+template <typename T, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnwGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  using F = TnFrag<T>;
+  constexpr int MSTEP = 64, STAGES = 3, SUB_B = 16384, STAGE_B = 3 * SUB_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = (int)gridDim.x;
+  const int c = xcd_remap(blockIdx.x, G);
+  const int S = g.S;
+  const int WS = g.W * S;
+  const int rb = (int)((long)c * g.RS / G), re = (int)((long)(c + 1) * g.RS / G);
+  const int total = WS + (re - rb);
+  if (total <= 0) return;
+  const int gt_first = WS > 0 ? c * g.W : g.W * G + rb / S;
+  const int m_first = WS > 0 ? 0 : rb % S;
+  const int gt_rem = g.W * G + rb / S, m_rem = rb % S;
+  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
+
+  // ---- DMA issue stream: a wave moves pieces {wave, wave + 8} of each of the three sub-tiles per step
+  const int lrow = lane >> 4, lpc = lane & 15;
+  const int prow0 = wave * 4 + lrow;
+  const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;
+  int is_job = -1, is_gt = gt_first, is_tile, is_mstep = m_first, is_ls = 0, is_slot = 0, is_ndy = 1;
+  bool is_live = true;
+  bool sin[3] = {false, false, false};           // the sub-tile's 8 columns of this lane are inside the matrix
+  unsigned soff[3] = {0u, 0u, 0u}, sstride[3] = {0u, 0u, 0u}, s32[3] = {0u, 0u, 0u};
+  rsrc_words_t yr, xr;
+  auto is_enter_tile = [&]() __attribute__((always_inline)) {
+    int j;
+    tnw_locate_tile(g, is_gt, j, is_tile);
+    const TnwJob& jb = g.job[j];
+    if (j != is_job) {
+      is_job = j;
+      yr = make_rsrc_words(jb.dY, (unsigned)((long)g.M * jb.ldy * 2));
+      xr = make_rsrc_words(jb.X, (unsigned)((long)g.M * jb.ldx * 2));
+      is_ndy = jb.wide_n ? 2 : 1;
+    }
+    const int tk = is_tile % jb.tiles_k, tn = is_tile / jb.tiles_k;
+    const int n0 = tn * (jb.wide_n ? 256 : 128), k0 = tk * (jb.wide_n ? 128 : 256);
+    const long m0 = (long)is_mstep * MSTEP + prow0;
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) {
+      const bool isy = sb < is_ndy;
+      const int col = (isy ? n0 + 128 * sb : k0 + 128 * (sb - is_ndy)) + fcol;
+      const int ld = isy ? jb.ldy : jb.ldx;
+      soff[sb] = (unsigned)((m0 * ld + col) * 2);
+      sstride[sb] = (unsigned)(MSTEP * ld * 2);
+      s32[sb] = (unsigned)(32 * ld * 2);
+      sin[sb] = col < (isy ? jb.N : jb.K);
+    }
+  };
+  is_enter_tile();
+  unsigned dof[3][2];
+  auto dma_addr = [&](int sb) __attribute__((always_inline)) {   // rows past M fall outside the descriptors: hardware zero fill
+    dof[sb][0] = (is_live && sin[sb]) ? soff[sb] : OOB;
+    dof[sb][1] = (is_live && sin[sb]) ? soff[sb] + s32[sb] : OOB;
+  };
+  auto dma_go = [&](int sb, int h) __attribute__((always_inline)) {
+    const unsigned st = smem_base + is_slot * STAGE_B + sb * SUB_B + (h * 8 + wave) * 1024;
+    if (sb < is_ndy) dma16_asm(yr, st, dof[sb][h]); else dma16_asm(xr, st, dof[sb][h]);
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) soff[sb] += sstride[sb];
+    ++is_ls;
+    const bool tile_end = is_mstep + 1 == S;
+    if (is_ls >= total) is_live = false;
+    else if (is_ls == WS) { is_gt = gt_rem; is_mstep = m_rem; is_enter_tile(); }
+    else if (tile_end) { is_gt = is_gt + 1; is_mstep = 0; is_enter_tile(); }
+    else is_mstep = is_mstep + 1;
+  };
+
+  // ---- fragments: a = dY (n) blocks, b = X (k) blocks of this wave's 64 x 64 tile; one byte offset per fragment
+  int oa[4], ob[4];
+  int wn = 0, wk = 0;
+  auto set_wave_layout = [&](int wide_n) __attribute__((always_inline)) {
+    wn = wide_n ? (wave & 3) : (wave & 1);
+    wk = wide_n ? (wave >> 2) : (wave >> 1);
+    const int ndy = wide_n ? 2 : 1;
+    const int ncol = 64 * wn, kcol = 64 * wk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int o0, o1;
+      F::offsets(0, (ncol & 127) + i * 16, lane, o0, o1);
+      oa[i] = (ncol >> 7) * SUB_B + o0;
+      F::offsets(0, (kcol & 127) + i * 16, lane, o0, o1);
+      ob[i] = (ndy + (kcol >> 7)) * SUB_B + o0;
+    }
+  };
+  // fragments are NOT double-buffered across steps here (acc 64 + 2 x 64 fragment registers spilled inside the loop): the kernel
+  // is fill-bound, so a step reads its first k-half up front and hides the second k-half's reads behind the first half's MFMAs
+  struct Frags { typename F::Frag a[2][4], b[2][4]; };
+  Frags fr;
+  auto read_frag = [&](const char* st, int idx) __attribute__((always_inline)) {   // idx 0..15: per k-half {b0..b3, a0..a3}
+    const int sx = idx >> 3, r = idx & 7;
+    const int o = (r < 4 ? ob[r] : oa[r - 4]) + sx * 8192;       // second k-half: +32 rows, same swizzle
+    const typename F::Frag v = F::load_at(st, o, o + 1024);      // second read: +4 rows, same swizzle
+    if (r < 4) fr.b[sx][r] = v; else fr.a[sx][r - 4] = v;
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+
+  // ---- compute cursor
+  int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;
+  int cj, ctile;
+  tnw_locate_tile(g, cgt, cj, ctile);
+  set_wave_layout(g.job[cj].wide_n);
+
+  // ---- prologue: two groups in flight
+  for (int i = 0; i < STAGES - 1; ++i) {
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) { dma_addr(sb); dma_go(sb, 0); dma_go(sb, 1); }
+    issue_advance();
+  }
+
+  int rd_slot = 0, st1 = 0, st2 = 0;
+  const int r15 = lane & 15, q = lane >> 4;
+  auto mma_block = [&](auto BIAS_) __attribute__((always_inline)) {
+    constexpr bool BIAS = decltype(BIAS_)::value;
+    const char* rst = smem + rd_slot * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_frag(rst, i);             // k-half 0 of this step (exposed)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int ms = i >> 4, r = i & 15, ni = r >> 2, ki = r & 3;
+      if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(fr.b[ms][ki], fr.a[ms][ni], acc[ni][ki]);     // D[k][n]
+      else asm volatile("" :: "v"(fr.b[ms][ki]), "v"(fr.a[ms][ni]));
+      if (i < 8) read_frag(rst, 8 + i);                          // k-half 1 behind the first half's MFMAs
+      if (i == 8) dma_addr(0);
+      if (i == 9) dma_go(0, 0);
+      if (i == 10) dma_go(0, 1);
+      if (i == 11) dma_addr(1);
+      if (i == 12) dma_go(1, 0);
+      if (i == 13) dma_go(1, 1);
+      if (i == 14) dma_addr(2);
+      if (i == 15) dma_go(2, 0);
+      if (i == 16) dma_go(2, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (BIAS) {
+      // column sums of dY from the fragments just multiplied: the waves sharing an n range split its four 16-column blocks
+      const bool two = g.job[cj].wide_n != 0;       // wide-n: 2 waves per n range -> 2 blocks each; wide-k: 4 waves -> 1 block each
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int blk = two ? 2 * wk + h : wk;
+          if (h == 0 || two) {
+            const typename F::Frag v = blk == 0 ? fr.a[ms][0] : (blk == 1 ? fr.a[ms][1] : (blk == 2 ? fr.a[ms][2] : fr.a[ms][3]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bf16x2_t pr = {v[2 * e], v[2 * e + 1]};
+              bsum[h] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum[h], false);
+            }
+          }
+        }
+    }
+  };
+  auto step = [&]() __attribute__((always_inline)) {
+    // stage gc landed: one younger group (6 pieces) + the last two steps' flush stores (16 each) may stay outstanding
+    if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    st2 = st1; st1 = 0;
+    const TnwJob& jb = g.job[cj];
+    const int tk = ctile % jb.tiles_k, tn = ctile / jb.tiles_k;
+    const bool bias_tile = jb.dbias != nullptr && tk == 0;
+    if (bias_tile) mma_block(std::true_type{}); else mma_block(std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
+    const bool range_end = cls + 1 == total;
+    if (tile_end || range_end) {
+      const int TNn = jb.wide_n ? 256 : 128, TNk = jb.wide_n ? 128 : 256;
+      const int n0 = tn * TNn + wn * 64, k0 = tk * TNk + wk * 64;
+      if (seg0 == 0 && tile_end) {
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(jb.dW, (unsigned)((long)jb.N * jb.ldw * 4));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {       // one n block at a time: 4 loads in flight, 16 VGPRs
+          u32x4 old[4];
+          unsigned o[4];
+#pragma unroll
+          for (int ki = 0; ki < 4; ++ki) {
+            const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
+            o[ki] = (n < jb.N && k < jb.K) ? (unsigned)(((long)n * jb.ldw + k) * 4) : OOB;
+            old[ki] = bload16(wr, o[ki]);
+          }
+#pragma unroll
+          for (int ki = 0; ki < 4; ++ki) {
+            const f32x4 v = acc[ni][ki] + f32x4{__uint_as_float(old[ki].x), __uint_as_float(old[ki].y), __uint_as_float(old[ki].z),
+                                                __uint_as_float(old[ki].w)};
+            bstore16(wr, o[ki], u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
+            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      } else {
+        const int slot = seg0 != 0 ? 0 : 1;
+        const unsigned base = (unsigned)(((long)c * 2 + slot) * TNW_SLOT_FLOATS * 4);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int ki = 0; ki < 4; ++ki) {
+            const int nl = wn * 64 + ni * 16 + r15, kl = wk * 64 + ki * 16 + q * 4;
+            bstore16(sr, base + (unsigned)((nl * TNk + kl) * 4), u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
+                                                                       __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
+            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+      st1 = 16;
+      if (bias_tile) {
+        const bool two = jb.wide_n != 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (h == 0 || two) {
+            float b = bsum[h];
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+            const int n = n0 + (two ? 2 * wk + h : wk) * 16 + r15;
+            if (q == 0 && n < jb.N) atomicAdd(jb.dbias + n, b);
+          }
+        }
+      }
+      bsum[0] = 0.f; bsum[1] = 0.f;
+    }
+    const int nls = cls + 1;
+    const bool jump = nls == WS && nls < total;
+    const bool moved = (jump || tile_end) && !range_end;
+    cgt = jump ? gt_rem : (tile_end ? cgt + 1 : cgt);
+    cm = jump ? m_rem : (tile_end ? 0 : cm + 1);
+    seg0 = jump ? m_rem : (tile_end ? 0 : seg0);
+    cls = nls;
+    issue_advance();
+    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
+    if (moved) {
+      const int pj = cj;
+      tnw_locate_tile(g, cgt, cj, ctile);
+      if (g.job[cj].wide_n != g.job[pj].wide_n) set_wave_layout(g.job[cj].wide_n);   // next step reads with the new wave layout
+    }
+  };
+  for (int gc = 0; gc < total; ++gc) step();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(256) void tnw_reduce_kernel(TnwGroup g, const float* __restrict__ slabs, int G) {
+  const int c = blockIdx.x + 1;
+  const int S = g.S;
+  const int b = (int)((long)c * g.RS / G);
+  if (b >= g.RS) return;
+  const int mstep = b % S;
+  if (mstep == 0) return;
+  const int tile_start = b - mstep;
+  if ((int)((long)(c - 1) * g.RS / G) > tile_start) return;
+  int j, tile;
+  tnw_locate_tile(g, g.W * G + b / S, j, tile);
+  const TnwJob& jb = g.job[j];
+  const int tile_endg = tile_start + S;
+  int clast = c;
+  while (clast + 1 < G && (int)((long)(clast + 1) * g.RS / G) < tile_endg) ++clast;
+  const int TNn = jb.wide_n ? 256 : 128, TNk = jb.wide_n ? 128 : 256;
+  const int tk = tile % jb.tiles_k, tn = tile / jb.tiles_k;
+  const int per = (TNW_SLOT_FLOATS / 4) / (int)gridDim.y;
+  const int kq = TNk / 4;                                   // float4 per slab row
+  for (int v = blockIdx.y * per + threadIdx.x; v < (blockIdx.y + 1) * per; v += 256) {
+    const int nl = v / kq, kl = (v - nl * kq) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + ((long)(c - 1) * 2 + 1) * TNW_SLOT_FLOATS + v * 4);
+#pragma unroll 4
+    for (int cc = c; cc <= clast; ++cc) s += *reinterpret_cast<const f32x4*>(slabs + ((long)cc * 2 + 0) * TNW_SLOT_FLOATS + v * 4);
+    const int n = tn * TNn + nl, k = tk * TNk + kl;
+    if (n < jb.N && k < jb.K) {
+      float* d = jb.dW + (long)n * jb.ldw + k;
+      *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -2323,7 +2638,7 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
                            : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s);
 }
 
-extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus() * 2 * TN_SLOT_FLOATS * (long)sizeof(float); }
+extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus() * 2 * TNW_SLOT_FLOATS * (long)sizeof(float); }   // covers both kernels
 
 extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW,
                                  float* const* dbias, int M, const int* N, const int* K, const int* ldy, const int* ldx,
@@ -2331,6 +2646,57 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   SPG_REQUIRE(dtype == SPG_BF16, "gemm_tn_group: bf16 only (dtype %d)", dtype);
   SPG_REQUIRE(njobs >= 1 && njobs <= TN_GROUP_MAX, "gemm_tn_group: 1..%d problems, got %d", TN_GROUP_MAX, njobs);
   SPG_REQUIRE(M > 0, "gemm_tn_group: empty M");
+  static int wide = -1;
+  // opt-in (SPG_TN_GROUP_WIDE=1): measured no faster than the 128 x 128 grouped kernel on the stage-3 / stage-4 blocks (97.1 vs 96.5,
+  // 96.7 vs 92.6 us), better only at stage 1 (139 vs 157 us) -- see the kernel's header and DESIGN.md 3.1
+  if (wide < 0) { const char* e = getenv("SPG_TN_GROUP_WIDE"); wide = e ? atoi(e) : 0; }
+  if (wide) {
+    TnwGroup gw;
+    long wtiles = 0;
+    for (int i = 0; i < njobs; ++i) {
+      SPG_REQUIRE(N[i] > 0 && K[i] > 0, "gemm_tn_group: empty problem %d", i);
+      SPG_REQUIRE(N[i] % 8 == 0 && K[i] % 8 == 0 && ldy[i] % 8 == 0 && ldx[i] % 8 == 0 && ldw[i] % 4 == 0 && ldy[i] >= N[i] && ldx[i] >= K[i] &&
+                      ldw[i] >= K[i],
+                  "gemm_tn_group: problem %d: N, K, ldy, ldx must be multiples of 8 (ldw of 4) and leading dimensions >= extents", i);
+      SPG_REQUIRE((long)M * ldy[i] * 2 < 0xFFFFFFF0L && (long)M * ldx[i] * 2 < 0xFFFFFFF0L && (long)N[i] * ldw[i] * 4 < 0xFFFFFFF0L,
+                  "gemm_tn_group: problem %d: operand larger than 4 GiB", i);
+      TnwJob& jb = gw.job[i];
+      jb.dY = dY[i]; jb.X = X[i]; jb.dW = dW[i]; jb.dbias = dbias ? dbias[i] : nullptr;
+      jb.N = N[i]; jb.K = K[i]; jb.ldy = ldy[i]; jb.ldx = ldx[i]; jb.ldw = ldw[i];
+      const long tn_ = (long)cdiv(N[i], 256) * cdiv(K[i], 128), tk_ = (long)cdiv(N[i], 128) * cdiv(K[i], 256);
+      jb.wide_n = (tn_ < tk_ || (tn_ == tk_ && N[i] >= K[i])) ? 1 : 0;     // the orientation with fewer (less padded) macro-tiles
+      jb.tiles_k = jb.wide_n ? cdiv(K[i], 128) : cdiv(K[i], 256);
+      jb.tiles = (int)(jb.wide_n ? tn_ : tk_);
+      jb.tile0 = (int)wtiles;
+      wtiles += jb.tiles;
+    }
+    for (int i = njobs; i < TN_GROUP_MAX; ++i) gw.job[i] = gw.job[njobs - 1];
+    const int S = cdiv(M, 64);
+    SPG_REQUIRE(wtiles * S < 0x7FFFFFFFL, "gemm_tn_group: too many steps");
+    gw.njobs = njobs; gw.M = M; gw.S = S; gw.T = (int)wtiles;
+    const long total_steps = wtiles * S;
+    const int G = total_steps < num_cus() ? (int)total_steps : num_cus();
+    gw.W = (int)(wtiles / G);
+    gw.RS = (int)((wtiles - (long)gw.W * G) * S);
+    const long need = (long)G * 2 * TNW_SLOT_FLOATS * (long)sizeof(float);
+    SPG_REQUIRE(workspace && workspace_bytes >= need, "gemm_tn_group: workspace of %ld bytes needed (got %ld)", need, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int LDSW = 3 * 3 * 16384;
+    static int dbgw = -1;
+    if (dbgw < 0) { const char* e = getenv("SPG_TN_GROUP_DEBUG"); dbgw = e ? atoi(e) : 0; }
+    static bool attrw = false;
+    if (!attrw) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<bf16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
+      attrw = true;
+    }
+    if (dbgw == 2) hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
+    else hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 0>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
+    int rc = check_launch("gemm_tn_group(wide)");
+    if (rc || G < 2 || gw.RS == 0) return rc;
+    hipLaunchKernelGGL(tnw_reduce_kernel, dim3(G - 1, 16), dim3(256), 0, s, gw, (const float*)workspace, G);
+    return check_launch("gemm_tn_group(wide reduce)");
+  }
   TnGroup g;
   long tiles = 0;
   for (int i = 0; i < njobs; ++i) {
