@@ -2407,8 +2407,9 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
         static int defer_on = -1;
         if (defer_on < 0) { const char* e = getenv("SPG_GEMM_DEFER"); defer_on = e ? atoi(e) : 0; }
         const bool defer = defer_on && K > 2 * (ROWB / (int)sizeof(T));
-        if ((dbg == 1 || dbg == 3 || dbg == 4 || dbg == 8 || dbg == 9) && !conv && nb == 4 && pact == PIPE_ACT_NONE) {
+        if ((dbg == 1 || dbg == 2 || dbg == 3 || dbg == 4 || dbg == 8 || dbg == 9) && !conv && nb == 4 && pact == PIPE_ACT_NONE) {
           if (dbg == 1) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 1); else if (dbg == 3) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 3);
+          else if (dbg == 2) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 2);
           else if (dbg == 8) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 8); else if (dbg == 9) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 9);
           else SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 4);
         } else if (conv) { if (defer) SPG_LAUNCHP_NB(true, PIPE_ACT_NONE, true); else SPG_LAUNCHP_NB(true, PIPE_ACT_NONE, false); }
