@@ -102,6 +102,11 @@ int spg_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, in
 /* patch embedding input gather: image f32/T NCHW [B,3,S,S] -> im2col rows [B*(S/4)^2, Kpad] (k = c*49+ky*7+kx,
  * zero padded to Kpad), so that patch-embed is a spg_gemm_nt; pos-embed add is the GEMM's residual.          */
 int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int S, int Kpad, spg_stream_t stream);
+/* device input pipeline (reference: CODImageProcessor.process_image, utils/image_processor.py:118-131): uint8 HWC [H,W,3] (device) ->
+ * float / 255 -> antialiased bilinear resize to OH x OW (ATen _upsample_bilinear2d_aa, align_corners = false) -> (v - mean) / std,
+ * written as f32 CHW [3,OH,OW].  mean3 / std3 are HOST arrays of three floats.                                                   */
+int spg_preprocess_image(const uint8_t* img_hwc, float* out_chw, int H, int W, int OH, int OW, const float* mean3, const float* std3,
+                         spg_stream_t stream);
 
 /* ---- column reductions / elementwise (HBM-bound) -----------------------------------------------------------
  * colsum: out[c] += sum_m x[m][c] (f32 atomics; bias gradients).  gap_sum / chan_prod_sum: the same per image. */

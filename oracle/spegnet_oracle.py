@@ -452,3 +452,12 @@ def train_step(sd: SD, opt_state: dict, images, masks, edges, loss_cfg=LOSS_DEFA
     for p in params.values():
         p.requires_grad_(False)
     return {k: float(v) for k, v in losses.items()}, float(total), grads
+
+
+def preprocess_image(img_u8_hwc: torch.Tensor, size, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
+    """CODImageProcessor.process_image after decoding (reference utils/image_processor.py:118-131): uint8 HWC -> float / 255 ->
+    F.interpolate(bilinear, align_corners=False, antialias=True) -> (v - mean) / std.  CPU, fp32."""
+    t = img_u8_hwc.cpu().float().permute(2, 0, 1) / 255.0
+    size = (size, size) if isinstance(size, int) else tuple(size)
+    t = F.interpolate(t[None], size=size, mode="bilinear", align_corners=False, antialias=True)[0]
+    return (t - torch.tensor(mean).view(-1, 1, 1)) / torch.tensor(std).view(-1, 1, 1)

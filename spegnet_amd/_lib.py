@@ -32,6 +32,7 @@ SIGNATURES = {
     "spg_maxpool2_fwd": "ippp" "iiiiiip",
     "spg_maxpool2_bwd": "ippp" "iiiiiip",
     "spg_patch_im2col": "ipp" "iiip",
+    "spg_preprocess_image": "pp" "iiii" "ppp",
     "spg_colsum": "ipp" "iiip",
     "spg_gap_sum": "ipp" "ilip",
     "spg_chan_prod_sum": "ippp" "ilip",

@@ -606,6 +606,62 @@ extern "C" int spg_patch_im2col(int dtype, const float* img, void* cols, int B, 
   else hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, S, Kpad);
   return check_launch("patch_im2col");
 }
+// ---------------------------------------------------------------------------------------------------
+// Input pipeline on the device: uint8 HWC image -> float / 255 -> antialiased bilinear resize -> (v - mean) / std
+// in one kernel; output f32 [3, OH, OW] (the reference's layout, utils/image_processor.py:118-131).  The resize is ATen's
+// _upsample_bilinear2d_aa (what F.interpolate(mode='bilinear', align_corners=False, antialias=True) runs): separable triangle
+// filter whose support grows with the down-scale factor; horizontal pass first, then vertical, weights normalised per output index.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void aa_taps(int i, float scale, int in_size, int& lo, int& n, float& center, float& invscale) {
+  const float support = scale >= 1.f ? scale : 1.f;
+  invscale = scale >= 1.f ? 1.f / scale : 1.f;
+  center = scale * ((float)i + 0.5f);
+  lo = max((int)(center - support + 0.5f), 0);
+  n = min((int)(center + support + 0.5f), in_size) - lo;
+}
+__device__ __forceinline__ float aa_tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
+
+__global__ __launch_bounds__(256) void preprocess_image_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int H, int W, int OH,
+                                                               int OW, float m0, float m1, float m2, float is0, float is1, float is2) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= OH * OW) return;
+  const int oy = idx / OW, ox = idx - oy * OW;
+  const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+  int ylo, yn, xlo, xn;
+  float yc, yinv, xc, xinv;
+  aa_taps(oy, sy, H, ylo, yn, yc, yinv);
+  aa_taps(ox, sx, W, xlo, xn, xc, xinv);
+  float wxs = 0.f, wys = 0.f;
+  for (int i = 0; i < xn; ++i) wxs += aa_tri(((float)(i + xlo) - xc + 0.5f) * xinv);
+  for (int j = 0; j < yn; ++j) wys += aa_tri(((float)(j + ylo) - yc + 0.5f) * yinv);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int j = 0; j < yn; ++j) {
+    const float wy = aa_tri(((float)(j + ylo) - yc + 0.5f) * yinv) / wys;
+    const uint8_t* row = img + ((long)(ylo + j) * W + xlo) * 3;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;                      // the horizontal pass of this input row
+    for (int i = 0; i < xn; ++i) {
+      const float wx = aa_tri(((float)(i + xlo) - xc + 0.5f) * xinv) / wxs;
+      r0 += wx * ((float)row[3 * i] / 255.f);
+      r1 += wx * ((float)row[3 * i + 1] / 255.f);
+      r2 += wx * ((float)row[3 * i + 2] / 255.f);
+    }
+    a0 += wy * r0; a1 += wy * r1; a2 += wy * r2;
+  }
+  const long plane = (long)OH * OW;
+  out[idx] = (a0 - m0) * is0;
+  out[plane + idx] = (a1 - m1) * is1;
+  out[2 * plane + idx] = (a2 - m2) * is2;
+}
+
+extern "C" int spg_preprocess_image(const uint8_t* img_hwc, float* out_chw, int H, int W, int OH, int OW, const float* mean3,
+                                    const float* std3, spg_stream_t stream) {
+  SPG_REQUIRE(H > 0 && W > 0 && OH > 0 && OW > 0 && mean3 && std3, "preprocess_image: bad sizes %dx%d -> %dx%d", H, W, OH, OW);
+  SPG_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "preprocess_image: zero std");
+  hipLaunchKernelGGL(preprocess_image_kernel, dim3(cdiv((long)OH * OW, 256)), dim3(256), 0, (hipStream_t)stream, img_hwc, out_chw, H, W, OH, OW,
+                     mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  return check_launch("preprocess_image");
+}
+
 extern "C" int spg_se_fc(const float* gap, const float* w1, const float* w2, float* hidden, float* scale, int B, int C, int R,
                          spg_stream_t stream) {
   hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, C, R);

@@ -248,6 +248,20 @@ def patch_im2col(img: Tensor, dtype: torch.dtype, kpad: int) -> Tensor:
     return cols
 
 
+def preprocess_image(img_u8_hwc: Tensor, size, mean, std) -> Tensor:
+    """uint8 [H,W,3] on the device -> f32 [3,OH,OW]: /255, antialiased bilinear resize, (v - mean) / std (one kernel).
+    Mirrors CODImageProcessor.process_image of the reference (utils/image_processor.py:118-131)."""
+    import ctypes
+    assert img_u8_hwc.dtype == torch.uint8 and img_u8_hwc.dim() == 3 and img_u8_hwc.shape[2] == 3, img_u8_hwc.shape
+    OH, OW = (size, size) if isinstance(size, int) else size
+    H, W, _ = img_u8_hwc.shape
+    out = torch.empty((3, OH, OW), dtype=torch.float32, device=img_u8_hwc.device)
+    F3 = ctypes.c_float * 3
+    _lib.call("spg_preprocess_image", _p(_c(img_u8_hwc)), _p(out), H, W, OH, OW, F3(*[float(v) for v in mean]), F3(*[float(v) for v in std]),
+              _stream())
+    return out
+
+
 # ---- reductions / elementwise ---------------------------------------------------------------------------
 def colsum(x: Tensor, out: Tensor) -> None:
     C = x.shape[-1]

@@ -1,6 +1,7 @@
 """Host-side image pre-processing for Predictor (reference utils/image_processor.py:48-212): PIL RGB -> float/255 ->
 antialiased bilinear resize to SxS -> ImageNet normalisation; masks / edges -> {0,1} at their original size.
-This is I/O-side host code (outside the kernel scope), kept so the predictor entry point works."""
+This is I/O-side host code (outside the kernel scope), kept so the predictor entry point works;
+process_image_device is the fused HIP version of the same arithmetic."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -36,6 +37,18 @@ class CODImageProcessor:
         t = torch.from_numpy(np.array(img)).float().permute(2, 0, 1) / 255.0
         t = F.interpolate(t[None], size=self.target_size, mode='bilinear', align_corners=False, antialias=True)[0]
         return (t - self.norm_mean) / self.norm_std
+
+    @torch.no_grad()
+    def process_image_device(self, image_path: Union[str, Path], device="cuda") -> torch.Tensor:
+        """Same result as process_image, computed on the GPU: the decoded uint8 HWC image is uploaded as is (3 bytes per pixel) and
+        one HIP kernel does /255, the antialiased resize and the normalisation (ops.preprocess_image)."""
+        from .. import ops
+        try:
+            img = Image.open(str(image_path)).convert('RGB')
+        except Exception as e:
+            raise RuntimeError(f"Failed to process image {image_path}: {e}")
+        u8 = torch.from_numpy(np.array(img)).to(device, non_blocking=True)
+        return ops.preprocess_image(u8, self.target_size, self.norm_mean.flatten().tolist(), self.norm_std.flatten().tolist())
 
     @torch.no_grad()
     def process_mask(self, path: Union[str, Path]) -> torch.Tensor:

@@ -3,7 +3,7 @@
     python tests/golden/make_golden.py
 
 It imports the reference's own importable modules from /root/reference (never copied into this repo)
--- models/feature_integration.py, models/object_detection.py, utils/loss_functions.py -- runs them on
+-- models/feature_integration.py, models/object_detection.py, utils/loss_functions.py, utils/image_processor.py -- runs them on
 seeded inputs with a seeded state_dict (oracle.init_state_dict, regenerated at test time, so only the
 OUTPUTS are stored) and records what they return.  For the Hiera trunk, whose code lives in the absent
 third-party `sam2` package, it records the outputs of transformers' independent Sam2HieraDetModel
@@ -183,16 +183,40 @@ def gen_trunk():
     torch.save(out, os.path.join(HERE, "trunk_hf.pt"))
 
 
+def gen_preprocess():
+    """The reference's own CODImageProcessor.process_image (utils/image_processor.py:94-134) on two small synthetic PNGs written to a
+    temporary directory: stores the decoded uint8 pixels (the INPUT of the arithmetic) and the tensor the reference returns."""
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, REF)
+    from utils.image_processor import CODImageProcessor
+    sys.path.pop(0)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, (H, W, S) in {"down": (97, 131, 64), "up": (40, 56, 64)}.items():
+            g = torch.Generator().manual_seed(H + W)
+            px = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+            path = os.path.join(d, name + ".png")
+            Image.fromarray(px.numpy()).save(path)
+            proc = CODImageProcessor(target_size=S)
+            out[name] = {"pixels": px, "size": S, "out": proc.process_image(path).clone()}
+    torch.save(out, os.path.join(HERE, "preprocess.pt"))
+    print("preprocess.pt", {k: tuple(v["out"].shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["head", "loss", "trunk"]
+    which = sys.argv[1:] or ["head", "loss", "trunk", "preprocess"]
     if "head" in which:
         gen_head()
     if "loss" in which:
         gen_loss()
     if "trunk" in which:
         gen_trunk()
+    if "preprocess" in which:
+        gen_preprocess()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -61,3 +61,21 @@ def test_trainer_process_batch_ragged_and_fixed():
     assert float(m3["loss"]) > 0
     groups = tr._get_param_groups()
     assert [g["weight_decay"] for g in groups] == [0.0, 0.0, 1e-5, 0.0] and abs(groups[0]["lr"] - 5e-6) < 1e-12
+
+
+def test_image_processor_device_path_matches_host_path(tmp_path):
+    """CODImageProcessor.process_image_device (decode on the host, one HIP kernel for /255 + antialiased resize + normalise) returns
+    what process_image (the reference's torch arithmetic on the CPU) returns for the same file."""
+    import numpy as np
+    from PIL import Image
+    from spegnet_amd.utils.image_processor import CODImageProcessor
+    g = torch.Generator().manual_seed(5)
+    px = torch.randint(0, 256, (333, 517, 3), generator=g, dtype=torch.uint8)
+    path = tmp_path / "img.png"
+    Image.fromarray(px.numpy()).save(str(path))
+    proc = CODImageProcessor(target_size=384)
+    host = proc.process_image(path)
+    dev = proc.process_image_device(path)
+    assert dev.is_cuda and dev.shape == host.shape == (3, 384, 384)
+    assert float((dev.cpu() - host).abs().max()) < 5e-6
+

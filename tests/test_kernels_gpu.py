@@ -138,6 +138,20 @@ def test_gemm_tn_group(ops, shapes):
             check(db, rb, tol(dt, 2e-5, 1e-4), f"group dbias {shp}")
 
 
+@pytest.mark.parametrize("H,W,S", [(600, 800, 384), (1033, 777, 384), (200, 300, 384), (384, 384, 384), (2000, 1500, (352, 416))])
+def test_preprocess_image_matches_reference_arithmetic(ops, H, W, S):
+    """Device input pipeline (uint8 HWC -> /255 -> antialiased bilinear resize -> normalise) against the oracle's restatement of
+    CODImageProcessor.process_image (same torch call as the reference, on CPU): down-scale, up-scale, identity, non-square."""
+    from oracle import spegnet_oracle as O
+    g = torch.Generator().manual_seed(H * 7 + W)
+    img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+    ref = O.preprocess_image(img, S)
+    out = ops.preprocess_image(img.cuda(), S, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    assert out.shape == ref.shape
+    err = float((out.cpu() - ref).abs().max())
+    assert err < 5e-6, f"max abs err {err:.2e}"
+
+
 def test_pack_matrix(ops):
     w = rnd(37, 53, seed=1)
     assert torch.equal(ops.pack_matrix(w, torch.float32), w)

@@ -131,3 +131,14 @@ def test_input_validation():
         O.hiera_trunk(sd, torch.zeros(1, 3, 48, 64), cfg=O.HIERA_TINY_TEST)
     with pytest.raises(ValueError):
         O.hiera_trunk(sd, torch.zeros(3, 64, 64), cfg=O.HIERA_TINY_TEST)
+
+
+def test_preprocess_matches_reference_image_processor(golden):
+    """oracle.preprocess_image vs what the reference's CODImageProcessor.process_image returned for the same decoded pixels
+    (fixture generated by importing utils/image_processor.py: tests/golden/make_golden.py::gen_preprocess)."""
+    fx = golden("preprocess.pt")
+    for name, c in fx.items():
+        out = O.preprocess_image(c["pixels"], c["size"])
+        assert out.shape == c["out"].shape
+        assert float((out - c["out"]).abs().max()) < 1e-6, name
+
