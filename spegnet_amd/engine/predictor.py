@@ -73,7 +73,10 @@ class Predictor:
 
     def preprocess_image(self, image_path: str) -> torch.Tensor:
         t0 = time.time()
-        t = self.image_processor(image_path).image.to(self.device)
+        if torch.device(self.device).type == "cuda":   # decode on the host, everything else in one HIP kernel (ops.preprocess_image)
+            t = self.image_processor.process_image_device(image_path, self.device)
+        else:
+            t = self.image_processor(image_path).image.to(self.device)
         self.result_manager.update_timing('preprocessing', time.time() - t0)
         return t.unsqueeze(0)
 
