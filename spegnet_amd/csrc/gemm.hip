@@ -2295,6 +2295,10 @@ __global__ void unpack_conv3x3_grad_kernel(const float* __restrict__ packed, flo
   }
 }
 
+// CUs the persistent GEMM grids are sized for.  SPG_CUS=<n> lowers it: these kernels occupy a CU completely (160 KiB LDS, every
+// VGPR), so when another long-running kernel holds some CUs -- RCCL's all-reduce while it overlaps the backward pass -- a grid sized
+// to all 256 needs a second round for the displaced workgroups (2x for every GEMM that overlaps the collective).  The multi-GPU
+// launcher leaves a few CUs to RCCL this way (bench.py, engine/distributed.py).
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -2302,6 +2306,8 @@ static int num_cus() {
     hipDeviceProp_t p;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
     if (n <= 0) n = 256;
+    const char* e = getenv("SPG_CUS");
+    if (e) { const int v = atoi(e); if (v >= 8 && v < n) n = v; }
   }
   return n;
 }

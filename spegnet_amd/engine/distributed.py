@@ -26,6 +26,12 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # The persistent GEMM kernels fill a CU completely, so a grid sized to all 256 CUs needs a second round for every workgroup
+        # displaced by RCCL's resident all-reduce blocks while the collective overlaps the backward pass.  Leave 16 CUs to RCCL:
+        # size the grids to 240 (csrc/gemm.hip num_cus()) and cap RCCL's channels to match.  862 MB of fp32 gradients per step
+        # have >20 ms of backward to hide in, so 16 channels are plenty.  Both are defaults only (set the variables to override).
+        os.environ.setdefault("SPG_CUS", "240")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         # "nccl" IS RCCL on ROCm.  SPG_DIST_BACKEND=gloo exists only to rehearse the N>1 code path with several ranks on ONE GPU
         backend = os.environ.get("SPG_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
