@@ -1155,13 +1155,11 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_tn, LDS-DMA pipeline (default): dW[n][k] += sum_m dY[m][n] * X[m][k] with NO register transposes.
+// Transpose-read fragments for the LDS-DMA weight-gradient kernels below (gemm_tn_pipe_kernel, gemm_tn_group_kernel, ...).
 // Tiles are DMA'd ROW-MAJOR ([m][128 features], 64 m rows of 256 B for bf16 / 32 rows of 512 B for f32) and the MFMA
 // fragments (which need 8 consecutive m for one feature) come from the hardware transpose read ds_read_b64_tr_b16
 // (bf16) or plain 4-byte reads (f32).  32-byte segments of a row are XOR-swizzled by row (on the DMA source side) so the
-// four rows a transpose read touches sit on different banks.  8 waves (wave tile 64 n x 32 k), 3-stage ring, persistent
-// over (tile, M-split) units; epilogue = f32 atomics into the gradient; the bias gradient comes from one extra MFMA per
-// n-block with an all-ones B operand (k-tile 0 only).
+// four rows a transpose read touches sit on different banks.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int tnd_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -1219,171 +1217,6 @@ template <> struct TnFrag<float> {
   }
   __device__ static __forceinline__ Frag load_at(const char* tile, int o0, int) { return *reinterpret_cast<const float*>(tile + o0); }
 };
-
-template <typename T, bool CONV>
-__global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const T* __restrict__ dY, const T* __restrict__ X, float* __restrict__ dW,
-                                                          int M, int N, int K, int ldy, int ldx, int ldw, ConvGeom g, int tiles_k,
-                                                          int tiles, int splits, int m_per_split, unsigned ybytes,
-                                                          unsigned xbytes, float* __restrict__ dbias, float* __restrict__ slabs) {
-  constexpr int VEC = ST<T>::VEC;
-  constexpr int RB = 128 * (int)sizeof(T);          // tile row bytes (256 / 512)
-  constexpr int RPP = 1024 / RB;                    // rows per 1-KiB DMA piece (4 / 2)
-  constexpr int MSTEP = 16384 / RB;                 // m rows per stage (64 / 32)
-  constexpr int CPR = RB / 16;                      // 16-byte chunks per row (16 / 32)
-  constexpr int STAGES = 3;
-  constexpr int STAGE_B = 32768;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
-  const int wn = wave & 1, wk = wave >> 1;                      // wave tile: n [64*wn, +64), k [32*wk, +32)
-  const int G = (int)gridDim.x;
-  const int first = xcd_remap(blockIdx.x, G);
-  const int units = tiles * splits;
-  if (first >= units) return;
-  const int my_units = (units - first + G - 1) / G;
-  const int nsteps = m_per_split / MSTEP;                        // steps per unit (m_per_split is a multiple of MSTEP)
-  const int total = my_units * nsteps;
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(dY, ybytes), xr = make_rsrc(X, xbytes);
-
-  const int lrow = lane / CPR, lpc = lane % CPR;
-  // issue-stream state: unit geometry is recomputed only when the stream enters a new unit (integer divisions are ~40 VALU ops)
-  int is_step = 0, is_j = 0, is_n0 = 0, is_k0 = 0, is_mbase = 0, is_mend = 0;
-  auto enter_unit = [&](int j, int& n0, int& k0, int& mbase, int& mend) {
-    const int u = first + j * G;
-    const int tile = u % tiles, split = u / tiles;
-    const int tk = tile % tiles_k, tn = tile / tiles_k;
-    n0 = tn * 128; k0 = tk * 128;
-    mbase = split * m_per_split;
-    mend = min(M, (split + 1) * m_per_split);
-  };
-  enter_unit(0, is_n0, is_k0, is_mbase, is_mend);
-  auto issue = [&](int gs) {
-    const int n0 = is_n0, k0 = is_k0;
-    const int m_begin = is_mbase + is_step * MSTEP;
-    const int m_end = is_mend;
-    char* st = smem + (gs % STAGES) * STAGE_B;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {                               // 16 pieces per operand / 8 waves
-      const int piece = i * 8 + wave;                           // 0..15
-      const int row = piece * RPP + lrow;                       // row inside the stage tile
-      const int m = m_begin + row;
-      const bool mv = m < m_end;
-      int chunk = lpc;
-      if constexpr (sizeof(T) == 2) chunk = ((((lpc >> 1) ^ tnd_swz(row)) << 1) | (lpc & 1));   // logical chunk stored at phys lpc
-      const int f = chunk * VEC;                                // feature offset inside the 128-wide tile
-      const unsigned yo = (unsigned)(((long)m * ldy + n0 + f) * (long)sizeof(T));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(st + piece * 1024), 16, (mv && n0 + f < N) ? yo : OOB, 0, 0, 0);
-      unsigned xo;
-      bool xin = mv && (k0 + f < K);
-      if constexpr (!CONV) {
-        xo = (unsigned)(((long)m * ldx + k0 + f) * (long)sizeof(T));
-      } else {
-        const int kk = k0 + f;
-        const int tap = kk / g.Ci, ci = kk - tap * g.Ci;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int hw = g.H * g.W;
-        const int b = m / hw, rem = m - b * hw;
-        const int y = rem / g.W, x = rem - y * g.W;
-        xin = xin && (unsigned)(y + dy) < (unsigned)g.H && (unsigned)(x + dx) < (unsigned)g.W;
-        xo = (unsigned)((((long)m + (long)dy * g.W + dx) * g.Ci + ci) * (long)sizeof(T));
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + 16384 + piece * 1024), 16, xin ? xo : OOB, 0, 0, 0);
-    }
-    if (++is_step == nsteps) { is_step = 0; ++is_j; if (is_j < my_units) enter_unit(is_j, is_n0, is_k0, is_mbase, is_mend); }
-  };
-
-  f32x4 acc[4][2], accb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  int gi = 0;
-  for (; gi < STAGES - 1 && gi < total; ++gi) issue(gi);
-  const int r15 = lane & 15, q = lane >> 4;
-  // fragment read offsets are lane constants: bf16 keeps all 2 x 6 x 2 of them in registers, f32 (8 k-steps) recomputes
-  constexpr int NS = TnFrag<T>::SUB;
-  constexpr bool PRE = sizeof(T) == 2;
-  int oa[PRE ? NS : 1][4][2], ob[PRE ? NS : 1][2][2];
-  if constexpr (PRE) {
-#pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) TnFrag<T>::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) TnFrag<T>::offsets(s2, wk * 32 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
-    }
-  }
-  int st_i = 0, j = 0;
-  int c_n0, c_k0, c_mb, c_me;
-  enter_unit(0, c_n0, c_k0, c_mb, c_me);
-  for (int gc = 0; gc < total; ++gc) {
-    {
-      const int ahead = gi - gc - 1;      // younger DMA groups (4 pieces per wave each)
-      if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (gi < total) { issue(gi); ++gi; }
-    const char* st = smem + (gc % STAGES) * STAGE_B;
-    const bool bias_unit = (dbias != nullptr) && (c_k0 == 0) && (wk == 0);
-#pragma unroll
-    for (int s = 0; s < TnFrag<T>::SUB; ++s) {
-      typename TnFrag<T>::Frag a[4], b[2];
-      if constexpr (PRE) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = TnFrag<T>::load_at(st, oa[s][i][0], oa[s][i][1]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) b[i] = TnFrag<T>::load_at(st + 16384, ob[s][i][0], ob[s][i][1]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = TnFrag<T>::load(st, s, wn * 64 + i * 16, lane);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) b[i] = TnFrag<T>::load(st + 16384, s, wk * 32 + i * 16, lane);
-      }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        acc[ni][0] = Mma<T>::mma(a[ni], b[0], acc[ni][0]);
-        acc[ni][1] = Mma<T>::mma(a[ni], b[1], acc[ni][1]);
-      }
-      if (bias_unit) {
-        const typename TnFrag<T>::Frag one = TnFrag<T>::ones();
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) accb[ni] = Mma<T>::mma(a[ni], one, accb[ni]);
-      }
-    }
-    if (++st_i == nsteps) {
-      const int n0 = c_n0, k0 = c_k0;
-      const int split_id = (first + j * G) / tiles;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-        for (int ki = 0; ki < 2; ++ki) {
-          const int k = k0 + wk * 32 + ki * 16 + r15;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = n0 + wn * 64 + ni * 16 + q * 4 + e;
-            if (k < K && n < N) {
-              if (slabs) slabs[((long)split_id * N + n) * K + k] = acc[ni][ki][e];
-              else atomicAdd(dW + (long)n * ldw + k, acc[ni][ki][e]);
-            }
-          }
-          acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (bias_unit && r15 == 0) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = n0 + wn * 64 + ni * 16 + q * 4 + e;
-            if (n < N) atomicAdd(dbias + n, accb[ni][e]);
-          }
-        }
-        accb[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      st_i = 0; ++j;
-      if (j < my_units) enter_unit(j, c_n0, c_k0, c_mb, c_me);
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // gemm_tn_pipe_kernel (bf16, dense X): the weight-gradient GEMM with the recipe of gemm_nt_pipe_kernel.
@@ -2526,9 +2359,9 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
     return SPG_ERR_UNSUPPORTED;
   }
   static int tnv = -1;
-  if (tnv < 0) {   // default: pipelined kernel where it applies; SPG_GEMM_TN=staged / dma select the older variants for A/B runs
+  if (tnv < 0) {   // default: pipelined kernel where it applies; SPG_GEMM_TN=staged selects the register-staged kernel for A/B runs
     const char* e = getenv("SPG_GEMM_TN");
-    tnv = (e && strcmp(e, "dma") == 0) ? 1 : ((e && strcmp(e, "staged") == 0) ? 0 : 2);
+    tnv = (e && strcmp(e, "staged") == 0) ? 0 : 2;
   }
   if constexpr (sizeof(T) == 2) {
     if (tnv == 2 && K % 4 == 0 && ws && (!conv || M < (1 << 24))) {
@@ -2563,37 +2396,6 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
         return check_launch("gemm_tn(pipe reduce)");
       }
     }
-  }
-  if (tnv == 1) {
-    // persistent kernel: one (tile, M-split) unit per workgroup is the balanced case -> as many splits as fit in the CU count
-    splits = num_cus() / tiles;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    m_per_split = cdiv(cdiv(M, splits), MSTEP) * MSTEP;
-    splits = cdiv(M, m_per_split);
-    slabs = (ws && splits > 1 && ws_bytes >= (size_t)splits * N * K * sizeof(float)) ? ws : nullptr;
-    const int units = tiles * splits;
-    const int grid = units < num_cus() ? units : num_cus();
-    constexpr int LDS = 3 * 32768;
-    static bool attr = false;
-    if (!attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr = true;
-    }
-    if (conv)
-      hipLaunchKernelGGL((gemm_tn_dma_kernel<T, true>), dim3(grid), dim3(512), LDS, s, (const T*)dY, (const T*)X, dW, M, N, K, ldy, ldx,
-                         ldw, g, tiles_k, tiles, splits, m_per_split, (unsigned)yb, (unsigned)xb, dbias, slabs);
-    else
-      hipLaunchKernelGGL((gemm_tn_dma_kernel<T, false>), dim3(grid), dim3(512), LDS, s, (const T*)dY, (const T*)X, dW, M, N, K, ldy, ldx,
-                         ldw, g, tiles_k, tiles, splits, m_per_split, (unsigned)yb, (unsigned)xb, dbias, slabs);
-    int rc = check_launch("gemm_tn(dma)");
-    if (rc || !slabs) return rc;
-    const long nk4 = (long)N * K / 4;
-    long gr = (nk4 + 255) / 256;
-    if (gr > 2048) gr = 2048;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, slabs, dW, splits, nk4, K, ldw);
-    return check_launch("gemm_tn(dma reduce)");
   }
   static int waves = -1;
   if (waves < 0) { const char* e = getenv("SPG_TN_WAVES"); waves = e ? atoi(e) : 4; }
