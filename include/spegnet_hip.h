@@ -81,6 +81,12 @@ int spg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int M, int C,
                       spg_stream_t stream);
+/* the dgamma / dbeta part of layernorm_bwd for up to 48 jobs in one launch (they only feed the optimizer, so the trunk backward
+ * defers them: 2 launches per step instead of 96).  A job is C <= 256 16-byte chunks of columns of a [M, ld] matrix (wider rows are
+ * split by the caller).  Arrays are HOST arrays of njobs entries; dgamma / dbeta accumulate (+=).                                 */
+int spg_layernorm_param_grads_batch(int dtype, int njobs, const void* const* dy, const void* const* x, const float* const* mean,
+                                    const float* const* rstd, float* const* dgamma, float* const* dbeta, const int* M, const int* C,
+                                    const int* ld, spg_stream_t stream);
 /* windowed multi-head attention straight from the fused qkv projection output [B,H,W,3,heads,hd].
  * Windows of ws x ws over the HxW map (ws<=0: one global window); padded window slots act as keys equal to
  * the qkv bias (what zero-padding after LN produces in the reference) with multiplicity folded in.

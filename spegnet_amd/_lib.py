@@ -27,6 +27,7 @@ SIGNATURES = {
     "spg_unpack_conv3x3_grad": "ppiip",
     "spg_layernorm_fwd": "ipppppp" "iifp",
     "spg_layernorm_bwd": "ippppppppp" "iip",
+    "spg_layernorm_param_grads_batch": "ii" "pppppp" "ppp" "p",
     "spg_attn_fwd": "ippppp" "iiiiiip",
     "spg_attn_bwd": "ippppppppp" "p" "iiiiiip",
     "spg_maxpool2_fwd": "ippp" "iiiiiip",

@@ -46,6 +46,8 @@ class Engine:
         self.wgrad_async = False
         self.group_wgrads = os.environ.get("SPG_TN_GROUP", "1") != "0"   # trunk blocks: one grouped wgrad launch per block
         self._wg_jobs = None
+        self.batch_ln_params = os.environ.get("SPG_LN_BATCH", "1") != "0"   # trunk: LayerNorm dgamma / dbeta in batched launches
+        self._ln_jobs = []
         self._side = None
         self._held = []
         self._forked = False
@@ -146,6 +148,21 @@ class Engine:
             torch.cuda.current_stream().wait_stream(self._side)
             self._held.clear()
             self._forked = False
+
+    # ------------------------------------------------------------------------------------------------ LayerNorm backward
+    def ln_bwd(self, dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
+        """dx now; the parameter gradients (which only feed the optimizer) are collected and issued as batched launches by
+        flush_ln_params() -- unless a per-unit gradient callback needs every finished range complete mid-backward."""
+        if not self.batch_ln_params or self.unit_cb is not None:
+            return ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=dres)
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, None, dres=dres)
+        self._ln_jobs.append((dy, x, mean, rstd, dgamma, dbeta))
+        return dx
+
+    def flush_ln_params(self) -> None:
+        if self._ln_jobs:
+            jobs, self._ln_jobs = self._ln_jobs, []
+            ops.layernorm_param_grads_batch(jobs)
 
     # ------------------------------------------------------------------------------------------------ linear helpers
     def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
@@ -262,8 +279,8 @@ class Engine:
         # MLP
         dh = self.lin_bwd(p + "mlp.layers.1", dx2, c["g"], gelu_h=c["h"])
         dln2 = self.lin_bwd(p + "mlp.layers.0", dh, c["ln2"])
-        dx1 = ops.layernorm_bwd(dln2, c["x1"], P[p + "norm2.weight"], c["mean2"], c["rstd2"], G(p + "norm2.weight"),
-                                G(p + "norm2.bias"), dres=dx2)
+        dx1 = self.ln_bwd(dln2, c["x1"], P[p + "norm2.weight"], c["mean2"], c["rstd2"], G(p + "norm2.weight"),
+                          G(p + "norm2.bias"), dres=dx2)
         # attention branch
         datt = self.lin_bwd(p + "attn.proj", dx1, c["att"])
         dqkv, dqp = ops.attn_bwd(c["qkv"], W[p + "attn.qkv.bias"], c["att"], datt, c["lse"], G(p + "attn.qkv.bias"), B, H, Wd,
@@ -281,8 +298,8 @@ class Engine:
         if self._wg_jobs is not None:
             jobs, self._wg_jobs = self._wg_jobs, None
             ops.gemm_tn_group(jobs)
-        dx = ops.layernorm_bwd(dln1, c["x"], P[p + "norm1.weight"], c["mean1"], c["rstd1"], G(p + "norm1.weight"),
-                               G(p + "norm1.bias"), dres=dres)
+        dx = self.ln_bwd(dln1, c["x"], P[p + "norm1.weight"], c["mean1"], c["rstd1"], G(p + "norm1.weight"),
+                         G(p + "norm1.bias"), dres=dres)
         return dx.view(B, H, Wd, dim)
 
     def trunk_bwd(self, ctx, dfeats: List[Optional[Tensor]]):
@@ -315,6 +332,7 @@ class Engine:
             st["unit"] += 1
             if self.unit_cb is not None:
                 self.unit_cb(st["unit"])
+        self.flush_ln_params()
         self.join_wgrad()
 
     def trunk_bwd_end(self):

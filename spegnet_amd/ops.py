@@ -208,6 +208,34 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     return dx
 
 
+LN_BATCH_MAX = 48
+
+
+def layernorm_param_grads_batch(jobs) -> None:
+    """jobs: list of (dy[M,C], x[M,C], mean[M], rstd[M], dgamma[C] f32, dbeta[C] f32), all of one dtype: dgamma += sum dy * xhat,
+    dbeta += sum dy for every job, 48 (column chunks of) LayerNorms per launch."""
+    import ctypes
+    if not jobs:
+        return
+    keep, sub = [], []                       # sub-jobs: (dy_ptr, x_ptr, mean_ptr, rstd_ptr, dg_ptr, db_ptr, M, cols, ld)
+    es = jobs[0][1].element_size()
+    step = 256 * (16 // es)                  # columns one 256-thread pass covers
+    for dy, x, mean, rstd, dg, db in jobs:
+        dy, x = _c(dy), _c(x)
+        keep.append((dy, x))
+        C = x.shape[-1]
+        M = x.numel() // C
+        for c0 in range(0, C, step):
+            sub.append((_p(dy) + c0 * es, _p(x) + c0 * es, _p(mean), _p(rstd), _p(f32(dg)) + 4 * c0, _p(f32(db)) + 4 * c0, M, min(step, C - c0), C))
+    dt = dcode(jobs[0][1])
+    for i in range(0, len(sub), LN_BATCH_MAX):
+        part = sub[i:i + LN_BATCH_MAX]
+        n = len(part)
+        P, I = ctypes.c_void_p * n, ctypes.c_int * n
+        _lib.call("spg_layernorm_param_grads_batch", dt, n, *[P(*[j[k] for j in part]) for k in range(6)],
+                  I(*[j[6] for j in part]), I(*[j[7] for j in part]), I(*[j[8] for j in part]), _stream())
+
+
 def attn_fwd(qkv: Tensor, bias_t: Tensor, B: int, H: int, W: int, heads: int, hd: int, ws: int,
              q_pooled: Optional[Tensor] = None):
     """qkv [B,H,W,3*heads*hd]; returns out [B,Hq,Wq,heads*hd], lse [B,Hq,Wq,heads]."""

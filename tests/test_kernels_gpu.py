@@ -138,6 +138,28 @@ def test_gemm_tn_group(ops, shapes):
             check(db, rb, tol(dt, 2e-5, 1e-4), f"group dbias {shp}")
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_layernorm_param_grads_batch(ops, dt):
+    """Batched dgamma / dbeta (one launch for many LayerNorms of different widths / row counts) == the per-layer layernorm_bwd."""
+    shapes = [(100, 144), (37, 1152), (513, 576), (64, 16), (4608, 576)] * 11      # 55 jobs: more than one launch
+    jobs, refs = [], []
+    for i, (M, C) in enumerate(shapes):
+        x, dy = rnd(M, C, seed=100 + i).to(dt), rnd(M, C, seed=200 + i).to(dt)
+        g, b = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+        _, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+        dg0, db0 = rnd(C, seed=300 + i), rnd(C, seed=400 + i)
+        dg_ref, db_ref = dg0.clone(), db0.clone()
+        ops.layernorm_bwd(dy, x, g, mean, rstd, dg_ref, db_ref)
+        dg, db = dg0.clone(), db0.clone()
+        jobs.append((dy, x, mean, rstd, dg, db))
+        refs.append((dg_ref, db_ref))
+    ops.layernorm_param_grads_batch(jobs)
+    torch.cuda.synchronize()
+    for (dy, x, mean, rstd, dg, db), (dg_ref, db_ref) in zip(jobs, refs):
+        check(dg, dg_ref, 2e-5, f"batched dgamma {tuple(x.shape)}")
+        check(db, db_ref, 2e-5, f"batched dbeta {tuple(x.shape)}")
+
+
 @pytest.mark.parametrize("H,W,S", [(600, 800, 384), (1033, 777, 384), (200, 300, 384), (384, 384, 384), (2000, 1500, (352, 416))])
 def test_preprocess_image_matches_reference_arithmetic(ops, H, W, S):
     """Device input pipeline (uint8 HWC -> /255 -> antialiased bilinear resize -> normalise) against the oracle's restatement of
