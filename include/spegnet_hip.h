@@ -58,7 +58,13 @@ long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K);
  * of sam2's MultiScaleBlock).                                                                                                     */
 int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias,
                       int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, void* workspace,
-                      long workspace_bytes, spg_stream_t stream);
+                      long workspace_bytes, void* reduce_desc_out, spg_stream_t stream);
+/* reduce_desc_out != NULL (a HOST buffer of spg_gemm_tn_group_desc_bytes()): the second kernel is not launched; the caller keeps the
+ * workspace and later folds up to 6 such launches at once with spg_gemm_tn_group_reduce_batch (descs / workspaces: HOST arrays of n
+ * pointers: host descriptors, device workspaces).  The gradients are complete only after that call; a gradient buffer may appear
+ * in only ONE pending launch (the batched fold adds into dW with plain read-modify-write).                                         */
+long spg_gemm_tn_group_desc_bytes(void);
+int spg_gemm_tn_group_reduce_batch(int n, const void* const* descs, const void* const* workspaces, spg_stream_t stream);
 long spg_gemm_tn_group_workspace_bytes(void);
 
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------

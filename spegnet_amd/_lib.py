@@ -20,7 +20,8 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 SIGNATURES = {
     "spg_gemm_nt": "ipppppppiiiiiiiiiiip",
     "spg_gemm_tn": "ipppppliiiiiiiiiiip",
-    "spg_gemm_tn_group": "ii" "pppp" "i" "ppppp" "plp",
+    "spg_gemm_tn_group": "ii" "pppp" "i" "ppppp" "plpp",
+    "spg_gemm_tn_group_reduce_batch": "ippp",
     "spg_pack_matrix": "ippiiip",
     "spg_pack_batch": "ipiip",
     "spg_pack_conv3x3": "ipppiip",
@@ -86,6 +87,8 @@ def load() -> ctypes.CDLL:
     lib.spg_gemm_tn_workspace_bytes.argtypes = [_I, _I, _I, _I]
     lib.spg_gemm_tn_group_workspace_bytes.restype = _L
     lib.spg_gemm_tn_group_workspace_bytes.argtypes = []
+    lib.spg_gemm_tn_group_desc_bytes.restype = _L
+    lib.spg_gemm_tn_group_desc_bytes.argtypes = []
     for table, required in ((SIGNATURES, True), (_OPTIONAL, False)):
         for name, sig in table.items():
             try:

@@ -1692,8 +1692,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
 
 // Folds the partial sums of the remainder tiles cut by share boundaries into dW.  Block b looks at boundary c = b + 1 (between the
 // remainder shares of logical workgroups c-1 and c); it acts only if that boundary falls inside a tile AND is the first one inside.
-__global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g, const float* __restrict__ slabs, int G) {
-  const int c = blockIdx.x + 1;
+__device__ __forceinline__ void tn_group_reduce_body(const TnGroup& g, const float* __restrict__ slabs, int G, int c, int ypart, int yparts) {
   const int S = g.S;
   const int b = (int)((long)c * g.RS / G);
   if (b >= g.RS) return;
@@ -1710,8 +1709,8 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g, const f
   const int tk = tile % jb.tiles_k, tn = tile / jb.tiles_k;
   // gridDim.y blocks share the tile's 4096 float4 (a remainder tile can be cut into a dozen pieces: one block alone would walk them
   // all at a single CU's bandwidth)
-  const int per = (TN_SLOT_FLOATS / 4) / (int)gridDim.y;
-  for (int v = blockIdx.y * per + threadIdx.x; v < (blockIdx.y + 1) * per; v += 256) {
+  const int per = (TN_SLOT_FLOATS / 4) / yparts;
+  for (int v = ypart * per + threadIdx.x; v < (ypart + 1) * per; v += 256) {
     const int nl = v >> 5, kl = (v & 31) * 4;
     f32x4 s = *reinterpret_cast<const f32x4*>(slabs + ((long)(c - 1) * 2 + 1) * TN_SLOT_FLOATS + v * 4);
 #pragma unroll 4
@@ -1722,6 +1721,20 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g, const f
       *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g, const float* __restrict__ slabs, int G) {
+  tn_group_reduce_body(g, slabs, G, blockIdx.x + 1, blockIdx.y, gridDim.y);
+}
+
+// the boundary reduces of up to 6 grouped launches in one launch (they only feed the optimizer: the trunk backward defers them)
+constexpr int TN_REDUCE_BATCH = 6;
+struct TnReduceDesc { TnGroup g; int G; int pad; };
+struct TnReduceBatch { TnGroup g[TN_REDUCE_BATCH]; const float* slabs[TN_REDUCE_BATCH]; int G[TN_REDUCE_BATCH]; int n; };
+__global__ __launch_bounds__(256) void tn_group_reduce_batch_kernel(TnReduceBatch b) {
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x + 1 >= b.G[z]) return;
+  tn_group_reduce_body(b.g[z], b.slabs[z], b.G[z], blockIdx.x + 1, blockIdx.y, gridDim.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2451,7 +2464,7 @@ extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus()
 
 extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW,
                                  float* const* dbias, int M, const int* N, const int* K, const int* ldy, const int* ldx,
-                                 const int* ldw, void* workspace, long workspace_bytes, spg_stream_t stream) {
+                                 const int* ldw, void* workspace, long workspace_bytes, void* reduce_desc_out, spg_stream_t stream) {
   SPG_REQUIRE(dtype == SPG_BF16, "gemm_tn_group: bf16 only (dtype %d)", dtype);
   SPG_REQUIRE(njobs >= 1 && njobs <= TN_GROUP_MAX, "gemm_tn_group: 1..%d problems, got %d", TN_GROUP_MAX, njobs);
   SPG_REQUIRE(M > 0, "gemm_tn_group: empty M");
@@ -2502,6 +2515,7 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
     if (dbgw == 2) hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
     else hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 0>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
     int rc = check_launch("gemm_tn_group(wide)");
+    if (reduce_desc_out) { TnReduceDesc d; memset(&d, 0, sizeof(d)); memcpy(reduce_desc_out, &d, sizeof(d)); }   // reduced right here
     if (rc || G < 2 || gw.RS == 0) return rc;
     hipLaunchKernelGGL(tnw_reduce_kernel, dim3(G - 1, 16), dim3(256), 0, s, gw, (const float*)workspace, G);
     return check_launch("gemm_tn_group(wide reduce)");
@@ -2547,9 +2561,36 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   } else
   hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   int rc = check_launch("gemm_tn_group");
+  if (reduce_desc_out) {     // deferred: the caller collects descriptors and folds the slabs later (spg_gemm_tn_group_reduce_batch)
+    TnReduceDesc d;
+    d.g = g; d.G = (G < 2 || g.RS == 0) ? 0 : G; d.pad = 0;
+    memcpy(reduce_desc_out, &d, sizeof(d));
+    return rc;
+  }
   if (rc || G < 2 || g.RS == 0) return rc;
   hipLaunchKernelGGL(tn_group_reduce_kernel, dim3(G - 1, 8), dim3(256), 0, s, g, (const float*)workspace, G);
   return check_launch("gemm_tn_group(reduce)");
+}
+
+extern "C" long spg_gemm_tn_group_desc_bytes(void) { return (long)sizeof(TnReduceDesc); }
+
+extern "C" int spg_gemm_tn_group_reduce_batch(int n, const void* const* descs, const void* const* workspaces, spg_stream_t stream) {
+  SPG_REQUIRE(n >= 1 && n <= TN_REDUCE_BATCH, "gemm_tn_group_reduce_batch: 1..%d groups, got %d", TN_REDUCE_BATCH, n);
+  TnReduceBatch b;
+  int maxG = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    TnReduceDesc d;
+    memcpy(&d, descs[i], sizeof(d));
+    if (d.G < 2) continue;                    // nothing was cut in that launch
+    b.g[m] = d.g; b.slabs[m] = (const float*)workspaces[i]; b.G[m] = d.G;
+    if (d.G > maxG) maxG = d.G;
+    ++m;
+  }
+  if (m == 0) return SPG_OK;
+  for (int i = m; i < TN_REDUCE_BATCH; ++i) { b.g[i] = b.g[0]; b.slabs[i] = b.slabs[0]; b.G[i] = 0; }
+  b.n = m;
+  hipLaunchKernelGGL(tn_group_reduce_batch_kernel, dim3(maxG - 1, 8, m), dim3(256), 0, (hipStream_t)stream, b);
+  return check_launch("gemm_tn_group_reduce_batch");
 }
 
 extern "C" long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {

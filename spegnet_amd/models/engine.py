@@ -48,6 +48,7 @@ class Engine:
         self._wg_jobs = None
         self.batch_ln_params = os.environ.get("SPG_LN_BATCH", "1") != "0"   # trunk: LayerNorm dgamma / dbeta in batched launches
         self._ln_jobs = []
+        self._tn_defer = []
         self._side = None
         self._held = []
         self._forked = False
@@ -160,9 +161,13 @@ class Engine:
         return dx
 
     def flush_ln_params(self) -> None:
+        """Issues everything the trunk backward deferred because only the optimizer needs it: LayerNorm parameter gradients and
+        the slab reduces of the grouped weight gradients."""
         if self._ln_jobs:
             jobs, self._ln_jobs = self._ln_jobs, []
             ops.layernorm_param_grads_batch(jobs)
+        if self._tn_defer:
+            ops.gemm_tn_group_reduce(self._tn_defer)
 
     # ------------------------------------------------------------------------------------------------ linear helpers
     def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
@@ -297,7 +302,9 @@ class Engine:
             dres = dx1
         if self._wg_jobs is not None:
             jobs, self._wg_jobs = self._wg_jobs, None
-            ops.gemm_tn_group(jobs)
+            # the groups' small slab reduces are deferred as well (flush_ln_params folds them, 6 per launch) unless a per-unit
+            # gradient callback needs finished ranges mid-backward
+            ops.gemm_tn_group(jobs, self._tn_defer if self.unit_cb is None else None)
         dx = self.ln_bwd(dln1, c["x"], P[p + "norm1.weight"], c["mean1"], c["rstd1"], G(p + "norm1.weight"),
                          G(p + "norm1.bias"), dres=dres)
         return dx.view(B, H, Wd, dim)

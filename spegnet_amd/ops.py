@@ -132,9 +132,11 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
 TN_GROUP_MAX = 8
 
 
-def gemm_tn_group(jobs) -> None:
+def gemm_tn_group(jobs, defer: Optional[list] = None) -> None:
     """jobs: list of (dy[M,N], x[M,K], dw[N,K] f32, dbias[N] f32 or None), all dense.  dw += dy^T x and dbias += colsum(dy) for every
-    job; bf16 jobs sharing M go out as grouped, CU-balanced launches of up to 8 problems (spg_gemm_tn_group), anything else one by one."""
+    job; bf16 jobs sharing M go out as grouped, CU-balanced launches of up to 8 problems (spg_gemm_tn_group), anything else one by one.
+    defer: a list -> the small slab-reduce kernel of each grouped launch is not issued; (descriptor, workspace) pairs are appended
+    and the caller folds them later with gemm_tn_group_reduce(defer) (the gradients are complete only then)."""
     import ctypes
     groups = {}
     for dy, x, dw, db in jobs:
@@ -147,16 +149,32 @@ def gemm_tn_group(jobs) -> None:
             gemm_tn(dy, x, dw, dbias=db)
     if not groups:
         return
-    wsb = _lib.load().spg_gemm_tn_group_workspace_bytes()
+    lib = _lib.load()
+    wsb = lib.spg_gemm_tn_group_workspace_bytes()
     for M, group in groups.items():
         for i in range(0, len(group), TN_GROUP_MAX):
             part = group[i:i + TN_GROUP_MAX]
             n = len(part)
             ws = torch.empty(wsb, dtype=torch.uint8, device=part[0][0].device)
+            desc = ctypes.create_string_buffer(lib.spg_gemm_tn_group_desc_bytes()) if defer is not None else None
             P, I = ctypes.c_void_p * n, ctypes.c_int * n
             Ns, Ks = I(*[j[4] for j in part]), I(*[j[5] for j in part])
             _lib.call("spg_gemm_tn_group", SPG_BF16, n, P(*[_p(j[0]) for j in part]), P(*[_p(j[1]) for j in part]),
-                      P(*[_p(j[2]) for j in part]), P(*[_p(j[3]) for j in part]), M, Ns, Ks, Ns, Ks, Ks, _p(ws), wsb, _stream())
+                      P(*[_p(j[2]) for j in part]), P(*[_p(j[3]) for j in part]), M, Ns, Ks, Ns, Ks, Ks, _p(ws), wsb,
+                      ctypes.addressof(desc) if desc is not None else None, _stream())
+            if defer is not None:
+                defer.append((desc, ws))
+
+
+def gemm_tn_group_reduce(deferred: list) -> None:
+    """Folds the slabs of deferred grouped launches into their gradients, 6 launches per kernel; empties the list."""
+    import ctypes
+    for i in range(0, len(deferred), 6):
+        part = deferred[i:i + 6]
+        n = len(part)
+        P = ctypes.c_void_p * n
+        _lib.call("spg_gemm_tn_group_reduce_batch", n, P(*[ctypes.addressof(d) for d, _ in part]), P(*[_p(w) for _, w in part]), _stream())
+    deferred.clear()
 
 
 def pack_matrix(src: Tensor, dtype: torch.dtype, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:

@@ -120,8 +120,10 @@ def test_gemm_tn(ops, dt, M, N, K):
     [(1000, 136, 72), (77, 432, 144), (5000, 1000, 200), (64, 16, 32), (130, 8, 8)],   # ragged N / K / M, tiles cut several times
     [(9000, 128, 128)],                                                               # one tile shared by many workgroups
 ])
-def test_gemm_tn_group(ops, shapes):
-    """Grouped stream-K wgrad: every problem's dW / dbias must match the per-problem reference, accumulating on top of what is there."""
+@pytest.mark.parametrize("defer", [False, True])
+def test_gemm_tn_group(ops, shapes, defer):
+    """Grouped stream-K wgrad: every problem's dW / dbias must match the per-problem reference, accumulating on top of what is there
+    (defer: the slab reduces are collected and folded afterwards in one batched launch, as the trunk backward does)."""
     dt = torch.bfloat16
     jobs, refs = [], []
     for i, (M, N, K) in enumerate(shapes):
@@ -130,7 +132,19 @@ def test_gemm_tn_group(ops, shapes):
         dw, db = dw0.clone(), (db0.clone() if i % 2 == 0 else None)
         jobs.append((dy, x, dw, db))
         refs.append((dw0 + dy.float().t() @ x.float(), (db0 + dy.float().sum(0)) if db is not None else None))
-    ops.gemm_tn_group(jobs)
+    if defer:
+        pending = []
+        ops.gemm_tn_group(jobs, pending)
+        # a second deferred launch (its own gradient buffer: one gradient may appear in only one pending launch) -- the batched
+        # reduce must fold both launches' slabs
+        dy0, x0 = jobs[0][0], jobs[0][1]
+        extra_dw = torch.zeros(dy0.shape[-1], x0.shape[-1], device="cuda")
+        ops.gemm_tn_group([(dy0, x0, extra_dw, None)], pending)
+        ops.gemm_tn_group_reduce(pending)
+        assert pending == []
+        check(extra_dw, dy0.float().t() @ x0.float(), tol(dt, 2e-5, 1e-2), "second deferred launch")
+    else:
+        ops.gemm_tn_group(jobs)
     torch.cuda.synchronize()
     for (dy, x, dw, db), (rw, rb), shp in zip(jobs, refs, shapes):
         check(dw, rw, tol(dt, 2e-5, 1e-2), f"group dW {shp}")
