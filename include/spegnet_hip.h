@@ -66,6 +66,9 @@ int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* c
 long spg_gemm_tn_group_desc_bytes(void);
 int spg_gemm_tn_group_reduce_batch(int n, const void* const* descs, const void* const* workspaces, spg_stream_t stream);
 long spg_gemm_tn_group_workspace_bytes(void);
+/* Number of CUs the persistent GEMM grids of the FOLLOWING launches are sized for (0 = all).  The kernels fill a CU completely, so a
+ * caller that overlaps them with another resident kernel (RCCL's all-reduce) leaves it some CUs instead of paying a second round.   */
+int spg_set_cu_budget(int n);
 
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
  * spg_pack_matrix: dst[r][c] = src[r][c] (transpose=0) or dst[c][r] = src[r][c] (transpose=1), src f32 [R,C].

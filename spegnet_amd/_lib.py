@@ -22,6 +22,7 @@ SIGNATURES = {
     "spg_gemm_tn": "ipppppliiiiiiiiiiip",
     "spg_gemm_tn_group": "ii" "pppp" "i" "ppppp" "plpp",
     "spg_gemm_tn_group_reduce_batch": "ippp",
+    "spg_set_cu_budget": "i",
     "spg_pack_matrix": "ippiiip",
     "spg_pack_batch": "ipiip",
     "spg_pack_conv3x3": "ipppiip",

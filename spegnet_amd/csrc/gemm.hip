@@ -2141,21 +2141,23 @@ __global__ void unpack_conv3x3_grad_kernel(const float* __restrict__ packed, flo
   }
 }
 
-// CUs the persistent GEMM grids are sized for.  SPG_CUS=<n> lowers it: these kernels occupy a CU completely (160 KiB LDS, every
-// VGPR), so when another long-running kernel holds some CUs -- RCCL's all-reduce while it overlaps the backward pass -- a grid sized
-// to all 256 needs a second round for the displaced workgroups (2x for every GEMM that overlaps the collective).  The multi-GPU
-// launcher leaves a few CUs to RCCL this way (bench.py, engine/distributed.py).
+// CUs the persistent GEMM grids are sized for.  These kernels occupy a CU completely (160 KiB LDS, every VGPR), so when another
+// long-running kernel holds some CUs -- RCCL's all-reduce while it overlaps the backward pass -- a grid sized to all 256 needs a second
+// round for the displaced workgroups (2x for every GEMM that overlaps the collective).  spg_set_cu_budget(n) lowers the count for the
+// launches that follow (the multi-GPU trainer sets it around the graph segments that run beside a collective, engine/trainer.py);
+// SPG_CUS=<n> caps it for the whole process.
+static int g_cu_budget = 0;
 static int num_cus() {
-  static int n = 0;
-  if (n == 0) {
+  static int hw = 0;
+  if (hw == 0) {
     int dev = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-    if (n <= 0) n = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) hw = p.multiProcessorCount;
+    if (hw <= 0) hw = 256;
     const char* e = getenv("SPG_CUS");
-    if (e) { const int v = atoi(e); if (v >= 8 && v < n) n = v; }
+    if (e) { const int v = atoi(e); if (v >= 8 && v < hw) hw = v; }
   }
-  return n;
+  return (g_cu_budget >= 8 && g_cu_budget < hw) ? g_cu_budget : hw;
 }
 static int gemm_variant() {  // SPG_GEMM=staged selects the register-staged kernel (A/B runs); default = LDS-DMA pipeline
   static int v = -1;
@@ -2458,6 +2460,11 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
   hipStream_t s = (hipStream_t)stream;
   return dtype == SPG_BF16 ? launch_nt<bf16_t>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s)
                            : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s);
+}
+
+extern "C" int spg_set_cu_budget(int n) {   // 0 (or anything outside [8, #CUs)) = all CUs
+  g_cu_budget = n;
+  return SPG_OK;
 }
 
 extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus() * 2 * TNW_SLOT_FLOATS * (long)sizeof(float); }   // covers both kernels

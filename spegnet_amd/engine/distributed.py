@@ -26,11 +26,10 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # The persistent GEMM kernels fill a CU completely, so a grid sized to all 256 CUs needs a second round for every workgroup
-        # displaced by RCCL's resident all-reduce blocks while the collective overlaps the backward pass.  Leave 16 CUs to RCCL:
-        # size the grids to 240 (csrc/gemm.hip num_cus()) and cap RCCL's channels to match.  862 MB of fp32 gradients per step
-        # have >20 ms of backward to hide in, so 16 channels are plenty.  Both are defaults only (set the variables to override).
-        os.environ.setdefault("SPG_CUS", "240")
+        # RCCL's resident all-reduce blocks and the persistent GEMM kernels (which fill a CU completely) would fight for CUs while a
+        # collective overlaps the backward pass: RCCL is capped to 16 channels here and the trainer sizes the GEMM grids that run
+        # beside a collective to COMM_CU_BUDGET CUs (engine/trainer.py; spg_set_cu_budget).  862 MB of fp32 gradients per step have
+        # > 20 ms of backward to hide in, so 16 channels are plenty.  A default only (set the variable to override).
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         # "nccl" IS RCCL on ROCm.  SPG_DIST_BACKEND=gloo exists only to rehearse the N>1 code path with several ranks on ONE GPU
         backend = os.environ.get("SPG_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
@@ -38,6 +37,10 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
             torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+# CUs left to the GEMM grids while a gradient all-reduce is in flight (the other 16 go to RCCL's channels)
+COMM_CU_BUDGET = int(os.environ.get("SPG_COMM_CUS", "240"))
 
 
 def make_buckets(unit_ends: List[int], bucket_elems: int) -> List[Tuple[int, int]]:

@@ -129,6 +129,11 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
               1 if conv else 0, B, H, W, Ci, _stream())
 
 
+def set_cu_budget(n: int) -> None:
+    """CUs the persistent GEMM grids of the following launches are sized for (0 = all); see spg_set_cu_budget."""
+    _lib.call("spg_set_cu_budget", int(n))
+
+
 TN_GROUP_MAX = 8
 
 
