@@ -42,10 +42,8 @@ def synthetic(B, S, device, seed):
     return images, masks, edges
 
 
-def cpu_baseline():
-    """The CPU oracle (fp32 restatement of the reference path) timed on this box's host cores: one full train step
-    at batch 2 @384x384 (bounded sample of the same workload)."""
-    from oracle import spegnet_oracle as O
+def host_cpu():
+    """(threads this process may use, CPU model string)"""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -57,19 +55,84 @@ def cpu_baseline():
             cores = max(1, min(cores, int(int(q) / int(per))))
     except Exception:
         pass
-    cores = min(cores, int(os.environ.get("SPG_CPU_THREADS", "16")))
+    if os.environ.get("SPG_CPU_THREADS"):
+        cores = min(cores, int(os.environ["SPG_CPU_THREADS"]))
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return cores, model
+
+
+def cpu_baseline():
+    """The CPU oracle (fp32 restatement of the reference path, oracle/spegnet_oracle.py) timed on this box's host cores, every core the
+    job may use: (1) BASELINE config #2's step -- one full train step at batch 8 @384x384, after one untimed warm-up step; (2) config #1 --
+    eval-mode forward of one 384x384 image (what Predictor.predict_single runs, reference engine/predictor.py:336-338), after the
+    reference's own warm-up forward (predictor.py:283-288).  A bounded sample (~20-40 s): a reported baseline, not the target."""
+    from oracle import spegnet_oracle as O
+    cores, model = host_cpu()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline: oracle train step on {cores} threads")
+    log(f"cpu_baseline: oracle on {cores} threads of {model}")
     sd = O.init_state_dict(seed=0)
-    B, n = 4, 2
+    x1 = torch.randn(1, 3, S, S, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        O.spegnet_forward(sd, x1, training=False)          # warm-up
+        t0 = time.time()
+        n1 = 3
+        for _ in range(n1):
+            O.spegnet_forward(sd, x1, training=False)
+        dt1 = (time.time() - t0) / n1
+    B = PER_GPU_BATCH
     x, masks, edges = O.synthetic_batch(B, S, seed=0)
     st = {}
+    O.train_step(sd, st, x, masks, edges)                  # warm-up step (allocator, thread pool)
     t0 = time.time()
-    for _ in range(n):
-        O.train_step(sd, st, x, masks, edges)
+    O.train_step(sd, st, x, masks, edges)
     dt = time.time() - t0
-    return {"value": round(B * n / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fp32 train steps (fwd+CODLoss+bwd+clip+AdamW) of the CPU oracle, batch {B} @{S}x{S}, {dt:.1f} s"}
+    return {"value": round(B / dt, 4), "unit": "img/s", "cores": cores, "cpu_model": model, "kind": "port",
+            "sample": f"1 fp32 train step (fwd+CODLoss+bwd+clip+AdamW) of the CPU oracle, batch {B} @{S}x{S}, {dt:.1f} s, after 1 warm-up step",
+            "forward_b1": {"value": round(1.0 / dt1, 3), "unit": "img/s", "ms": round(dt1 * 1e3, 1),
+                           "sample": f"eval forward of one {S}x{S} image (BASELINE config #1), mean of {n1} after 1 warm-up"}}
+
+
+PEAK_HBM_GBS = 8000.0       # HBM3E peak, MI355X_MICROARCH.md "Chip-level parameters" (6.29 TB/s measured copy rate)
+
+
+def roofline_table(rec, bracket_s, dtype):
+    """Per-op roofline rows from ops.PROFILE records (name, bound, algorithmic work, start, end): achieved = sum of work / sum of
+    HIP-event durations (bracket cost subtracted), against the MFMA peak of the dtype or the HBM peak."""
+    peak_mfma = PEAK_BF16_TFLOPS if dtype == "bf16" else 157.3
+    tot = {}
+    for name, bound, work, e0, e1 in rec:
+        a = tot.setdefault((name, bound), [0.0, 0.0, 0])
+        a[0] += work; a[1] += max(e0.elapsed_time(e1) * 1e-3 - bracket_s, 1e-7); a[2] += 1
+    rows = []
+    for (name, bound), (work, sec, n) in tot.items():
+        if bound == "mfma":
+            ach, peak, unit = work / sec / 1e12, peak_mfma, "TFLOP/s"
+        else:
+            ach, peak, unit = work / sec / 1e9, PEAK_HBM_GBS, "GB/s"
+        rows.append({"kernel": name, "bound": bound, "launches_per_step": n / 2, "avg_us": round(sec / n * 1e6, 2),
+                     "ms_per_step": round(sec / 2 * 1e3, 3), "work_per_launch": work / n, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                     "frac": round(ach / peak, 4)})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def committed_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    FETCH_SIZE x2 per MI355X_MICROARCH.md; bench.py cannot collect counters itself).  Returns (bytes, source) or (None, None)."""
+    path = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        e = d["kernels"][kernel_key]
+        return e["fetch_bytes_x2"] + e["write_bytes"], "profiles/round2_pmc_traffic.json: " + d.get("source", "")
+    except Exception:
+        return None, None
 
 
 def main():
@@ -217,20 +280,17 @@ def main():
                 eager(images, masks, edges)
                 torch.cuda.synchronize()
             rec, ops.PROFILE = ops.PROFILE, None
-            tot = {}
-            for kind, dt_, fl, e0, e1 in rec:
-                k = (kind, str(dt_))
-                a = tot.setdefault(k, [0.0, 0.0, 0])
-                a[0] += fl; a[1] += max(e0.elapsed_time(e1) * 1e-3 - bracket_s, 1e-7); a[2] += 1
-            want = ("dense", "torch.bfloat16" if args.dtype == "bf16" else "torch.float32")
-            fl, sec, n = tot[want]
-            ach = fl / sec / 1e12
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-            roof = {"bound": "mfma", "kernel": "gemm_nt_pipe_kernel<%s,dense> (all gemm_nt launches)" % args.dtype, "achieved": round(ach, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": n,
-                    "avg_launch_us": round(sec / n * 1e6, 2), "event_bracket_us": round(bracket_s * 1e6, 2), "flop_per_launch_avg": fl / n,
-                    "other": {f"{k[0]}": {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "launches": v[2], "avg_us": round(v[1] / v[2] * 1e6, 2)}
-                              for k, v in tot.items() if k != want}}
+            rows = roofline_table(rec, bracket_s, args.dtype)
+            want = "gemm_nt<%s,dense>" % ("bf16" if args.dtype == "bf16" else "f32")
+            dom = next(r for r in rows if r["kernel"] == want)
+            traffic, src = committed_traffic(want)
+            roof = {"bound": "mfma", "kernel": "gemm_nt_pipe_kernel<%s,dense> (all dense gemm_nt launches: Linear / 1x1 conv fwd + dgrad)" % args.dtype,
+                    "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                    "traffic_source": src, "launches": int(dom["launches_per_step"] * 2), "avg_launch_us": dom["avg_us"],
+                    "event_bracket_us": round(bracket_s * 1e6, 2), "flop_per_launch_avg": dom["work_per_launch"],
+                    # every instrumented op of the step (2 eager steps, HIP events on the launch stream): recompute frac = achieved / peak,
+                    # achieved = work_per_launch / avg_us
+                    "kernels": rows}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -84,18 +84,21 @@ int spg_unpack_conv3x3_grad(const float* packed, float* dst, int Co, int Ci, spg
 
 /* ---- Hiera trunk pieces (sam2 Hiera MultiScaleBlock) --------------------------------
  * layernorm: y = LN(x)*g+b over last dim C (eps), stats saved (mean,rstd f32 [M]) for backward.
- * layernorm_bwd: dx = LN'(dy) (+ dres if non-null); dgamma/dbeta f32 atomically accumulated.            */
+ * layernorm_bwd: dx = LN'(dy) (+ dres if non-null); dgamma/dbeta (f32) += the column sums, by a deterministic reduction
+ *   (see "Deterministic reductions" below for red_ws / red_counters; both may be NULL when dgamma == dbeta == NULL).   */
 int spg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                       float* rstd, int M, int C, float eps, spg_stream_t stream);
 int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int M, int C,
-                      spg_stream_t stream);
+                      float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
 /* the dgamma / dbeta part of layernorm_bwd for up to 48 jobs in one launch (they only feed the optimizer, so the trunk backward
  * defers them: 2 launches per step instead of 96).  A job is C <= 256 16-byte chunks of columns of a [M, ld] matrix (wider rows are
  * split by the caller).  Arrays are HOST arrays of njobs entries; dgamma / dbeta accumulate (+=).                                 */
 int spg_layernorm_param_grads_batch(int dtype, int njobs, const void* const* dy, const void* const* x, const float* const* mean,
                                     const float* const* rstd, float* const* dgamma, float* const* dbeta, const int* M, const int* C,
-                                    const int* ld, spg_stream_t stream);
+                                    const int* ld, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
+/* floats of red_ws the batched call needs for these column counts (HOST array); it also needs njobs zeroed counters */
+long spg_layernorm_param_grads_batch_workspace_floats(int njobs, const int* C);
 /* windowed multi-head attention straight from the fused qkv projection output [B,H,W,3,heads,hd].
  * Windows of ws x ws over the HxW map (ws<=0: one global window); padded window slots act as keys equal to
  * the qkv bias (what zero-padding after LN produces in the reference) with multiplicity folded in.
@@ -123,31 +126,54 @@ int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int S, int 
 int spg_preprocess_image(const uint8_t* img_hwc, float* out_chw, int H, int W, int OH, int OW, const float* mean3, const float* std3,
                          spg_stream_t stream);
 
+/* the same for a batch of up to 64 images of different sizes in ONE launch: image i is uint8 HWC [H[i],W[i],3] at base + offs[i] (device
+ * buffer `base`; offs / H / W are HOST arrays); output f32 [B,3,OH,OW] = the model's input batch (utils/data_loader.py:177-212 stacks
+ * the per-image tensors the reference's DataLoader workers compute on the CPU).                                                      */
+int spg_preprocess_batch(const uint8_t* base, const long* offs, const int* H, const int* W, float* out_b3hw, int B, int OH, int OW,
+                         const float* mean3, const float* std3, spg_stream_t stream);
+
 /* ---- column reductions / elementwise (HBM-bound) -----------------------------------------------------------
- * colsum: out[c] += sum_m x[m][c] (f32 atomics; bias gradients).  gap_sum / chan_prod_sum: the same per image. */
-int spg_colsum(int dtype, const void* x, float* out, int M, int C, int ldx, spg_stream_t stream);
-int spg_gap_sum(int dtype, const void* x, float* out, int B, long HW, int C, spg_stream_t stream);
-int spg_chan_prod_sum(int dtype, const void* a, const void* b, float* out, int B, long HW, int C, spg_stream_t stream);
+ * Deterministic reductions: a reduction that spans workgroups writes one partial vector per workgroup into red_ws (caller-owned
+ * scratch of >= spg_reduce_workspace_floats(dtype, C, nimg) floats, contents irrelevant) and the workgroup that arrives last at a
+ * counter (red_counters: >= spg_reduce_counters(dtype, C, nimg) 32-bit words that are ZERO before their first use; each launch leaves
+ * them zero) adds the partials in a fixed order.  No float atomics: identical inputs give bit-identical results, which train-mode
+ * BatchNorm statistics (feature_integration.py:335-345: B values per channel) need.  Launches sharing counters must be stream-ordered.
+ * colsum: out[c] (+)= sum_m x[m][c] (bias gradients).  gap_sum / chan_prod_sum: out[b][c] = the same per image (overwrites).     */
+long spg_reduce_workspace_floats(int dtype, int C, int nimg);
+int spg_reduce_counters(int dtype, int C, int nimg);
+int spg_colsum(int dtype, const void* x, float* out, int M, int C, int ldx, int accumulate, float* red_ws, long red_ws_floats,
+               unsigned* red_counters, spg_stream_t stream);
+int spg_gap_sum(int dtype, const void* x, float* out, int B, long HW, int C, float* red_ws, long red_ws_floats,
+                unsigned* red_counters, spg_stream_t stream);
+int spg_chan_prod_sum(int dtype, const void* a, const void* b, float* out, int B, long HW, int C, float* red_ws, long red_ws_floats,
+                      unsigned* red_counters, spg_stream_t stream);
 int spg_add(int dtype, const void* a, const void* b, void* out, long n, spg_stream_t stream);
 int spg_cast_bf16(const float* f32, void* bf16, long n, int to_f32, spg_stream_t stream);
 int spg_copy_channels(int dtype, const void* x, void* y, long M, int C, int ldx, int cx0, int ldy, int cy0,
                       int accumulate, spg_stream_t stream);
 
 /* ---- BatchNorm2d on NHWC rows [M,C] (nn.BatchNorm2d eps 1e-5, momentum 0.1) ----------
- * bn_stats: stats[c] += sum x, stats[C+c] += sum x^2 (caller zeroes stats f32 [2C]).
+ * bn_stats: stats[c] = sum x, stats[C+c] = sum x^2 (f32 [2C], overwritten; deterministic, see above).
  * bn_finalize: training: batch mean / biased var from stats, running stats updated with the unbiased var;
  *   eval: running stats.  Writes scale_shift f32 [2C] (y = x*scale+shift) and mean_invstd f32 [2C].
  * bn_apply: y = relu?(x*scale+shift).
- * bn_bwd_reduce: sums[c] += sum dy', sums[C+c] += sum dy'*xhat, dy' = dy where the (recomputed) ReLU passed.
+ * bn_bwd_reduce: sums[c] = sum dy', sums[C+c] = sum dy'*xhat, dy' = dy where the (recomputed) ReLU passed (overwritten).
  * bn_bwd_apply: dx = gamma*invstd*(dy' - sums0/M - xhat*sums1/M); dgamma += sums1, dbeta += sums0.          */
-int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, spg_stream_t stream);
+int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, float* red_ws, long red_ws_floats, unsigned* red_counters,
+                 spg_stream_t stream);
+/* bn_stats + bn_finalize(training) in ONE launch: the workgroup that finishes a channel slab's sums also writes its scale_shift /
+ * mean_invstd / running statistics; num_batches_tracked (int64 device scalar or NULL) += 1.  stats f32 [2C] is scratch.          */
+int spg_bn_stats_finalize(int dtype, const void* x, float* stats, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, long long* num_batches_tracked, float* scale_shift, float* mean_invstd, long M, int C,
+                          float eps, float momentum, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
 int spg_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* scale_shift, float* mean_invstd, long M, int C, float eps,
                     float momentum, int training, spg_stream_t stream);
 int spg_bn_apply(int dtype, const void* x, const float* scale_shift, void* y, long M, int C, int relu,
                  spg_stream_t stream);
 int spg_bn_bwd_reduce(int dtype, const void* dy, const void* x, const float* scale_shift, const float* mean_invstd,
-                      float* sums, long M, int C, int relu, spg_stream_t stream);
+                      float* sums, long M, int C, int relu, float* red_ws, long red_ws_floats, unsigned* red_counters,
+                      spg_stream_t stream);
 int spg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* scale_shift, const float* mean_invstd,
                      const float* gamma, const float* sums, void* dx, float* dgamma, float* dbeta, long M, int C,
                      int relu, spg_stream_t stream);
@@ -166,37 +192,72 @@ int spg_upsample_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int h,
                               int c0, int accumulate, spg_stream_t stream);
 int spg_se_fc(const float* gap, const float* w1, const float* w2, float* hidden, float* scale, int B, int C, int R,
               spg_stream_t stream);
+/* reductions across workgroups below are deterministic (partials + fixed-order finish by the last workgroup): red_ws is scratch of the
+ * stated size, red_counter ONE 32-bit word that is zero before its first use (see "Deterministic reductions").
+ * se_fc_bwd: B*(C+R) floats.  dwconv3x3_wgrad: 64*9*C floats.  easpp_fuse_bwd: 32*B*6*C floats (dglob is overwritten).            */
 int spg_se_fc_bwd(const float* gap, const float* w1, const float* w2, const float* hidden, const float* scale,
-                  const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, spg_stream_t stream);
+                  const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, float* red_ws, long red_ws_floats,
+                  unsigned* red_counter, spg_stream_t stream);
 int spg_chan_scale(int dtype, const void* x, const float* scale, void* y, int B, long HW, int C, spg_stream_t stream);
 int spg_chan_scale_bwd(int dtype, const void* dy, const float* scale, const float* dgap, void* dx, int B, long HW,
                        int C, spg_stream_t stream);
 int spg_dwconv3x3(int dtype, const void* x, const float* w, void* y, int B, int H, int W, int C, int dil, int flip,
                   spg_stream_t stream);
 int spg_dwconv3x3_wgrad(int dtype, const void* dy, const void* x, float* dw, int B, int H, int W, int C, int dil,
-                        spg_stream_t stream);
+                        float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream);
 int spg_easpp_fuse(int dtype, const void* br0, const void* br1, const void* br2, const void* br3, const float* glob,
                    const float* w, void* y, int B, long HW, int C, spg_stream_t stream);
 int spg_easpp_fuse_bwd(int dtype, const void* dy, const void* br0, const void* br1, const void* br2, const void* br3,
                        const float* glob, const float* w, void* d0, void* d1, void* d2, void* d3, float* dglob,
-                       float* dw, int B, long HW, int C, spg_stream_t stream);
+                       float* dw, int B, long HW, int C, float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream);
 
 /* ---- EFE / PED heads (models/object_detection.py:126-130,155,306,339): 1x1 conv C->1 with bias ------------ */
 int spg_head1x1(int dtype, const void* x, const float* w, const float* b, void* y, long M, int C, spg_stream_t stream);
+long spg_head1x1_bwd_workspace_floats(int C);   /* scratch of spg_head1x1_bwd's deterministic dw / db reduction (+ one zeroed counter) */
 int spg_head1x1_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, long M,
-                    int C, int accumulate, spg_stream_t stream);
+                    int C, int accumulate, float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream);
+
+/* ---- fused CFI / EFE / PED element kernels (csrc/head.hip) ---------------------------------------------------------------------
+ * bn_apply_head: y = relu?(x*scale+shift) (y may be NULL: not stored) and pred[m] = w . y[m,:] + b[0] in one pass -- BN-apply + ReLU +
+ *   the 1x1 head of object_detection.py:150-155 (EFE) and :232-236 + :339 (PED stage end).
+ * ped_gather: pc[B,H,W,Cx+Ce] = cat[ up2(act(x[B,hx,wx,Cx])), up(edge[B,he,we,Ce]) ] (object_detection.py:219-232), act = relu(x*scale+shift)
+ *   when x_scale_shift != NULL (the previous stage's BN-apply folded in), identity otherwise; H = 2*hx, edge scale 2 or 4; Ce may be 0.
+ * ped_gather_bwd: exact adjoint of one source's bilinear upsample (scale 2 or 4), gather form, no atomics:
+ *   dx[B,h,w,C] (+)= up^T(dy[B,H,W,ldy][..., c0:c0+C]).
+ * bn_bwd_head: BatchNorm backward (training) with the 1x1 head's gradient formed on the fly:  dy = dnext (may be NULL) + dpred[m]*head_w[c],
+ *   masked by the recomputed ReLU; dx as spg_bn_bwd_apply; dgamma, dbeta, dhead_w, dhead_b accumulate (+=).  sums: f32 [3C+1] scratch.
+ *   Deterministic reduction: red_ws >= spg_bn_bwd_head_workspace_floats(dtype, C) floats, spg_bn_bwd_head_counters zeroed words.     */
+/* cfi_combine: out[B,H,W,C] = y2 + up(y3[B,h3,w3,C]) + up(y4[B,h4,w4,C]) (bilinear, align_corners=False): the CFI fusion's 1x1 conv over
+ *   cat[s2, up(s3), up(s4)] (feature_integration.py:229-239) evaluated as three GEMMs at each map's own resolution -- a 1x1 conv commutes
+ *   with bilinear interpolation -- so the 2016-channel concat is never built.                                                          */
+int spg_cfi_combine(int dtype, const void* y2, const void* y3, const void* y4, void* out, int B, int H, int W, int h3, int w3, int h4,
+                    int w4, int C, spg_stream_t stream);
+int spg_bn_apply_head(int dtype, const void* x, const float* scale_shift, const float* w, const float* b, void* y, void* pred, long M,
+                      int C, int relu, spg_stream_t stream);
+int spg_ped_gather(int dtype, const void* x, const float* x_scale_shift, int hx, int wx, int Cx, const void* edge, int he, int we, int Ce,
+                   void* y, int B, int H, int W, spg_stream_t stream);
+int spg_ped_gather_bwd(int dtype, const void* dy, void* dx, int B, int h, int w, int C, int H, int W, int ldy, int c0, int accumulate,
+                       spg_stream_t stream);
+long spg_bn_bwd_head_workspace_floats(int dtype, int C);
+int spg_bn_bwd_head_counters(int dtype, int C);
+int spg_bn_bwd_head(int dtype, const void* dnext, const void* x, const void* dpred, const float* head_w, const float* scale_shift,
+                    const float* mean_invstd, const float* gamma, float* sums, void* dx, float* dgamma, float* dbeta, float* dhead_w,
+                    float* dhead_b, long M, int C, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
 
 /* ---- CODLoss, fixed-size ground truth (utils/loss_functions.py:114-295 + resize loop engine/trainer.py:358-383) ----------
- * weight_map: w = 1 + bw*(|Laplace3x3 m| + |avgpool31 m - m|); stats[b] = {sum m, sum w, sum edge_gt, 0} (caller zeroes).
+ * weight_map: w = 1 + bw*(|Laplace3x3 m| + |avgpool31 m - m|); stats[b] = {sum m, sum w, sum edge_gt, -} (overwritten).
  * loss_reduce: per image sums at the TARGET resolution of the bilinearly resized logits: edge=0 -> {sum w*bce, sum s*m*w,
- *   sum (s+m)*w}; edge=1 -> {sum focal, sum s*t, sum s} (caller zeroes sums f32 [B][3]).
+ *   sum (s+m)*w}; edge=1 -> {sum focal, sum s*t, sum s} (sums f32 [B][3], overwritten).  Both reductions are deterministic
+ *   (partials + fixed-order finish): red_ws >= spg_loss_workspace_floats(B, S) floats, red_counters = B zeroed words (see above).
  * loss_finalize: out = {loss, seg_loss, edge_loss} from stats + seg_sums[3][B][3] + edge_sums[B][3].
  * loss_grad: d loss / d prediction at the prediction's own resolution (bilinear adjoint in gather form), times
  *   coef * grad_out[0] (grad_out may be NULL = 1).                                                                    */
+long spg_loss_workspace_floats(int B, int S);
 int spg_loss_weight_map(const float* mask, const float* edge_gt, float* wmap, float* stats, int B, int S,
-                        float boundary_weight, spg_stream_t stream);
+                        float boundary_weight, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
 int spg_loss_reduce(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
-                    float* sums, int B, int S, int h, int w, int edge, float alpha, float gamma, spg_stream_t stream);
+                    float* sums, int B, int S, int h, int w, int edge, float alpha, float gamma, float* red_ws,
+                    long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
 int spg_loss_finalize(const float* stats, const float* seg_sums, const float* edge_sums, float* out, int B, int S,
                       float sw0, float sw1, float sw2, float bce_w, float iou_w, float edge_w, spg_stream_t stream);
 int spg_loss_grad(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
@@ -204,14 +265,25 @@ int spg_loss_grad(int dtype, const void* pred, const float* target, const float*
                   float bce_w, float iou_w, float alpha, float gamma, spg_stream_t stream);
 
 /* ---- optimizer (engine/trainer.py:274-306 param groups, :399-409 clip + AdamW step) over a flat f32 arena ---------
- * sumsq: out[0] += sum x^2.  adamw: step_f[0] += 1, then clip coefficient min(1, clip/(sqrt(gnorm_sq)*grad_scale+1e-6))
+ * sumsq: out[0] = sum x^2 (deterministic: 2048 floats of scratch + one zeroed counter, see "Deterministic reductions").  adamw: step_f[0] += 1, then clip coefficient min(1, clip/(sqrt(gnorm_sq)*grad_scale+1e-6))
  * and a decoupled-weight-decay Adam update; group_of_chunk[i/256] selects lr[g], wd[g] (device arrays, so the
  * scheduler can change them without re-capturing a hipGraph).  Every parameter starts on a 256-element boundary.
  * zero_grad != 0 clears g after use (the next step's kernels accumulate into it), saving a separate memset pass.      */
-int spg_sumsq(const float* x, float* out, long n, spg_stream_t stream);
+int spg_sumsq(const float* x, float* out, long n, float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream);
 int spg_adamw(float* p, float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,
               const float* wd, const float* gnorm_sq, float* step_f, float clip, float beta1, float beta2, float eps,
               float grad_scale, int zero_grad, long n, spg_stream_t stream);
+
+/* adamw fused with the per-step weight re-pack (replaces spg_adamw + spg_pack_batch + spg_pack_conv3x3 inside a train step): while
+ * the new parameter values are in registers the kernel also writes the compute-dtype copies the GEMMs read.  jobs = DEVICE array of
+ *   struct { long off; void* dst; void* dst_t; int R, C, lds, ldd, item0, kind; }          (48 bytes)
+ * kind 1 (matrix): source element (r, c) at arena offset off + r*lds + c; dst[r*ldd + c] and dst_t[c*R + r] (either may be NULL);
+ *   work items = 64 x 64 tiles.  kind 0 (flat, R = 1, C = n elements): dst[i] copy or NULL; kind 2 (3x3 convolution [R = Co][C = Ci][3][3]):
+ *   dst = [Co][tap][Ci], dst_t = [Ci][8 - tap][Co]; both in 4096-element work items.  item0 = prefix sum of work items, total_items their
+ *   sum; the jobs must cover every parameter exactly once.  Other arguments as spg_adamw.                                           */
+int spg_adamw_pack(int dtype, float* p, float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,
+                   const float* wd, const float* gnorm_sq, float* step_f, float clip, float beta1, float beta2, float eps,
+                   float grad_scale, int zero_grad, const void* jobs, int njobs, int total_items, spg_stream_t stream);
 
 #ifdef __cplusplus
 }

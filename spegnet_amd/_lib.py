@@ -28,43 +28,64 @@ SIGNATURES = {
     "spg_pack_conv3x3": "ipppiip",
     "spg_unpack_conv3x3_grad": "ppiip",
     "spg_layernorm_fwd": "ipppppp" "iifp",
-    "spg_layernorm_bwd": "ippppppppp" "iip",
-    "spg_layernorm_param_grads_batch": "ii" "pppppp" "ppp" "p",
+    "spg_layernorm_bwd": "ippppppppp" "ii" "plp" "p",
+    "spg_layernorm_param_grads_batch": "ii" "pppppp" "ppp" "plp" "p",
     "spg_attn_fwd": "ippppp" "iiiiiip",
     "spg_attn_bwd": "ippppppppp" "p" "iiiiiip",
     "spg_maxpool2_fwd": "ippp" "iiiiiip",
     "spg_maxpool2_bwd": "ippp" "iiiiiip",
     "spg_patch_im2col": "ipp" "iiip",
     "spg_preprocess_image": "pp" "iiii" "ppp",
-    "spg_colsum": "ipp" "iiip",
-    "spg_gap_sum": "ipp" "ilip",
-    "spg_chan_prod_sum": "ippp" "ilip",
+    "spg_preprocess_batch": "pppp" "p" "iii" "ppp",
+    "spg_colsum": "ipp" "iiii" "plp" "p",
+    "spg_gap_sum": "ipp" "ili" "plp" "p",
+    "spg_chan_prod_sum": "ippp" "ili" "plp" "p",
     "spg_add": "ippp" "lp",
     "spg_cast_bf16": "pp" "lip",
     "spg_copy_channels": "ipp" "liiiiiip",
-    "spg_bn_stats": "ipp" "lip",
+    "spg_bn_stats": "ipp" "li" "plp" "p",
+    "spg_bn_stats_finalize": "ipp" "ppppppp" "liff" "plp" "p",
     "spg_bn_finalize": "ppppppp" "liffip",
     "spg_bn_apply": "ippp" "liip",
-    "spg_bn_bwd_reduce": "ippppp" "liip",
+    "spg_bn_bwd_reduce": "ippppp" "lii" "plp" "p",
     "spg_bn_bwd_apply": "ippppppppp" "liip",
     "spg_upsample_bilinear": "ipp" "iiiiiiiip",
     "spg_upsample_bilinear_bwd": "ipp" "iiiiiiiiip",
     "spg_se_fc": "ppppp" "iiip",
-    "spg_se_fc_bwd": "ppppppppp" "iiip",
+    "spg_se_fc_bwd": "ppppppppp" "iii" "plp" "p",
     "spg_chan_scale": "ippp" "ilip",
     "spg_chan_scale_bwd": "ipppp" "ilip",
     "spg_dwconv3x3": "ippp" "iiiiiip",
-    "spg_dwconv3x3_wgrad": "ippp" "iiiiip",
+    "spg_dwconv3x3_wgrad": "ippp" "iiiii" "plp" "p",
     "spg_easpp_fuse": "ippppppp" "ilip",
-    "spg_easpp_fuse_bwd": "ipppppppppppp" "p" "ilip",
+    "spg_easpp_fuse_bwd": "ipppppppppppp" "p" "ili" "plp" "p",
     "spg_head1x1": "ipppp" "lip",
-    "spg_head1x1_bwd": "ipppppp" "liip",
-    "spg_loss_weight_map": "pppp" "iifp",
-    "spg_loss_reduce": "ippppp" "iiiiiffp",
+    "spg_head1x1_bwd": "ipppppp" "lii" "plp" "p",
+    "spg_cfi_combine": "ipppp" "iiiiiiii" "p",
+    "spg_bn_apply_head": "ippppp" "p" "lii" "p",
+    "spg_ped_gather": "ipp" "iii" "p" "iii" "p" "iii" "p",
+    "spg_ped_gather_bwd": "ipp" "iiiiiiiii" "p",
+    "spg_bn_bwd_head": "ippppppp" "pppppp" "li" "plp" "p",
+    "spg_loss_weight_map": "pppp" "iif" "plp" "p",
+    "spg_loss_reduce": "ippppp" "iiiiiff" "plp" "p",
     "spg_loss_finalize": "pppp" "iiffffffp",
     "spg_loss_grad": "ippppppp" "iiiiifffffp",
-    "spg_sumsq": "pp" "lp",
+    "spg_sumsq": "pp" "l" "plp" "p",
     "spg_adamw": "ppppppppp" "fffff" "ilp",
+    "spg_adamw_pack": "i" "ppppppppp" "fffff" "i" "pii" "p",
+}
+# name -> (return type, argument types): host-side size queries
+QUERIES = {
+    "spg_gemm_tn_workspace_bytes": ("l", "iiii"),
+    "spg_gemm_tn_group_workspace_bytes": ("l", ""),
+    "spg_gemm_tn_group_desc_bytes": ("l", ""),
+    "spg_reduce_workspace_floats": ("l", "iii"),
+    "spg_reduce_counters": ("i", "iii"),
+    "spg_layernorm_param_grads_batch_workspace_floats": ("l", "ip"),
+    "spg_loss_workspace_floats": ("l", "ii"),
+    "spg_head1x1_bwd_workspace_floats": ("l", "i"),
+    "spg_bn_bwd_head_workspace_floats": ("l", "ii"),
+    "spg_bn_bwd_head_counters": ("i", "ii"),
 }
 _OPTIONAL = {}
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F}
@@ -84,12 +105,9 @@ def load() -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH)
     lib.spg_last_error.restype = ctypes.c_char_p
     lib.spg_version.restype = _I
-    lib.spg_gemm_tn_workspace_bytes.restype = _L
-    lib.spg_gemm_tn_workspace_bytes.argtypes = [_I, _I, _I, _I]
-    lib.spg_gemm_tn_group_workspace_bytes.restype = _L
-    lib.spg_gemm_tn_group_workspace_bytes.argtypes = []
-    lib.spg_gemm_tn_group_desc_bytes.restype = _L
-    lib.spg_gemm_tn_group_desc_bytes.argtypes = []
+    for name, (res, sig) in QUERIES.items():   # size queries: return a count, not a status
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = _CT[res], [_CT[c] for c in sig]
     for table, required in ((SIGNATURES, True), (_OPTIONAL, False)):
         for name, sig in table.items():
             try:

@@ -115,6 +115,67 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// ---- deterministic cross-workgroup reductions ----------------------------------------------------------
+// Every reduction that spans workgroups writes one partial vector per workgroup and the workgroup that arrives LAST at a counter
+// sums the partials in a fixed order (no float atomics: results are bitwise reproducible, which train-mode BatchNorm statistics
+// need).  Hand-off = cdna_hip_programming.md Guideline 16, R1 in its counter form: partials are stored WRITE-THROUGH (st_part: an
+// agent-scope relaxed store = global_store sc1, so no release fence and no L2 write-back per workgroup), every storing wave drains
+// its stores, workgroup barrier, one lane draws a ticket; the last arriver acquires at agent scope (drops this CU's L1) before the
+// workgroup reads the other workgroups' partials with plain loads.  The last arriver re-arms the counter (0), so a counter only
+// has to be zero before its FIRST use.
+__device__ __forceinline__ void st_part(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned expected, unsigned* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = (t == expected - 1u) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0u;
+}
+// out[c] (+)= sum_{b < nblk} part[b * ld + c] for c < ncols, summed in the fixed order b = w, w+NW, ... per wave w, then over the
+// waves in order (NT threads = NW waves, 64 consecutive columns per wave pass).  scratch: NT floats of LDS.
+template <int NT>
+__device__ __forceinline__ void finish_partials(const float* __restrict__ part, int nblk, int ld, int ncols, float* __restrict__ out,
+                                                int accumulate, float* scratch) {
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < ncols; c0 += 64) {
+    const int c = c0 + lane;
+    float s = 0.f;
+    if (c < ncols) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains keep the loads in flight; order stays fixed
+      int b = w;
+      for (; b + 3 * NW < nblk; b += 4 * NW) {
+        s0 += part[(long)b * ld + c];
+        s1 += part[(long)(b + NW) * ld + c];
+        s2 += part[(long)(b + 2 * NW) * ld + c];
+        s3 += part[(long)(b + 3 * NW) * ld + c];
+      }
+      for (; b < nblk; b += NW) s0 += part[(long)b * ld + c];
+      s = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    scratch[threadIdx.x] = s;
+    __syncthreads();
+    if (w == 0 && c < ncols) {
+      float t = scratch[lane];
+#pragma unroll
+      for (int i = 1; i < NW; ++i) t += scratch[i * 64 + lane];
+      out[c] = accumulate ? out[c] + t : t;
+    }
+  }
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace spg

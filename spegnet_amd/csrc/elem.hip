@@ -234,19 +234,23 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ ga
     scale[(long)b * C + c] = sigmoid_f(s);
   }
 }
-// given dscale -> dgap, dw1 +=, dw2 +=
+// given dscale -> dgap, dw1 +=, dw2 += (one block per image; the weight gradients sum over images in image order, by the block
+// that arrives last: ws holds dz[B][C] then dh[B][R])
 __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
                                                         const float* __restrict__ w2, const float* __restrict__ hidden,
                                                         const float* __restrict__ scale, const float* __restrict__ dscale,
                                                         float* __restrict__ dgap, float* __restrict__ dw1,
-                                                        float* __restrict__ dw2, int C, int R) {
-  extern __shared__ float sm[];  // dz[C] + dh[R] + g[C]
-  const int b = blockIdx.x;
-  float* dz = sm; float* dh = sm + C; float* g = dh + R;
+                                                        float* __restrict__ dw2, int C, int R, float* __restrict__ ws,
+                                                        unsigned* __restrict__ counter) {
+  extern __shared__ float sm[];  // dz[C] + dh[R]
+  __shared__ unsigned s_last;
+  const int b = blockIdx.x, B = gridDim.x;
+  float* dz = sm; float* dh = sm + C;
+  float* gdz = ws; float* gdh = ws + (long)B * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float s = scale[(long)b * C + c];
     dz[c] = dscale[(long)b * C + c] * s * (1.f - s);
-    g[c] = gap[(long)b * C + c];
+    st_part(gdz + (long)b * C + c, dz[c]);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -255,17 +259,24 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
     for (int c = lane; c < C; c += 64) s += w2[(long)c * R + r] * dz[c];
     s = wave_sum(s);
     const float hr = hidden[(long)b * R + r];
-    if (lane == 0) dh[r] = hr > 0.f ? s : 0.f;
+    if (lane == 0) { dh[r] = hr > 0.f ? s : 0.f; st_part(gdh + (long)b * R + r, dh[r]); }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
-    for (int r = 0; r < R; ++r) {
-      s += w1[(long)r * C + c] * dh[r];
-      atomicAdd(dw2 + (long)c * R + r, dz[c] * hidden[(long)b * R + r]);
-      atomicAdd(dw1 + (long)r * C + c, dh[r] * g[c]);
-    }
+    for (int r = 0; r < R; ++r) s += w1[(long)r * C + c] * dh[r];
     dgap[(long)b * C + c] = s;
+  }
+  if (!arrive_last(counter, (unsigned)B, &s_last)) return;
+  for (int i = threadIdx.x; i < C * R; i += 256) {
+    const int c = i / R, r = i - c * R;
+    float s2 = 0.f, s1 = 0.f;
+    for (int bb = 0; bb < B; ++bb) {
+      s2 += gdz[(long)bb * C + c] * hidden[(long)bb * R + r];
+      s1 += gdh[(long)bb * R + r] * gap[(long)bb * C + c];
+    }
+    dw2[(long)c * R + r] += s2;
+    dw1[(long)r * C + c] += s1;
   }
 }
 
@@ -304,12 +315,23 @@ __global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const T* __restrict
 }
 
 // ---- dilated depth-wise 3x3 (pad = dil), NHWC, weights f32 [C][9] ------------------------------------------
+// A thread keeps ONE 16-byte channel chunk for its whole grid-stride walk (256 and the grid stride are multiples of the chunk count),
+// so its 9 x VEC weights are loaded once into registers instead of 72 scalar loads per pixel.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
                                                      int B, int H, int W, int C, int dil, int flip) {
   constexpr int VEC = ST<T>::VEC;
   const int nch = C / VEC;
   const long total = (long)B * H * W * nch;
+  const bool fixed = (256 % nch) == 0;                 // chunk index is loop invariant
+  float wr[9][VEC];
+  const int ch0 = threadIdx.x % nch;
+  if (fixed) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) wr[t][e] = w[(ch0 * VEC + e) * 9 + (flip ? 8 - t : t)];
+  }
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int ch = (int)(i % nch);
     long p = i / nch;
@@ -326,9 +348,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
       if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
         float v[VEC];
         unpack16<T>(ld16(x + (((long)b * H + yy) * W + xx) * C + ch * VEC), v);
-        const int tw = flip ? 8 - t : t;
+        if (fixed) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] += w[(ch * VEC + e) * 9 + tw] * v[e];
+          for (int e = 0; e < VEC; ++e) acc[e] += wr[t][e] * v[e];
+        } else {
+          const int tw = flip ? 8 - t : t;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] += w[(ch * VEC + e) * 9 + tw] * v[e];
+        }
       }
     }
     st16(y + i * VEC, pack16<T>(acc));
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            float* __restrict__ dw, int B, int H, int W, int C, int dil,
-                                                           long pix_per_block) {
+                                                           long pix_per_block, float* __restrict__ part, unsigned* __restrict__ counter) {
   constexpr int VEC = ST<T>::VEC;
   const int nch = C / VEC;
   const int ppar = 256 / nch;
@@ -369,6 +396,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     }
   }
   __shared__ float red[256 * 8];
+  __shared__ unsigned s_last;
+  float* mypart = part + (long)blockIdx.x * 9 * C;
   for (int t = 0; t < 9; ++t) {
     __syncthreads();
 #pragma unroll
@@ -377,9 +406,11 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     for (int c = threadIdx.x; c < C; c += 256) {
       float s = 0.f;
       for (int r = 0; r < ppar; ++r) s += red[r * nch * VEC + c];
-      atomicAdd(dw + (long)c * 9 + t, s);
+      st_part(mypart + (long)c * 9 + t, s);
     }
   }
+  if (!arrive_last(counter, gridDim.x, &s_last)) return;
+  finish_partials<256>(part, gridDim.x, 9 * C, 9 * C, dw, 1, red);
 }
 
 // ---- e-ASPP grouped 1x1 over the branch-major concat: y[p][g] = sum_j w[g][j] * cat[p][5g+j] --------------
@@ -421,8 +452,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void easpp_fuse_bwd_reduce_kernel(const T* __restrict__ dy, const T* b0, const T* b1,
                                                                     const T* b2, const T* b3, const float* __restrict__ glob,
                                                                     const float* __restrict__ w, float* __restrict__ dglob,
-                                                                    float* __restrict__ dw, long HW, int C, long rows_per_block) {
+                                                                    float* __restrict__ dw, long HW, int C, long rows_per_block,
+                                                                    float* __restrict__ part, unsigned* __restrict__ counter) {
   const T* br[4] = {b0, b1, b2, b3};
+  __shared__ float scratch[256];
+  __shared__ unsigned s_last;
+  float* mypart = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 6 * C;   // [5C: dw partials][C: dglob partials]
   const long b = blockIdx.y;
   const long r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
   // thread -> (g, j) pairs: 5*C of them; loop
@@ -435,9 +470,14 @@ __global__ __launch_bounds__(256) void easpp_fuse_bwd_reduce_kernel(const T* __r
       sw += d * cat_at<T>(br, glob, b, p, C, cc);
       sd += d;
     }
-    atomicAdd(dw + gj, sw);
-    if (cc >= 4 * C) atomicAdd(dglob + b * C + (cc - 4 * C), w[gj] * sd);
+    st_part(mypart + gj, sw);
+    if (cc >= 4 * C) st_part(mypart + 5 * C + (cc - 4 * C), w[gj] * sd);
   }
+  const int gx = gridDim.x, nimg = gridDim.y;
+  if (!arrive_last(counter, (unsigned)(gx * nimg), &s_last)) return;
+  finish_partials<256>(part, gx * nimg, 6 * C, 5 * C, dw, 1, scratch);
+  for (int bb = 0; bb < nimg; ++bb)
+    finish_partials<256>(part + (long)bb * gx * 6 * C + 5 * C, gx, 6 * C, C, dglob + (long)bb * C, 0, scratch);
 }
 
 // ---- 1x1 prediction heads: y[m] = x[m,:].w + b --------------------------------------------------------------
@@ -493,7 +533,7 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           float* __restrict__ dw, float* __restrict__ db, long M, int C,
-                                                          long rows_per_block) {
+                                                          long rows_per_block, float* __restrict__ part, unsigned* __restrict__ counter) {
   constexpr int VEC = ST<T>::VEC;
   const int nch = C / VEC;
   const int rpar = 256 / nch;
@@ -518,16 +558,21 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const T* __restrict__ 
   for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = acc[e];
   redb[threadIdx.x] = sb;
   __syncthreads();
+  __shared__ unsigned s_last;
+  float* mypart = part + (long)blockIdx.x * (C + 1);
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
     for (int r = 0; r < rpar; ++r) s += red[r * nch * VEC + c];
-    atomicAdd(dw + c, s);
+    st_part(mypart + c, s);
   }
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int r = 0; r < 256; ++r) s += redb[r];
-    atomicAdd(db, s);
+    st_part(mypart + C, s);
   }
+  if (!arrive_last(counter, gridDim.x, &s_last)) return;
+  finish_partials<256>(part, gridDim.x, C + 1, C, dw, 1, red);
+  finish_partials<256>(part + C, gridDim.x, C + 1, 1, db, 1, red);
 }
 
 }  // namespace spg
@@ -653,6 +698,63 @@ __global__ __launch_bounds__(256) void preprocess_image_kernel(const uint8_t* __
   out[2 * plane + idx] = (a2 - m2) * is2;
 }
 
+// The same arithmetic for a whole batch in ONE launch: images of different sizes packed in one device buffer (image i starts at byte
+// offs[i]), blockIdx.y = image; output f32 [B, 3, OH, OW] -- the model's input batch.
+constexpr int PRE_BATCH_MAX = 64;
+struct PreBatch { long off[PRE_BATCH_MAX]; int H[PRE_BATCH_MAX], W[PRE_BATCH_MAX]; };
+__global__ __launch_bounds__(256) void preprocess_batch_kernel(const uint8_t* __restrict__ base, PreBatch pb, float* __restrict__ out, int OH, int OW,
+                                                               float m0, float m1, float m2, float is0, float is1, float is2) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= OH * OW) return;
+  const int b = blockIdx.y;
+  const int H = pb.H[b], W = pb.W[b];
+  const uint8_t* img = base + pb.off[b];
+  const int oy = idx / OW, ox = idx - oy * OW;
+  const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+  int ylo, yn, xlo, xn;
+  float yc, yinv, xc, xinv;
+  aa_taps(oy, sy, H, ylo, yn, yc, yinv);
+  aa_taps(ox, sx, W, xlo, xn, xc, xinv);
+  float wxs = 0.f, wys = 0.f;
+  for (int i = 0; i < xn; ++i) wxs += aa_tri(((float)(i + xlo) - xc + 0.5f) * xinv);
+  for (int j = 0; j < yn; ++j) wys += aa_tri(((float)(j + ylo) - yc + 0.5f) * yinv);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int j = 0; j < yn; ++j) {
+    const float wy = aa_tri(((float)(j + ylo) - yc + 0.5f) * yinv) / wys;
+    const uint8_t* row = img + ((long)(ylo + j) * W + xlo) * 3;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    for (int i = 0; i < xn; ++i) {
+      const float wx = aa_tri(((float)(i + xlo) - xc + 0.5f) * xinv) / wxs;
+      r0 += wx * ((float)row[3 * i] / 255.f);
+      r1 += wx * ((float)row[3 * i + 1] / 255.f);
+      r2 += wx * ((float)row[3 * i + 2] / 255.f);
+    }
+    a0 += wy * r0; a1 += wy * r1; a2 += wy * r2;
+  }
+  const long plane = (long)OH * OW;
+  float* o = out + (long)b * 3 * plane;
+  o[idx] = (a0 - m0) * is0;
+  o[plane + idx] = (a1 - m1) * is1;
+  o[2 * plane + idx] = (a2 - m2) * is2;
+}
+
+/* offs / H / W: HOST arrays of B entries (B <= 64 per call); base: device buffer holding the uint8 HWC images */
+extern "C" int spg_preprocess_batch(const uint8_t* base, const long* offs, const int* H, const int* W, float* out_b3hw, int B, int OH, int OW,
+                                    const float* mean3, const float* std3, spg_stream_t stream) {
+  SPG_REQUIRE(B > 0 && B <= PRE_BATCH_MAX && OH > 0 && OW > 0 && base && offs && H && W && out_b3hw && mean3 && std3,
+              "preprocess_batch: 1..%d images per call, got %d", PRE_BATCH_MAX, B);
+  SPG_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "preprocess_batch: zero std");
+  PreBatch pb;
+  for (int i = 0; i < B; ++i) {
+    SPG_REQUIRE(H[i] > 0 && W[i] > 0 && offs[i] >= 0, "preprocess_batch: image %d has size %dx%d", i, H[i], W[i]);
+    pb.off[i] = offs[i]; pb.H[i] = H[i]; pb.W[i] = W[i];
+  }
+  for (int i = B; i < PRE_BATCH_MAX; ++i) { pb.off[i] = 0; pb.H[i] = 1; pb.W[i] = 1; }
+  hipLaunchKernelGGL(preprocess_batch_kernel, dim3(cdiv((long)OH * OW, 256), B), dim3(256), 0, (hipStream_t)stream, base, pb, out_b3hw, OH, OW,
+                     mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  return check_launch("preprocess_batch");
+}
+
 extern "C" int spg_preprocess_image(const uint8_t* img_hwc, float* out_chw, int H, int W, int OH, int OW, const float* mean3,
                                     const float* std3, spg_stream_t stream) {
   SPG_REQUIRE(H > 0 && W > 0 && OH > 0 && OW > 0 && mean3 && std3, "preprocess_image: bad sizes %dx%d -> %dx%d", H, W, OH, OW);
@@ -668,8 +770,11 @@ extern "C" int spg_se_fc(const float* gap, const float* w1, const float* w2, flo
   return check_launch("se_fc");
 }
 extern "C" int spg_se_fc_bwd(const float* gap, const float* w1, const float* w2, const float* hidden, const float* scale,
-                             const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, spg_stream_t stream) {
-  hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(256), (2 * C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, dscale, dgap, dw1, dw2, C, R);
+                             const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, float* red_ws,
+                             long red_ws_floats, unsigned* red_counter, spg_stream_t stream) {
+  SPG_REQUIRE(red_ws && red_counter && red_ws_floats >= (long)B * (C + R), "se_fc_bwd: needs B*(C+R) floats of scratch and one zeroed counter");
+  hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, dscale, dgap, dw1, dw2, C, R,
+                     red_ws, red_counter);
   return check_launch("se_fc_bwd");
 }
 extern "C" int spg_chan_scale(int dtype, const void* x, const float* scale, void* y, int B, long HW, int C, spg_stream_t stream) {
@@ -698,16 +803,18 @@ extern "C" int spg_dwconv3x3(int dtype, const void* x, const float* w, void* y, 
   else hipLaunchKernelGGL(dwconv_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, (float*)y, B, H, W, C, dil, flip);
   return check_launch("dwconv3x3");
 }
+constexpr int DWW_MAX_BLOCKS = 64;
 extern "C" int spg_dwconv3x3_wgrad(int dtype, const void* dy, const void* x, float* dw, int B, int H, int W, int C, int dil,
-                                   spg_stream_t stream) {
+                                   float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream) {
   const int v = vec_of(dtype);
   SPG_REQUIRE(C % v == 0 && C / v <= 256, "dwconv3x3_wgrad: C alignment");
+  SPG_REQUIRE(red_ws && red_counter && red_ws_floats >= (long)DWW_MAX_BLOCKS * 9 * C, "dwconv3x3_wgrad: needs 64*9*C floats of scratch and one zeroed counter");
   const long npix = (long)B * H * W;
-  long ppb = cdiv(npix, 512);
+  long ppb = cdiv(npix, DWW_MAX_BLOCKS);
   if (ppb < 64) ppb = 64;
   const int grid = cdiv(npix, ppb);
-  if (dtype == SPG_BF16) hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, dw, B, H, W, C, dil, ppb);
-  else hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, dw, B, H, W, C, dil, ppb);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, dw, B, H, W, C, dil, ppb, red_ws, red_counter);
+  else hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, dw, B, H, W, C, dil, ppb, red_ws, red_counter);
   return check_launch("dwconv3x3_wgrad");
 }
 extern "C" int spg_easpp_fuse(int dtype, const void* br0, const void* br1, const void* br2, const void* br3, const float* glob,
@@ -719,17 +826,19 @@ extern "C" int spg_easpp_fuse(int dtype, const void* br0, const void* br1, const
 }
 extern "C" int spg_easpp_fuse_bwd(int dtype, const void* dy, const void* br0, const void* br1, const void* br2, const void* br3,
                                   const float* glob, const float* w, void* d0, void* d1, void* d2, void* d3, float* dglob,
-                                  float* dw, int B, long HW, int C, spg_stream_t stream) {
+                                  float* dw, int B, long HW, int C, float* red_ws, long red_ws_floats, unsigned* red_counter,
+                                  spg_stream_t stream) {
   const long total = (long)B * HW * 4 * C;
   long rpb = cdiv(HW, 32);
   if (rpb < 8) rpb = 8;
   dim3 g2(cdiv(HW, rpb), B);
+  SPG_REQUIRE(red_ws && red_counter && red_ws_floats >= 32L * B * 6 * C, "easpp_fuse_bwd: needs 32*B*6*C floats of scratch and one zeroed counter");
   if (dtype == SPG_BF16) {
     hipLaunchKernelGGL(easpp_fuse_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, w, (bf16_t*)d0, (bf16_t*)d1, (bf16_t*)d2, (bf16_t*)d3, HW, C, total);
-    hipLaunchKernelGGL(easpp_fuse_bwd_reduce_kernel<bf16_t>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)br0, (const bf16_t*)br1, (const bf16_t*)br2, (const bf16_t*)br3, glob, w, dglob, dw, HW, C, rpb);
+    hipLaunchKernelGGL(easpp_fuse_bwd_reduce_kernel<bf16_t>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)br0, (const bf16_t*)br1, (const bf16_t*)br2, (const bf16_t*)br3, glob, w, dglob, dw, HW, C, rpb, red_ws, red_counter);
   } else {
     hipLaunchKernelGGL(easpp_fuse_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)d0, (float*)d1, (float*)d2, (float*)d3, HW, C, total);
-    hipLaunchKernelGGL(easpp_fuse_bwd_reduce_kernel<float>, g2, dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)br0, (const float*)br1, (const float*)br2, (const float*)br3, glob, w, dglob, dw, HW, C, rpb);
+    hipLaunchKernelGGL(easpp_fuse_bwd_reduce_kernel<float>, g2, dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)br0, (const float*)br1, (const float*)br2, (const float*)br3, glob, w, dglob, dw, HW, C, rpb, red_ws, red_counter);
   }
   return check_launch("easpp_fuse_bwd");
 }
@@ -743,19 +852,22 @@ extern "C" int spg_head1x1(int dtype, const void* x, const float* w, const float
   else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, b, (float*)y, M, C);
   return check_launch("head1x1");
 }
+static inline long head_bwd_blocks(int C) { long b = 32768 / C; return b < 64 ? 64 : (b > 512 ? 512 : b); }
+extern "C" long spg_head1x1_bwd_workspace_floats(int C) { return head_bwd_blocks(C) * (C + 1); }
 extern "C" int spg_head1x1_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, long M,
-                               int C, int accumulate, spg_stream_t stream) {
+                               int C, int accumulate, float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream) {
   const int v = vec_of(dtype);
   SPG_REQUIRE(C % v == 0 && C / v <= 256, "head1x1_bwd: C alignment");
+  SPG_REQUIRE(red_ws && red_counter && red_ws_floats >= spg_head1x1_bwd_workspace_floats(C), "head1x1_bwd: reduction workspace too small");
   const long rpar = 256 / (C / v);
-  long rpb = cdiv(M, 1024);
+  long rpb = cdiv(M, head_bwd_blocks(C));
   if (rpb < rpar * 8) rpb = rpar * 8;
   if (dtype == SPG_BF16) {
     hipLaunchKernelGGL(head_bwd_dx_kernel<bf16_t>, dim3(ew_grid(M * (C / v))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, w, (bf16_t*)dx, M, C, accumulate);
-    hipLaunchKernelGGL(head_bwd_dw_kernel<bf16_t>, dim3(cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, dw, db, M, C, rpb);
+    hipLaunchKernelGGL(head_bwd_dw_kernel<bf16_t>, dim3(cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, dw, db, M, C, rpb, red_ws, red_counter);
   } else {
     hipLaunchKernelGGL(head_bwd_dx_kernel<float>, dim3(ew_grid(M * (C / v))), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, M, C, accumulate);
-    hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, dw, db, M, C, rpb);
+    hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, dw, db, M, C, rpb, red_ws, red_counter);
   }
   return check_launch("head1x1_bwd");
 }

@@ -1713,8 +1713,12 @@ __device__ __forceinline__ void tn_group_reduce_body(const TnGroup& g, const flo
   for (int v = ypart * per + threadIdx.x; v < (ypart + 1) * per; v += 256) {
     const int nl = v >> 5, kl = (v & 31) * 4;
     f32x4 s = *reinterpret_cast<const f32x4*>(slabs + ((long)(c - 1) * 2 + 1) * TN_SLOT_FLOATS + v * 4);
+    // (workgroups whose remainder share is empty -- RS < G, i.e. few rows -- wrote no slot: skipping them matters, their slots hold
+    // whatever an earlier launch left in the scratch)
 #pragma unroll 4
-    for (int cc = c; cc <= clast; ++cc) s += *reinterpret_cast<const f32x4*>(slabs + ((long)cc * 2 + 0) * TN_SLOT_FLOATS + v * 4);
+    for (int cc = c; cc <= clast; ++cc)
+      if ((int)((long)(cc + 1) * g.RS / G) > (int)((long)cc * g.RS / G))
+        s += *reinterpret_cast<const f32x4*>(slabs + ((long)cc * 2 + 0) * TN_SLOT_FLOATS + v * 4);
     const int n = tn * 128 + nl, k = tk * 128 + kl;
     if (n < jb.N && k < jb.K) {
       float* d = jb.dW + (long)n * jb.ldw + k;

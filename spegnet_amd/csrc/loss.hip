@@ -36,7 +36,8 @@ __device__ __forceinline__ float pos_weight(float npos, float total) {
 
 // stats[b] = {sum m, sum w, sum edge_gt, 0}
 __global__ __launch_bounds__(256) void loss_wmap_kernel(const float* __restrict__ mask, const float* __restrict__ egt,
-                                                        float* __restrict__ wmap, float* __restrict__ stats, int S, float bw) {
+                                                        float* __restrict__ wmap, float* __restrict__ stats, int S, float bw,
+                                                        float* __restrict__ part, unsigned* __restrict__ counters) {
   __shared__ float tile[62][65];
   __shared__ float hs[62][33];
   __shared__ float red[4];
@@ -80,19 +81,24 @@ __global__ __launch_bounds__(256) void loss_wmap_kernel(const float* __restrict_
   sm = block_sum<256>(sm, red);
   sw = block_sum<256>(sw, red);
   se = block_sum<256>(se, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(stats + b * 4 + 0, sm);
-    atomicAdd(stats + b * 4 + 1, sw);
-    atomicAdd(stats + b * 4 + 2, se);
-  }
+  // deterministic finish: one partial triple per tile, the image's last tile adds them in tile order
+  __shared__ unsigned s_last;
+  const int nblk = gridDim.x * gridDim.y, bl = blockIdx.y * gridDim.x + blockIdx.x;
+  float* pp = part + ((long)b * nblk + bl) * 4;
+  if (threadIdx.x == 0) { st_part(pp, sm); st_part(pp + 1, sw); st_part(pp + 2, se); }
+  if (!arrive_last(counters + b, (unsigned)nblk, &s_last)) return;
+  finish_partials<256>(part + (long)b * nblk * 4, nblk, 4, 3, stats + b * 4, 0, &hs[0][0]);
 }
 
 // sums[b] = {A, I, U}
 template <typename T>
 __global__ __launch_bounds__(256) void loss_seg_reduce_kernel(const T* __restrict__ pred, const float* __restrict__ mask,
                                                               const float* __restrict__ wmap, const float* __restrict__ stats,
-                                                              float* __restrict__ sums, int S, int h, int w) {
+                                                              float* __restrict__ sums, int S, int h, int w,
+                                                              float* __restrict__ part, unsigned* __restrict__ counters) {
   __shared__ float red[4];
+  __shared__ float scratch[256];
+  __shared__ unsigned s_last;
   const int b = blockIdx.y;
   const long HW = (long)S * S;
   const float pw = pos_weight(stats[b * 4 + 0], (float)HW);
@@ -108,15 +114,21 @@ __global__ __launch_bounds__(256) void loss_seg_reduce_kernel(const T* __restric
     A += wv * bce; I += s * m * wv; U += (s + m) * wv;
   }
   A = block_sum<256>(A, red); I = block_sum<256>(I, red); U = block_sum<256>(U, red);
-  if (threadIdx.x == 0) { atomicAdd(sums + b * 3 + 0, A); atomicAdd(sums + b * 3 + 1, I); atomicAdd(sums + b * 3 + 2, U); }
+  float* pp = part + ((long)b * gridDim.x + blockIdx.x) * 4;
+  if (threadIdx.x == 0) { st_part(pp, A); st_part(pp + 1, I); st_part(pp + 2, U); }
+  if (!arrive_last(counters + b, gridDim.x, &s_last)) return;
+  finish_partials<256>(part + (long)b * gridDim.x * 4, gridDim.x, 4, 3, sums + b * 3, 0, scratch);
 }
 
 // sums[b] = {F, I, P}
 template <typename T>
 __global__ __launch_bounds__(256) void loss_edge_reduce_kernel(const T* __restrict__ pred, const float* __restrict__ egt,
                                                                const float* __restrict__ stats, float* __restrict__ sums, int S,
-                                                               int h, int w, float alpha, float gamma) {
+                                                               int h, int w, float alpha, float gamma,
+                                                               float* __restrict__ part, unsigned* __restrict__ counters) {
   __shared__ float red[4];
+  __shared__ float scratch[256];
+  __shared__ unsigned s_last;
   const int b = blockIdx.y;
   const long HW = (long)S * S;
   const float pw = pos_weight(stats[b * 4 + 2], (float)HW);
@@ -132,7 +144,10 @@ __global__ __launch_bounds__(256) void loss_edge_reduce_kernel(const T* __restri
     I += s * t; P += s;
   }
   Fs = block_sum<256>(Fs, red); I = block_sum<256>(I, red); P = block_sum<256>(P, red);
-  if (threadIdx.x == 0) { atomicAdd(sums + b * 3 + 0, Fs); atomicAdd(sums + b * 3 + 1, I); atomicAdd(sums + b * 3 + 2, P); }
+  float* pp = part + ((long)b * gridDim.x + blockIdx.x) * 4;
+  if (threadIdx.x == 0) { st_part(pp, Fs); st_part(pp + 1, I); st_part(pp + 2, P); }
+  if (!arrive_last(counters + b, gridDim.x, &s_last)) return;
+  finish_partials<256>(part + (long)b * gridDim.x * 4, gridDim.x, 4, 3, sums + b * 3, 0, scratch);
 }
 
 struct LossCfg {
@@ -237,26 +252,36 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ pr
 
 using namespace spg;
 
+/* partial floats the two reductions need (wmap tiles / reduce blocks, 4 floats each); both also need B zeroed counters */
+extern "C" long spg_loss_workspace_floats(int B, int S) {
+  const long tiles = (long)cdiv(S, 32) * cdiv(S, 32);
+  return (long)B * 4 * (tiles > 64 ? tiles : 64);
+}
+
 extern "C" int spg_loss_weight_map(const float* mask, const float* edge_gt, float* wmap, float* stats, int B, int S,
-                                   float boundary_weight, spg_stream_t stream) {
+                                   float boundary_weight, float* red_ws, long red_ws_floats, unsigned* red_counters_, spg_stream_t stream) {
   SPG_REQUIRE(B > 0 && S > 0, "loss_weight_map: empty");
-  hipLaunchKernelGGL(loss_wmap_kernel, dim3(cdiv(S, 32), cdiv(S, 32), B), dim3(256), 0, (hipStream_t)stream, mask, edge_gt, wmap, stats, S, boundary_weight);
+  SPG_REQUIRE(red_ws && red_counters_ && red_ws_floats >= spg_loss_workspace_floats(B, S), "loss_weight_map: reduction workspace too small");
+  hipLaunchKernelGGL(loss_wmap_kernel, dim3(cdiv(S, 32), cdiv(S, 32), B), dim3(256), 0, (hipStream_t)stream, mask, edge_gt, wmap, stats, S, boundary_weight,
+                     red_ws, red_counters_);
   return check_launch("loss_weight_map");
 }
 
 extern "C" int spg_loss_reduce(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
-                               float* sums, int B, int S, int h, int w, int edge, float alpha, float gamma, spg_stream_t stream) {
+                               float* sums, int B, int S, int h, int w, int edge, float alpha, float gamma, float* red_ws,
+                               long red_ws_floats, unsigned* red_counters_, spg_stream_t stream) {
   SPG_REQUIRE(S % h == 0 && S % w == 0, "loss_reduce: target size %d must be a multiple of the prediction size %dx%d", S, h, w);
+  SPG_REQUIRE(red_ws && red_counters_ && red_ws_floats >= (long)B * 64 * 4, "loss_reduce: reduction workspace too small");
   long per = ((long)S * S + 255) / 256;
   int gx = (int)(per < 64 ? per : 64);
   dim3 grid(gx, B);
   hipStream_t s = (hipStream_t)stream;
   if (edge) {
-    if (dtype == SPG_BF16) hipLaunchKernelGGL(loss_edge_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred, target, stats, sums, S, h, w, alpha, gamma);
-    else hipLaunchKernelGGL(loss_edge_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)pred, target, stats, sums, S, h, w, alpha, gamma);
+    if (dtype == SPG_BF16) hipLaunchKernelGGL(loss_edge_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred, target, stats, sums, S, h, w, alpha, gamma, red_ws, red_counters_);
+    else hipLaunchKernelGGL(loss_edge_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)pred, target, stats, sums, S, h, w, alpha, gamma, red_ws, red_counters_);
   } else {
-    if (dtype == SPG_BF16) hipLaunchKernelGGL(loss_seg_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred, target, wmap, stats, sums, S, h, w);
-    else hipLaunchKernelGGL(loss_seg_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)pred, target, wmap, stats, sums, S, h, w);
+    if (dtype == SPG_BF16) hipLaunchKernelGGL(loss_seg_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred, target, wmap, stats, sums, S, h, w, red_ws, red_counters_);
+    else hipLaunchKernelGGL(loss_seg_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)pred, target, wmap, stats, sums, S, h, w, red_ws, red_counters_);
   }
   return check_launch("loss_reduce");
 }

@@ -112,15 +112,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // ---------------------------------------------------------------------------------------------------
 enum { RED_SUM = 0, RED_SUM_SQ = 1, RED_BN_BWD = 2, RED_PROD = 3, RED_LN = 4 };
 
+// Grid (row blocks, images, column slabs).  A slab is NCHS <= 16 consecutive 16-byte channel chunks; a block covers 256 / NCHS rows of
+// it at a time.  Block totals go to part[] (plain stores); the block that arrives last at its (image, slab) counter sums the row
+// blocks' partials in a fixed order and writes out (deterministic: no float atomics).
+// optional BatchNorm finalize folded into the last workgroup of a RED_SUM_SQ reduction (gamma == nullptr: none): batch mean / biased
+// variance -> scale_shift, mean_invstd, running statistics (unbiased variance), num_batches_tracked += 1 -- what bn_finalize_kernel does
+// in its own launch (and a torch kernel for the counter)
+struct BnFin {
+  const float* gamma; const float* beta; float* rmean; float* rvar; long long* nbt; float* ss; float* mi;
+  float eps, momentum;
+};
+constexpr int RED_SLAB_CHUNKS = 16;
+constexpr int RED_MAX_GX = 1024;
+constexpr int RED_MAX_BLOCKS = 2048;
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                         const float* __restrict__ p0, const float* __restrict__ p1,
-                                                        float* __restrict__ out, long M, int C, int lda, long rows_per_block,
-                                                        long img_rows, int relu, float* __restrict__ out1) {
+                                                        float* __restrict__ out, float* __restrict__ out1, long M, int C, int lda,
+                                                        long rows_per_block, long img_rows, int relu, int nchs,
+                                                        float* __restrict__ part, unsigned* __restrict__ counters, int accumulate,
+                                                        BnFin fin) {
   constexpr int VEC = ST<T>::VEC;
+  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN);
+  constexpr int K = TWO ? 2 : 1;
   const int nch = C / VEC;
-  const int rpar = 256 / nch;  // rows handled in parallel by a block
-  const int ch = threadIdx.x % nch, rl = threadIdx.x / nch;
+  const int rpar = 256 / nchs;  // rows handled in parallel by a block
+  const int chl = threadIdx.x % nchs, rl = threadIdx.x / nchs;
+  const int slab = blockIdx.z, nslabs = gridDim.z;
+  const int ch = slab * nchs + chl;
+  const bool active = ch < nch && rl < rpar;
   // blockIdx.y = image index for per-image reductions (img_rows > 0), else 0
   const long base = (long)blockIdx.y * img_rows;
   const long rows_total = img_rows > 0 ? img_rows : M;
@@ -133,11 +154,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
   if constexpr (MODE == RED_BN_BWD) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const int c = ch * VEC + e;
+      const int c = active ? ch * VEC + e : 0;
       mu[e] = p0[c]; is[e] = p0[C + c]; sc[e] = p1[c]; sh[e] = p1[C + c];
     }
   }
-  if (rl < rpar) {
+  if (active) {
     for (long r = r0 + rl; r < r1; r += rpar) {
       float av[VEC];
       unpack16<T>(ld16(a + (base + r) * lda + ch * VEC), av);
@@ -171,44 +192,105 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
     }
   }
   __shared__ float red[2][256 * 8];
+  __shared__ unsigned s_last;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x * VEC + e] = s0[e]; red[1][threadIdx.x * VEC + e] = s1[e]; }
   __syncthreads();
-  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN);
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int SW = nchs * VEC;                                // columns of a slab
+  const int gx = gridDim.x;
+  float* mypart = part + ((((long)blockIdx.y * nslabs + slab) * gx) + blockIdx.x) * (K * SW);
+  for (int c = threadIdx.x; c < SW; c += 256) {
     float t0 = 0.f, t1 = 0.f;
     for (int r = 0; r < rpar; ++r) {
-      t0 += red[0][r * nch * VEC + c];
-      if (TWO) t1 += red[1][r * nch * VEC + c];
+      t0 += red[0][r * SW + c];
+      if (TWO) t1 += red[1][r * SW + c];
     }
-    float* o = out + (long)blockIdx.y * C * (TWO ? 2 : 1);
-    atomicAdd(o + c, t0);
-    if (TWO) atomicAdd((out1 ? out1 : o + C) + c, t1);
+    st_part(mypart + c, t0);
+    if (TWO) st_part(mypart + SW + c, t1);
+  }
+  if (!arrive_last(counters + blockIdx.y * nslabs + slab, (unsigned)gx, &s_last)) return;
+  const float* pbase = part + (((long)blockIdx.y * nslabs + slab) * gx) * (K * SW);
+  const int ncols = min(SW, C - slab * SW);
+  float* o = out + (long)blockIdx.y * C * K + slab * SW;
+  finish_partials<256>(pbase, gx, K * SW, ncols, o, accumulate, &red[0][0]);
+  if (TWO) finish_partials<256>(pbase + SW, gx, K * SW, ncols, (out1 ? out1 : out + (long)blockIdx.y * C * K + C) + slab * SW, accumulate, &red[0][0]);
+  if constexpr (MODE == RED_SUM_SQ) {
+    if (fin.gamma) {            // this slab's channels: the sums were just written by threads of wave 0 of THIS block
+      __syncthreads();
+      const float Mf = (float)rows_total;
+      for (int cl = threadIdx.x; cl < ncols; cl += 256) {
+        const int c = slab * SW + cl;
+        const float mu = out[c] / Mf;
+        const float var = fmaxf(out[C + c] / Mf - mu * mu, 0.f);
+        if (fin.rmean) {
+          fin.rmean[c] = (1.f - fin.momentum) * fin.rmean[c] + fin.momentum * mu;
+          const float unb = rows_total > 1 ? var * (Mf / (Mf - 1.f)) : var;
+          fin.rvar[c] = (1.f - fin.momentum) * fin.rvar[c] + fin.momentum * unb;
+        }
+        const float is = rsqrtf(var + fin.eps);
+        const float sc = fin.gamma[c] * is;
+        fin.ss[c] = sc;
+        fin.ss[C + c] = fin.beta[c] - mu * sc;
+        if (fin.mi) { fin.mi[c] = mu; fin.mi[C + c] = is; }
+      }
+      if (slab == 0 && threadIdx.x == 0 && fin.nbt) fin.nbt[0] += 1;
+    }
   }
 }
 
+struct RedPlan { int nchs, nslabs, gx; long rpb; };
+static inline RedPlan red_plan(long rows, int nch, int nimg) {
+  RedPlan p;
+  p.nchs = nch < RED_SLAB_CHUNKS ? nch : RED_SLAB_CHUNKS;
+  p.nslabs = cdiv(nch, p.nchs);
+  const int rpar = 256 / p.nchs;
+  const int ni = nimg > 0 ? nimg : 1;
+  long want = rows / ((long)rpar * 16);              // >= 16 rows per thread: enough blocks to stream at HBM rate, few partials
+  long cap = RED_MAX_BLOCKS / ((long)ni * p.nslabs);
+  if (cap > RED_MAX_GX) cap = RED_MAX_GX;
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  p.rpb = (rows + want - 1) / want;
+  if (p.rpb < rpar) p.rpb = rpar;
+  p.gx = cdiv(rows, p.rpb);
+  return p;
+}
+// upper bounds (any row count) of the scratch a column reduction over C channels / nimg images needs: partial floats, counters
+static inline long red_ws_floats(int vec, int C, int nimg) {
+  const int nch = C / vec, nchs = nch < RED_SLAB_CHUNKS ? nch : RED_SLAB_CHUNKS, nslabs = cdiv(nch, nchs), ni = nimg > 0 ? nimg : 1;
+  long cap = RED_MAX_BLOCKS / ((long)ni * nslabs);
+  if (cap > RED_MAX_GX) cap = RED_MAX_GX;
+  if (cap < 1) cap = 1;
+  return cap * ni * nslabs * 2L * nchs * vec;
+}
+static inline int red_counters(int vec, int C, int nimg) {
+  const int nch = C / vec, nchs = nch < RED_SLAB_CHUNKS ? nch : RED_SLAB_CHUNKS;
+  return cdiv(nch, nchs) * (nimg > 0 ? nimg : 1);
+}
+
+struct RedWs { float* part; long floats; unsigned* counters; };
+
 template <typename T, int MODE>
 static int launch_colreduce(const void* a, const void* b, const float* p0, const float* p1, float* out, long M, int C,
-                            int lda, int nimg, long img_rows, int relu, hipStream_t s, const char* what, float* out1 = nullptr) {
+                            int lda, int nimg, long img_rows, int relu, RedWs ws, int accumulate, hipStream_t s, const char* what,
+                            float* out1 = nullptr, BnFin fin = BnFin{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f}) {
   constexpr int VEC = ST<T>::VEC;
-  if (C % VEC != 0 || C / VEC > 256 || lda % VEC != 0) {
-    set_error("%s: C=%d (lda=%d) must be a multiple of %d and C/%d <= 256", what, C, lda, VEC, VEC);
+  if (C % VEC != 0 || lda % VEC != 0) {
+    set_error("%s: C=%d (lda=%d) must be a multiple of %d", what, C, lda, VEC);
     return SPG_ERR_BAD_ARG;
   }
   const long rows = img_rows > 0 ? img_rows : M;
-  const int rpar = 256 / (C / VEC);
-  // few blocks per output address (the final atomics contend per column), more when there are many rows to stream
-  long want = rows / ((long)rpar * 16);
-  if (want < 384) want = 384;
-  if (want > 2048) want = 2048;
-  want /= (nimg > 0 ? nimg : 1);
-  if (want < 1) want = 1;
-  long rpb = cdiv(rows, want);
-  const long min_rpb = (long)rpar * 8;
-  if (rpb < min_rpb) rpb = min_rpb;
-  const int gx = cdiv(rows, rpb);
-  hipLaunchKernelGGL((colreduce_kernel<T, MODE>), dim3(gx, nimg > 0 ? nimg : 1), dim3(256), 0, s, (const T*)a, (const T*)b,
-                     p0, p1, out, M, C, lda, rpb, img_rows, relu, out1);
+  const RedPlan p = red_plan(rows, C / VEC, nimg);
+  const int ni = nimg > 0 ? nimg : 1;
+  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN);
+  const long need = (long)p.gx * ni * p.nslabs * (TWO ? 2 : 1) * p.nchs * VEC;
+  if (!ws.part || !ws.counters || ws.floats < need) {
+    set_error("%s: reduction workspace of %ld floats (+ %d zeroed counters) required, got %ld", what, need, p.nslabs * ni, ws.floats);
+    return SPG_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL((colreduce_kernel<T, MODE>), dim3(p.gx, ni, p.nslabs), dim3(256), 0, s, (const T*)a, (const T*)b,
+                     p0, p1, out, out1, M, C, lda, p.rpb, img_rows, relu, p.nchs, ws.part, ws.counters, accumulate, fin);
   return check_launch(what);
 }
 
@@ -343,7 +425,7 @@ extern "C" int spg_layernorm_fwd(int dtype, const void* x, const float* gamma, c
 
 extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int M, int C,
-                                 spg_stream_t stream) {
+                                 float* red_ws, long red_ws_floats, unsigned* red_counters_, spg_stream_t stream) {
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(M > 0 && C > 0 && C % vec == 0 && C / vec <= 64 * LN_MAXCH, "layernorm_bwd: bad C=%d", C);
   hipStream_t s = (hipStream_t)stream;
@@ -354,17 +436,9 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
   int rc = check_launch("layernorm_bwd");
   if (rc || (!dgamma && !dbeta)) return rc;
   SPG_REQUIRE(dgamma && dbeta, "layernorm_bwd: dgamma and dbeta must both be given");
-  const int step = 256 * vec;
-  const size_t es = dtype == SPG_BF16 ? 2 : 4;
-  for (int c0 = 0; c0 < C; c0 += step) {
-    const int cs = C - c0 < step ? C - c0 : step;
-    const char* dyp = (const char*)dy + (size_t)c0 * es;
-    const char* xp = (const char*)x + (size_t)c0 * es;
-    rc = DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_LN>(dyp, xp, mean, rstd, dbeta + c0, M, cs, C, 0, 0, 0, s, "layernorm_bwd(params)", dgamma + c0)),
-                    (launch_colreduce<float, RED_LN>(dyp, xp, mean, rstd, dbeta + c0, M, cs, C, 0, 0, 0, s, "layernorm_bwd(params)", dgamma + c0)));
-    if (rc) return rc;
-  }
-  return SPG_OK;
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_LN>(dy, x, mean, rstd, dbeta, M, C, C, 0, 0, 0, ws, 1, s, "layernorm_bwd(params)", dgamma)),
+                    (launch_colreduce<float, RED_LN>(dy, x, mean, rstd, dbeta, M, C, C, 0, 0, 0, ws, 1, s, "layernorm_bwd(params)", dgamma)));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -373,14 +447,15 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
 // costs ~4.5 us of launch floor on this GPU).  Jobs travel in the kernel-argument struct: no device table.
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_BATCH_MAX = 48;
+constexpr int LN_BATCH_BLOCKS = 64;   // row blocks per job (upper bound): the partials of a job are <= 64 x 2C floats
 struct LnJob {
   const void* dy; const void* x; const float* mean; const float* rstd; float* dgamma; float* dbeta;
-  int M, C, ld, block0, rpb;  // C: columns of this job (<= 256 16-byte chunks), ld: row stride; block0: first block; rpb: rows per block
-};
+  int M, C, ld, block0, rpb, nblk, poff;  // C: columns of this job (<= 256 16-byte chunks), ld: row stride; block0: first block; rpb: rows per block;
+};                                        // nblk: its blocks; poff: float offset of its partials
 struct LnBatch { LnJob job[LN_BATCH_MAX]; int njobs; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void ln_param_batch_kernel(LnBatch bt) {
+__global__ __launch_bounds__(256) void ln_param_batch_kernel(LnBatch bt, float* __restrict__ part, unsigned* __restrict__ counters) {
   constexpr int VEC = ST<T>::VEC;
   int j = 0;
 #pragma unroll 1
@@ -391,7 +466,8 @@ __global__ __launch_bounds__(256) void ln_param_batch_kernel(LnBatch bt) {
   const int C = jb.C, nch = C / VEC;
   const int rpar = 256 / nch;
   const int ch = threadIdx.x % nch, rl = threadIdx.x / nch;
-  const long r0 = (long)((int)blockIdx.x - jb.block0) * jb.rpb;
+  const int bl = (int)blockIdx.x - jb.block0;
+  const long r0 = (long)bl * jb.rpb;
   const long r1 = min((long)jb.M, r0 + jb.rpb);
   float s0[VEC], s1[VEC];
 #pragma unroll
@@ -407,25 +483,40 @@ __global__ __launch_bounds__(256) void ln_param_batch_kernel(LnBatch bt) {
     }
   }
   __shared__ float red[2][256 * 8];
+  __shared__ unsigned s_last;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x * VEC + e] = s0[e]; red[1][threadIdx.x * VEC + e] = s1[e]; }
   __syncthreads();
+  float* mypart = part + jb.poff + (long)bl * 2 * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     float t0 = 0.f, t1 = 0.f;
     for (int r = 0; r < rpar; ++r) { t0 += red[0][r * nch * VEC + c]; t1 += red[1][r * nch * VEC + c]; }
-    atomicAdd(jb.dbeta + c, t0);
-    atomicAdd(jb.dgamma + c, t1);
+    st_part(mypart + c, t0);
+    st_part(mypart + C + c, t1);
   }
+  if (!arrive_last(counters + j, (unsigned)jb.nblk, &s_last)) return;
+  finish_partials<256>(part + jb.poff, jb.nblk, 2 * C, C, jb.dbeta, 1, &red[0][0]);
+  finish_partials<256>(part + jb.poff + C, jb.nblk, 2 * C, C, jb.dgamma, 1, &red[0][0]);
+}
+
+/* scratch: LN_BATCH_BLOCKS * 2 * sum(C[i]) floats of partials and njobs zeroed counters */
+extern "C" long spg_layernorm_param_grads_batch_workspace_floats(int njobs, const int* C) {
+  long t = 0;
+  for (int i = 0; i < njobs; ++i) t += (long)LN_BATCH_BLOCKS * 2 * C[i];
+  return t;
 }
 
 extern "C" int spg_layernorm_param_grads_batch(int dtype, int njobs, const void* const* dy, const void* const* x, const float* const* mean,
                                                const float* const* rstd, float* const* dgamma, float* const* dbeta, const int* M,
-                                               const int* C, const int* ld, spg_stream_t stream) {
+                                               const int* C, const int* ld, float* red_ws, long red_ws_floats, unsigned* red_counters_,
+                                               spg_stream_t stream) {
   SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "layernorm_param_grads_batch: bad dtype %d", dtype);
   SPG_REQUIRE(njobs >= 1 && njobs <= LN_BATCH_MAX, "layernorm_param_grads_batch: 1..%d jobs, got %d", LN_BATCH_MAX, njobs);
+  SPG_REQUIRE(red_ws && red_counters_, "layernorm_param_grads_batch: reduction workspace and counters required");
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   LnBatch bt;
   int blocks = 0;
+  long poff = 0;
   for (int i = 0; i < njobs; ++i) {
     SPG_REQUIRE(M[i] > 0 && C[i] > 0 && C[i] % vec == 0 && C[i] / vec <= 256 && ld[i] >= C[i] && ld[i] % vec == 0,
                 "layernorm_param_grads_batch: job %d: bad M=%d C=%d ld=%d (C <= %d columns per job: split wider rows)", i, M[i], C[i], ld[i], 256 * vec);
@@ -433,36 +524,55 @@ extern "C" int spg_layernorm_param_grads_batch(int dtype, int njobs, const void*
     jb.dy = dy[i]; jb.x = x[i]; jb.mean = mean[i]; jb.rstd = rstd[i]; jb.dgamma = dgamma[i]; jb.dbeta = dbeta[i];
     jb.M = M[i]; jb.C = C[i]; jb.ld = ld[i];
     const int rpar = 256 / (C[i] / vec);
-    int rpb = cdiv(M[i], 64);                        // ~64 blocks per job: enough rows in flight, few atomics per column
+    int rpb = cdiv(M[i], LN_BATCH_BLOCKS);           // ~64 blocks per job: enough rows in flight, few partials per column
     if (rpb < rpar * 8) rpb = rpar * 8;
     jb.rpb = rpb; jb.block0 = blocks;
-    blocks += cdiv(M[i], rpb);
+    jb.nblk = cdiv(M[i], rpb);
+    jb.poff = (int)poff;
+    poff += (long)jb.nblk * 2 * C[i];
+    blocks += jb.nblk;
   }
+  SPG_REQUIRE(poff <= red_ws_floats, "layernorm_param_grads_batch: workspace of %ld floats required, got %ld", poff, red_ws_floats);
   for (int i = njobs; i < LN_BATCH_MAX; ++i) bt.job[i] = bt.job[njobs - 1];
   bt.njobs = njobs;
-  if (dtype == SPG_BF16) hipLaunchKernelGGL(ln_param_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
-  else hipLaunchKernelGGL(ln_param_batch_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(ln_param_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt, red_ws, red_counters_);
+  else hipLaunchKernelGGL(ln_param_batch_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt, red_ws, red_counters_);
   return check_launch("layernorm_param_grads_batch");
 }
 
-extern "C" int spg_colsum(int dtype, const void* x, float* out, int M, int C, int ldx, spg_stream_t stream) {
+/* scratch a column reduction over C channels (per image when nimg > 0) needs, for any row count: floats of partials, and counters
+ * (32-bit words that must be ZERO before their first use; every launch leaves them zero again) */
+extern "C" long spg_reduce_workspace_floats(int dtype, int C, int nimg) { return red_ws_floats(dtype == SPG_BF16 ? 8 : 4, C, nimg); }
+extern "C" int spg_reduce_counters(int dtype, int C, int nimg) { return red_counters(dtype == SPG_BF16 ? 8 : 4, C, nimg); }
+
+extern "C" int spg_colsum(int dtype, const void* x, float* out, int M, int C, int ldx, int accumulate, float* red_ws, long red_ws_floats,
+                          unsigned* red_counters_, spg_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  const int vec = dtype == SPG_BF16 ? 8 : 4;
-  const int step = 256 * vec;  // columns per launch
-  for (int c0 = 0; c0 < C; c0 += step) {
-    const int cs = C - c0 < step ? C - c0 : step;
-    const char* xp = (const char*)x + (size_t)c0 * (dtype == SPG_BF16 ? 2 : 4);
-    int rc = DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM>(xp, nullptr, nullptr, nullptr, out + c0, M, cs, ldx, 0, 0, 0, s, "colsum")),
-                        (launch_colreduce<float, RED_SUM>(xp, nullptr, nullptr, nullptr, out + c0, M, cs, ldx, 0, 0, 0, s, "colsum")));
-    if (rc) return rc;
-  }
-  return SPG_OK;
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM>(x, nullptr, nullptr, nullptr, out, M, C, ldx, 0, 0, 0, ws, accumulate, s, "colsum")),
+                    (launch_colreduce<float, RED_SUM>(x, nullptr, nullptr, nullptr, out, M, C, ldx, 0, 0, 0, ws, accumulate, s, "colsum")));
 }
 
-extern "C" int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, spg_stream_t stream) {
+extern "C" int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, float* red_ws, long red_ws_floats,
+                            unsigned* red_counters_, spg_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, s, "bn_stats")),
-                    (launch_colreduce<float, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, s, "bn_stats")));
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats")),
+                    (launch_colreduce<float, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats")));
+}
+
+// batch statistics AND the finalize in one launch (training mode): stats f32 [2C] scratch (overwritten), the rest as bn_finalize;
+// num_batches_tracked (int64, may be NULL) is incremented
+extern "C" int spg_bn_stats_finalize(int dtype, const void* x, float* stats, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, long long* num_batches_tracked, float* scale_shift, float* mean_invstd, long M,
+                                     int C, float eps, float momentum, float* red_ws, long red_ws_floats, unsigned* red_counters_,
+                                     spg_stream_t stream) {
+  SPG_REQUIRE(gamma && beta && scale_shift && stats, "bn_stats_finalize: gamma, beta, stats and scale_shift are required");
+  hipStream_t s = (hipStream_t)stream;
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  const BnFin fin{gamma, beta, running_mean, running_var, num_batches_tracked, scale_shift, mean_invstd, eps, momentum};
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats_finalize", nullptr, fin)),
+                    (launch_colreduce<float, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats_finalize", nullptr, fin)));
 }
 
 extern "C" int spg_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
@@ -491,10 +601,12 @@ extern "C" int spg_bn_apply(int dtype, const void* x, const float* scale_shift, 
 }
 
 extern "C" int spg_bn_bwd_reduce(int dtype, const void* dy, const void* x, const float* scale_shift,
-                                 const float* mean_invstd, float* sums, long M, int C, int relu, spg_stream_t stream) {
+                                 const float* mean_invstd, float* sums, long M, int C, int relu, float* red_ws, long red_ws_floats,
+                                 unsigned* red_counters_, spg_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_BN_BWD>(dy, x, mean_invstd, scale_shift, sums, M, C, C, 0, 0, relu, s, "bn_bwd_reduce")),
-                    (launch_colreduce<float, RED_BN_BWD>(dy, x, mean_invstd, scale_shift, sums, M, C, C, 0, 0, relu, s, "bn_bwd_reduce")));
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_BN_BWD>(dy, x, mean_invstd, scale_shift, sums, M, C, C, 0, 0, relu, ws, 0, s, "bn_bwd_reduce")),
+                    (launch_colreduce<float, RED_BN_BWD>(dy, x, mean_invstd, scale_shift, sums, M, C, C, 0, 0, relu, ws, 0, s, "bn_bwd_reduce")));
 }
 
 extern "C" int spg_bn_bwd_apply(int dtype, const void* dy, const void* x, const float* scale_shift,
@@ -513,16 +625,19 @@ extern "C" int spg_bn_bwd_apply(int dtype, const void* dy, const void* x, const 
   return check_launch("bn_bwd_apply");
 }
 
-// per-image column mean numerators: out[b][c] += sum_hw x[b][hw][c]   (caller divides / zeroes)
-extern "C" int spg_gap_sum(int dtype, const void* x, float* out, int B, long HW, int C, spg_stream_t stream) {
+// per-image column mean numerators: out[b][c] = sum_hw x[b][hw][c]   (caller divides)
+extern "C" int spg_gap_sum(int dtype, const void* x, float* out, int B, long HW, int C, float* red_ws, long red_ws_floats,
+                           unsigned* red_counters_, spg_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM>(x, nullptr, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, s, "gap_sum")),
-                    (launch_colreduce<float, RED_SUM>(x, nullptr, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, s, "gap_sum")));
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM>(x, nullptr, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, ws, 0, s, "gap_sum")),
+                    (launch_colreduce<float, RED_SUM>(x, nullptr, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, ws, 0, s, "gap_sum")));
 }
-// per-image channel products: out[b][c] += sum_hw a[b][hw][c]*b[b][hw][c]   (SE scale gradient)
-extern "C" int spg_chan_prod_sum(int dtype, const void* a, const void* b, float* out, int B, long HW, int C,
-                                 spg_stream_t stream) {
+// per-image channel products: out[b][c] = sum_hw a[b][hw][c]*b[b][hw][c]   (SE scale gradient)
+extern "C" int spg_chan_prod_sum(int dtype, const void* a, const void* b, float* out, int B, long HW, int C, float* red_ws,
+                                 long red_ws_floats, unsigned* red_counters_, spg_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_PROD>(a, b, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, s, "chan_prod_sum")),
-                    (launch_colreduce<float, RED_PROD>(a, b, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, s, "chan_prod_sum")));
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_PROD>(a, b, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, ws, 0, s, "chan_prod_sum")),
+                    (launch_colreduce<float, RED_PROD>(a, b, nullptr, nullptr, out, B * HW, C, C, B, HW, 0, ws, 0, s, "chan_prod_sum")));
 }

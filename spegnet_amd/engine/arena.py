@@ -96,17 +96,50 @@ class Arena:
             self.g.zero_()
         self._clean = False
 
-    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, packer=None):
+        """Global-norm clip + AdamW.  packer (the model's Engine): the update kernel also writes the compute-dtype weight copies of the
+        next forward (spg_adamw_pack) instead of leaving them to a separate re-pack pass."""
         if self.m is None:
             self.m = torch.zeros_like(self.p)
             self.v = torch.zeros_like(self.p)
         s = torch.cuda.current_stream().cuda_stream
-        self.gnorm_sq.zero_()
-        _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, s)
-        _lib.call("spg_adamw", self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                  self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
-                  self.step_f.data_ptr(), float(clip), betas[0], betas[1], eps, float(grad_scale), 1, self.size, s)
+        from .. import ops
+        if getattr(self, "_red_ws", None) is None:
+            self._red_ws = torch.empty(2048, dtype=torch.float32, device=self.p.device)
+        es = 2 if (packer is not None and packer.dtype == torch.bfloat16) else 4
+        # algorithmic bytes: sumsq reads g; adamw reads p, g, m, v and writes p, m, v, g (cleared) (+ the two compute-dtype copies)
+        with ops._prof("sumsq + adamw_pack (clip + AdamW + weight re-pack)" if packer is not None else "sumsq + adamw", "hbm",
+                       self.size * (4 + 32 + (2 * es if packer is not None else 0))):
+            _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, self._red_ws.data_ptr(), 2048,
+                      ops.red_counters(self.p.device, 1), s)
+            if packer is not None:
+                blob, njobs, items = packer.opt_jobs(self)
+                dt = _lib.SPG_BF16 if packer.dtype == torch.bfloat16 else _lib.SPG_F32
+                _lib.call("spg_adamw_pack", dt, self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                          self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
+                          self.step_f.data_ptr(), float(clip), betas[0], betas[1], eps, float(grad_scale), 1, blob.data_ptr(), njobs, items, s)
+            else:
+                _lib.call("spg_adamw", self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                          self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
+                          self.step_f.data_ptr(), float(clip), betas[0], betas[1], eps, float(grad_scale), 1, self.size, s)
         self._clean = True
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_f.clone(), "lr": self.lr.clone(), "wd": self.wd.clone()}
+        """Optimizer state of the flat arena: Adam moments (arena layout), step counter, per-group lr / weight decay, and the name ->
+        (offset, numel) table that lets load_state_dict verify the layout."""
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(self.p), torch.zeros_like(self.p)
+        return {"m": self.m.clone(), "v": self.v.clone(), "step": self.step_f.clone(), "lr": self.lr.clone(), "wd": self.wd.clone(),
+                "layout": {n: self.offsets[n] for n in self.names}, "size": self.size}
+
+    def load_state_dict(self, sd) -> None:
+        """Restores what state_dict() saved (checkpoint resume: the reference only saves, engine/trainer.py:588-606).  The parameters
+        themselves come from the model's state_dict; this restores m, v, the step counter and the learning rates."""
+        if int(sd["size"]) != self.size or any(self.offsets.get(n) != o for n, o in sd["layout"].items()):
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        dev = self.p.device
+        self.m = sd["m"].to(dev, torch.float32).clone()
+        self.v = sd["v"].to(dev, torch.float32).clone()
+        self.step_f.copy_(sd["step"].to(dev))
+        self.lr.copy_(sd["lr"].to(dev))
+        self.wd.copy_(sd["wd"].to(dev))

@@ -72,8 +72,8 @@ class TrainStep:
         return {k: v.detach() for k, v in losses.items()}
 
     def _opt(self, scale: float):
-        self.arena.step(self.clip, grad_scale=scale)
-        self.model._engine.pack()  # compute-dtype copies for the next forward (inside the step so it is captured too)
+        # AdamW writes the compute-dtype weight copies of the next forward itself (spg_adamw_pack): no separate re-pack pass
+        self.arena.step(self.clip, grad_scale=scale, packer=self.model._engine)
 
     def _eager(self, images, masks, edges):
         losses = self._fwd_bwd(images, masks, edges)
@@ -235,6 +235,13 @@ class TrainStep:
                 self._capture_segmented(images, masks, edges)
             else:
                 self._capture(images, masks, edges)
+        # the captured graphs are frozen to the shapes of the first batch: anything else (a short last batch, another ground-truth size)
+        # runs eagerly instead of being broadcast into / rejected by the static buffers
+        if any(dst.shape != src.shape for dst, src in zip(self.static, (images, masks, edges))):
+            if self.world > 1:
+                raise RuntimeError("a batch shape that differs from the captured one needs drop_last=True in multi-GPU graph mode "
+                                   "(ranks would disagree on the collective schedule)")
+            return self._eager(images, masks, edges)
         for dst, src in zip(self.static, (images, masks, edges)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
@@ -251,7 +258,7 @@ class TrainingMonitor:
     def __init__(self, dir_manager=None):
         self.dir_manager = dir_manager
         self.history: List[Dict] = []
-        self.best = -1.0
+        self.best = -float("inf")
         self._sums: Dict[str, float] = {}
         self._n = 0
 
@@ -259,6 +266,14 @@ class TrainingMonitor:
         for k, v in metrics.items():
             self._sums[k] = self._sums.get(k, 0.0) + float(v) * n
         self._n += n
+
+    def check_best_model(self, metrics: Dict[str, float], key: str = "s_alpha") -> bool:
+        """True when the structure measure improved as well (reference engine/trainer.py:156-183 keeps the best S_alpha)."""
+        v = float(metrics.get(key, metrics.get("weighted_f", -metrics.get("loss", 0.0))))
+        if v > self.best:
+            self.best = v
+            return True
+        return False
 
     def end_epoch(self, epoch: int, phase: str) -> Dict[str, float]:
         m = {k: v / max(self._n, 1) for k, v in self._sums.items()}
@@ -295,7 +310,7 @@ class Trainer:
             self.sync = GradSync(self.arena.g, self.arena.unit_ends)
         self.step_fn = TrainStep(self.model, self.criterion, self.arena, self.grad_clip, self.sync,
                                  capture=bool(self.config.get('capture_graph', False)))
-        self._plateau_best, self._plateau_bad = -1.0, 0
+        self._plateau_best, self._plateau_bad = -float("inf"), 0
 
     # ---- optimisation set-up (reference engine/trainer.py:255-306) --------------------------------------
     def _get_param_groups(self) -> List[Dict]:
@@ -336,7 +351,16 @@ class Trainer:
         edges = [e.to(self.device, non_blocking=True) for e in batch['edges']]
         timing['data_time'] = time.time() - t0
         same = all(m.shape == masks[0].shape for m in masks) and all(e.shape == edges[0].shape for e in edges)
-        if is_train and same:
+        # the fused step (HIP CODLoss) needs square ground truth of ONE size that is a multiple of every prediction size; everything
+        # else -- original-resolution masks such as 640x480 or 400x400 against 384 logits -- takes the reference's per-sample path
+        S = masks[0].shape[-1]
+        fused_ok = (same and masks[0].shape[-2] == S and edges[0].shape == masks[0].shape and images.shape[-1] == images.shape[-2]
+                    and all(S % (images.shape[-1] // d) == 0 for d in (8, 4, 2, 1)))
+        if self.sync is not None:   # every rank must take the same path (the two paths issue different collectives)
+            flag = torch.tensor([1.0 if fused_ok else 0.0], device=self.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            fused_ok = bool(flag.item() > 0.5)
+        if is_train and fused_ok:
             t1 = time.time()
             metrics = self.step_fn(images, torch.stack(masks), torch.stack(edges))
             timing['step_time'] = time.time() - t1
@@ -377,26 +401,71 @@ class Trainer:
             self.monitor.update_batch(metrics, len(batch['masks']))
         return self.monitor.end_epoch(-1, "val")
 
-    def train(self, dataset_dirs: Sequence[str]):
-        """Full loop of reference engine/trainer.py:522-586; needs the COD datasets on disk."""
+    def _loaders(self, dataset_dirs: Sequence[str]):
+        """This package's loader (utils/data_loader.py, the reference's surface + pinned memory + optional device preprocessing), or --
+        `training.use_host_loader: true` -- the host tree's utils.data_loader when the package is dropped into the reference checkout."""
+        kw = dict(dataset_dirs=list(dataset_dirs), model_config=self.model_config, batch_size=self.batch_size,
+                  num_workers=self.config.get('num_workers', 8), val_ratio=self.config.get('val_ratio', 0.1))
+        if self.config.get('use_host_loader', False):
+            try:
+                from utils.data_loader import get_training_loaders as host_loaders   # the reference's module (utils/data_loader.py:214-314)
+            except ImportError as e:
+                raise ImportError("training.use_host_loader is set but `utils.data_loader` is not importable: run from the reference "
+                                  "checkout (its utils/ on sys.path) or unset the flag to use spegnet_amd.utils.data_loader") from e
+            return host_loaders(**kw)
         from ..utils.data_loader import get_training_loaders
-        train_loader, val_loader = get_training_loaders(dataset_dirs, self.model_config['image_processing'], self.batch_size,
-                                                        self.config.get('num_workers', 8), self.config.get('val_ratio', 0.1))
-        best, bad = float('inf'), 0
-        for epoch in range(self.num_epochs):
-            tr = self.train_epoch(train_loader, epoch)
-            va = self.validate(val_loader)
-            self.scheduler_step(-va['loss'])
-            logger.info("epoch %d train %s val %s", epoch, tr, va)
-            if va['loss'] < best - self.config.get('min_delta', 0.0):
-                best, bad = va['loss'], 0
-                self._save_checkpoint(epoch, va, is_best=True)
-            else:
-                bad += 1
+        return get_training_loaders(device_preprocess=bool(self.config.get('device_preprocess', False)), **kw)
+
+    def _batches(self, loader):
+        """batches one step ahead of the compute stream (pinned H2D + batched device preprocessing on a copy stream)"""
+        if self.device.type != 'cuda':
+            return loader
+        from ..utils.data_loader import DeviceBatcher, prefetch
+        ip = self.model_config.get('image_processing', {})
+        if getattr(self, "_batcher", None) is None and self.config.get('device_preprocess', False):
+            self._batcher = DeviceBatcher(ip.get('target_size', 512), ip.get('normalize_mean', (0.485, 0.456, 0.406)),
+                                          ip.get('normalize_std', (0.229, 0.224, 0.225)), self.device)
+        return prefetch(loader, getattr(self, "_batcher", None), self.device)
+
+    def train(self, dataset_dirs: Sequence[str]):
+        """Training loop of reference engine/trainer.py:522-586: plateau scheduler, early stop (min_delta 1e-4) and best checkpoint are
+        driven by the validation weighted F-measure when validation computes it (Evaluator metrics), by -loss otherwise."""
+        train_loader, val_loader = self._loaders(dataset_dirs)
+        logger.info("Training samples: %d", len(train_loader.dataset))
+        best, bad = 0.0, 0
+        min_delta = self.config.get('min_delta', 1e-4)
+        start = getattr(self, "_start_epoch", 0)
+        for epoch in range(start, self.num_epochs):
+            tr = self.train_epoch(self._batches(train_loader), epoch)
+            va = tr
+            if val_loader is not None:
+                va = self.validate(self._batches(val_loader))
+                score = va['weighted_f'] if 'weighted_f' in va else -va['loss']
+                self.scheduler_step(score)
+                if score - best > min_delta or (epoch == start and 'weighted_f' not in va):
+                    best, bad = score, 0
+                    if self.monitor.check_best_model(va):
+                        self._save_checkpoint(epoch, va, is_best=True)
+                else:
+                    bad += 1
                 if bad >= self.early_stop_patience:
+                    logger.info("Early stopping triggered")
                     break
+            logger.info("epoch %d train %s val %s", epoch, tr, va)
             if (epoch + 1) % self.save_freq == 0:
                 self._save_checkpoint(epoch, va, is_best=False)
+
+    def resume(self, path: str) -> int:
+        """Checkpoint resume (the reference saves but never loads optimizer state, engine/trainer.py:588-606): restores the model,
+        the arena's Adam moments / step / learning rates and the scheduler bookkeeping; returns the next epoch."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ckpt['model_state_dict'])
+        self.arena.load_state_dict(ckpt['optimizer_state_dict'])
+        sch = ckpt.get('scheduler_state_dict') or {}
+        self._plateau_best, self._plateau_bad = sch.get('best', self._plateau_best), sch.get('bad', self._plateau_bad)
+        self.model.mark_params_changed()
+        self._start_epoch = int(ckpt.get('epoch', -1)) + 1
+        return self._start_epoch
 
     def _save_checkpoint(self, epoch: int, metrics: Dict, is_best: bool = False):
         """Same checkpoint schema as reference engine/trainer.py:588-606 (model_state_dict + config are what

@@ -21,6 +21,7 @@ from .params import block_table
 
 Tensor = torch.Tensor
 EASPP_RATES = (1, 6, 12, 18)
+FUSION_W = "fusion.conv1x1.weight"
 PATCH_KPAD = 160  # 3*7*7 = 147 padded to a multiple of 16 elements
 
 
@@ -76,7 +77,7 @@ class Engine:
             for name, p in P.items():
                 if not name.endswith(".weight") or p.dim() < 2:
                     continue
-                if name.endswith("patch_embed.proj.weight"):
+                if name.endswith("patch_embed.proj.weight") or name == FUSION_W:
                     continue
                 if p.dim() == 4 and p.shape[2] == 3 and p.shape[1] > 1:
                     self._pack_conv.append(name)
@@ -102,21 +103,97 @@ class Engine:
         for name in self._pack_conv:
             f, d = ops.pack_conv3x3(P[name].detach(), T, W.get(name), W.get(name + ":dgrad"))
             W[name], W[name + ":dgrad"] = f, d
+        # CFI fusion conv, split by input map ([512, 288 | 576 | 1152]): one [N,K] / [K,N] pair per source (head_fwd evaluates the conv per
+        # source resolution); per step these copies are written by the fused optimizer (opt_jobs), this path runs at load time only
+        fw = P[FUSION_W].detach().view(P[FUSION_W].shape[0], -1)
+        for tag, (a, b) in self.fusion_split().items():
+            sub = fw[:, a:b].contiguous()
+            W[FUSION_W + tag] = ops.pack_matrix(sub, T, out=W.get(FUSION_W + tag))
+            W[FUSION_W + tag + "T"] = ops.pack_matrix(sub, T, transpose=True, out=W.get(FUSION_W + tag + "T"))
         e = "encoder.encoder.patch_embed.proj.weight"
         pw = P[e]
         w2 = torch.zeros((pw.shape[0], PATCH_KPAD), dtype=torch.float32, device=pw.device)
         w2[:, :147] = pw.detach().reshape(pw.shape[0], 147)
         W[e] = ops.pack_matrix(w2, T, out=W.get(e))
 
+    def fusion_split(self):
+        """column ranges of fusion.conv1x1.weight [512, C2+C3+C4] belonging to s2 / s3 / s4"""
+        d = self.cfg["embed_dim"]
+        c2, c3, c4 = 2 * d, 4 * d, 8 * d
+        return {":s2": (0, c2), ":s3": (c2, c2 + c3), ":s4": (c2 + c3, c2 + c3 + c4)}
+
+    def opt_jobs(self, arena):
+        """Job table of spg_adamw_pack (AdamW fused with this re-pack): (device blob, jobs, work items).  Covers every parameter of
+        the arena once: matrices as 64 x 64 tiles with their [N,K] / [K,N] copies, 3x3 convolutions and everything else as flat
+        4096-element chunks (runs of parameters that need no copy are merged into one flat job: the arena is contiguous)."""
+        import struct
+        key = (arena.p.data_ptr(), tuple(t.data_ptr() for t in self.W.values()))
+        if getattr(self, "_opt_jobs_key", None) == key:
+            return self._opt_jobs
+        if not self.W:
+            self.pack()
+        P, W = self.P, self.W
+        recs, item0 = [], 0
+        run = None     # [off, end] of a run of copy-less parameters
+
+        def flush():
+            nonlocal run, item0
+            if run is not None:
+                n = run[1] - run[0]
+                recs.append(struct.pack("<qQQiiiiii", run[0], 0, 0, 1, n, n, n, item0, 0))
+                item0 += (n + 4095) // 4096
+                run = None
+
+        e = "encoder.encoder.patch_embed.proj.weight"
+        for name in arena.names:
+            p, off = P[name], arena.offsets[name]
+            n = p.numel()
+            rec = None
+            if name == FUSION_W:       # three column slices of one parameter (source row stride = its full width)
+                flush()
+                R, Ct = p.shape[0], n // p.shape[0]
+                for tag, (a, b) in self.fusion_split().items():
+                    recs.append(struct.pack("<qQQiiiiii", off + a, W[name + tag].data_ptr(), W[name + tag + "T"].data_ptr(), R, b - a, Ct, b - a, item0, 1))
+                    item0 += ((R + 63) // 64) * ((b - a + 63) // 64)
+                continue
+            if name == e:
+                rec = (off, W[e].data_ptr(), 0, p.shape[0], 147, 147, PATCH_KPAD, 1)
+            elif name + ":dgrad" in W:
+                rec = (off, W[name].data_ptr(), W[name + ":dgrad"].data_ptr(), p.shape[0], p.shape[1], 0, 0, 2)
+            elif name + ":T" in W:
+                R = p.shape[0]
+                C = n // R
+                rec = (off, W[name].data_ptr(), W[name + ":T"].data_ptr(), R, C, C, C, 1)
+            elif name in W:      # qkv bias: a compute-dtype copy of a vector
+                rec = (off, W[name].data_ptr(), 0, 1, n, n, n, 0)
+            if rec is None:
+                if run is not None and run[1] <= off:
+                    run[1] = off + n
+                else:
+                    flush()
+                    run = [off, off + n]
+                continue
+            flush()
+            o, d, dt_, R, C, lds, ldd, kind = rec
+            recs.append(struct.pack("<qQQiiiiii", o, d, dt_, R, C, lds, ldd, item0, kind))
+            if kind == 1:
+                item0 += ((R + 63) // 64) * ((C + 63) // 64)
+            elif kind == 2:
+                item0 += (R * C * 9 + 4095) // 4096
+            else:
+                item0 += (C + 4095) // 4096
+        flush()
+        blob = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(arena.p.device)
+        self._opt_jobs_key, self._opt_jobs = key, (blob, len(recs), item0)
+        return self._opt_jobs
+
     # ------------------------------------------------------------------------------------------------ BN
     def bn_fwd(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool):
         P = self.P
         M = x.numel() // C
         if training:
-            stats = ops.bn_stats(x, C)
-            ss, mi = ops.bn_finalize(stats, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
-                                     P[prefix + "running_var"], M, True)
-            P[prefix + "num_batches_tracked"] += 1
+            ss, mi = ops.bn_stats_finalize(x, C, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
+                                           P[prefix + "running_var"], P[prefix + "num_batches_tracked"])
         else:
             ss, mi = ops.bn_finalize(None, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
                                      P[prefix + "running_var"], M, False)
@@ -126,6 +203,20 @@ class Engine:
             st = BNState()
             st.x, st.ss, st.mi, st.C, st.relu, st.prefix = x, ss, mi, C, relu, prefix
         return y, st
+
+    def bn_prepare(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool) -> BNState:
+        """Statistics / scale-shift only: the apply is fused into whichever kernel consumes x (bn_apply_head, ped_gather)."""
+        P = self.P
+        M = x.numel() // C
+        if training:
+            ss, mi = ops.bn_stats_finalize(x, C, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
+                                           P[prefix + "running_var"], P[prefix + "num_batches_tracked"])
+        else:
+            ss, mi = ops.bn_finalize(None, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
+                                     P[prefix + "running_var"], M, False)
+        st = BNState()
+        st.x, st.ss, st.mi, st.C, st.relu, st.prefix = (x if save else None), ss, mi, C, relu, prefix
+        return st
 
     def bn_bwd(self, st: BNState, dy: Tensor) -> Tensor:
         return ops.bn_bwd(dy, st.x, st.ss, st.mi, self.P[st.prefix + "weight"], self.grad(st.prefix + "weight"),
@@ -386,12 +477,13 @@ class Engine:
         Ct = C2 + C3 + C4
         dev = s2.device
         c: dict = {"B": B, "h": h, "w": w, "chans": (C2, C3, C4), "s_shapes": (s3.shape, s4.shape)}
-        # --- CFI fusion: gather-upsample-concat -> 1x1 -> BN -> ReLU -> SE
-        cat = torch.empty((M, Ct), dtype=T, device=dev)
-        ops.copy_channels(s2, cat, M, C2, C2, 0, Ct, 0)
-        ops.upsample_into(s3, cat, B, s3.shape[1], s3.shape[2], C3, h, w, Ct, C2)
-        ops.upsample_into(s4, cat, B, s4.shape[1], s4.shape[2], C4, h, w, Ct, C2 + C3)
-        f0 = ops.gemm_nt(cat, W["fusion.conv1x1.weight"])
+        # --- CFI fusion: 1x1 conv over cat[s2, up(s3), up(s4)] evaluated per source resolution (a 1x1 conv commutes with bilinear
+        # interpolation): three GEMMs + one combine pass, no 2016-channel concat buffer -> BN -> ReLU -> SE
+        h3, w3, h4, w4 = s3.shape[1], s3.shape[2], s4.shape[1], s4.shape[2]
+        y2 = ops.gemm_nt(s2.reshape(M, C2), W[FUSION_W + ":s2"])
+        y3 = ops.gemm_nt(s3.reshape(-1, C3), W[FUSION_W + ":s3"])
+        y4 = ops.gemm_nt(s4.reshape(-1, C4), W[FUSION_W + ":s4"])
+        f0 = ops.cfi_combine(y2, y3, y4, B, h, w, h3, w3, h4, w4, 512)
         f1, c["bn_f"] = self.bn_fwd("fusion.bn.", f0, 512, True, training, save)
         gap = ops.gap_sum(f1, B, HW, 512) / HW
         hidden, scale = ops.se_fc(gap, P["fusion.se_block.fc.0.weight"], P["fusion.se_block.fc.2.weight"])
@@ -411,33 +503,34 @@ class Engine:
         fu1, c["bn_u"] = self.bn_fwd("context.fusion.1.", fu0, 128, True, training, save)
         e0 = ops.gemm_nt(fu1, W["context.expand.0.weight"])
         context, c["bn_e"] = self.bn_fwd("context.expand.1.", e0, 256, True, training, save)
-        # --- EFE
+        # --- EFE: conv3x3 -> BN statistics -> [BN-apply + ReLU + 1x1 edge head] in one pass
         ec = self.conv3_fwd("edge_detector.conv1", context, B, h, w, 256, bias=False)
-        edge_f, c["bn_ef"] = self.bn_fwd("edge_detector.bn1.", ec, 64, True, training, save)
-        edge = ops.head1x1(edge_f, P["edge_detector.edge_conv.weight"].view(64), P["edge_detector.edge_conv.bias"], M, 64)
-        # --- PED
+        c["bn_ef"] = st_ef = self.bn_prepare("edge_detector.bn1.", ec, 64, True, training, save)
+        edge_f, edge = ops.bn_apply_head(ec, st_ef.ss, P["edge_detector.edge_conv.weight"].view(64), P["edge_detector.edge_conv.bias"], 64)
+        # --- PED.  Per stage: ONE gather builds the conv input cat[up2(relu(bn2(previous raw conv output))), up(edge_features)] (the
+        # previous stage's BN-apply is folded into the gather, its activated output is never stored); conv1 -> BN -> ReLU -> conv2 ->
+        # BN statistics -> [BN-apply + ReLU + 1x1 prediction head] reading the raw conv2 output once.
         preds, stages = [], []
-        x, Hc, Wc, Cin = context, h, w, 256
+        x, x_ss, Hc, Wc, Cin = context, None, h, w, 256
         for i, (Co, ec_ch) in enumerate(zip((256, 128, 64), (64, 64, 0))):
             H2, W2 = Hc * 2, Wc * 2
             Cc = Cin + ec_ch
-            pc = torch.empty((B * H2 * W2, Cc), dtype=T, device=dev)
-            ops.upsample_into(x, pc, B, Hc, Wc, Cin, H2, W2, Cc, 0)
-            if ec_ch:
-                ops.upsample_into(edge_f, pc, B, h, w, 64, H2, W2, Cc, Cin)
+            pc = ops.ped_gather(x, x_ss, B, Hc, Wc, Cin, edge_f if ec_ch else None, h, w, ec_ch)
             pre = f"decoder.decoder_blocks.{i}."
             a0 = self.conv3_fwd(pre + "conv1", pc, B, H2, W2, Cc, bias=True)
             a1, st1 = self.bn_fwd(pre + "bn1.", a0, Co, True, training, save)
             b0 = self.conv3_fwd(pre + "conv2", a1, B, H2, W2, Co, bias=True)
-            b1, st2 = self.bn_fwd(pre + "bn2.", b0, Co, True, training, save)
-            pred = ops.head1x1(b1, P[f"decoder.pred_heads.{i}.weight"].view(Co), P[f"decoder.pred_heads.{i}.bias"], B * H2 * W2, Co)
+            st2 = self.bn_prepare(pre + "bn2.", b0, Co, True, training, save)
+            _, pred = ops.bn_apply_head(b0, st2.ss, P[f"decoder.pred_heads.{i}.weight"].view(Co), P[f"decoder.pred_heads.{i}.bias"], Co,
+                                        write_y=False)
             preds.append(pred.view(B, 1, H2, W2))
-            stages.append(dict(pc=pc if save else None, a1=a1, b1=b1, bn1=st1, bn2=st2, H=H2, W=W2, Cin=Cin, ec=ec_ch, Co=Co))
-            x, Hc, Wc, Cin = b1, H2, W2, Co
+            stages.append(dict(pc=pc if save else None, a1=a1 if save else None, bn1=st1, bn2=st2 if save else None, H=H2, W=W2, Cin=Cin,
+                               ec=ec_ch, Co=Co))
+            x, x_ss, Hc, Wc, Cin = b0, st2.ss, H2, W2, Co
         out = {"predictions": preds, "edge": edge.view(B, 1, h, w), "context": context.view(B, h, w, 256),
                "fused": fused.view(B, h, w, 512), "edge_features": edge_f.view(B, h, w, 64)}
         if save:
-            c.update(cat=cat, f1=f1, gap=gap, hidden=hidden, scale=scale, fused=fused, r1=r1, brs=brs, bn_b=bn_b, gm=gm,
+            c.update(s2=s2, s3=s3, s4=s4, f1=f1, gap=gap, hidden=hidden, scale=scale, fused=fused, r1=r1, brs=brs, bn_b=bn_b, gm=gm,
                      glob=glob, fu1=fu1, context=context, edge_f=edge_f, stages=stages)
         return out, (c if save else None)
 
@@ -446,51 +539,51 @@ class Engine:
         P, W, G, T = self.P, self.W, self.grad, self.dtype
         B, h, w = c["B"], c["h"], c["w"]
         HW, M = h * w, c["B"] * c["h"] * c["w"]
-        dev = c["cat"].device
+        dev = c["f1"].device
         C2, C3, C4 = c["chans"]
 
         def zeros(*shape):
             return torch.zeros(shape, dtype=T, device=dev)
 
-        d_edge_f = zeros(M, 64)
-        d_context = zeros(M, 256)
-        have_ctx = False
-        # --- PED, last stage first
-        d_next = None  # gradient w.r.t. this stage's output b1 coming from the next stage
+        d_edge_f = torch.empty((M, 64), dtype=T, device=dev)
+        d_context = torch.empty((M, 256), dtype=T, device=dev)
+        edge_acc = False
+        # --- PED, last stage first.  BN2 backward forms its incoming gradient d_next + dpred (x) w_head on the fly (bn_bwd_head): the
+        # head's rank-one dx and the activated stage output are never materialised.
+        d_next = None  # gradient w.r.t. this stage's activated output coming from the next stage's gather
         for i in (2, 1, 0):
             st = c["stages"][i]
             H2, W2, Cin, ec_ch, Co = st["H"], st["W"], st["Cin"], st["ec"], st["Co"]
             Mi = B * H2 * W2
-            if d_next is None:
-                d_b1 = zeros(Mi, Co)
-            else:
-                d_b1 = d_next
-            if dpreds[i] is not None:
-                ops.head1x1_bwd(dpreds[i].to(T).contiguous().view(Mi), st["b1"], P[f"decoder.pred_heads.{i}.weight"].view(Co), d_b1,
-                                G(f"decoder.pred_heads.{i}.weight").view(Co), G(f"decoder.pred_heads.{i}.bias"), Mi, Co, True)
             pre = f"decoder.decoder_blocks.{i}."
-            d_b0 = self.bn_bwd(st["bn2"], d_b1)
+            bn2 = st["bn2"]
+            dp = dpreds[i].to(T).contiguous().view(Mi) if dpreds[i] is not None else torch.zeros(Mi, dtype=T, device=dev)
+            d_b0 = ops.bn_bwd_head(d_next, bn2.x, dp, P[f"decoder.pred_heads.{i}.weight"].view(Co), bn2.ss, bn2.mi, P[pre + "bn2.weight"],
+                                   G(pre + "bn2.weight"), G(pre + "bn2.bias"), G(f"decoder.pred_heads.{i}.weight").view(Co),
+                                   G(f"decoder.pred_heads.{i}.bias"), Co)
             d_a1 = self.conv3_bwd(pre + "conv2", d_b0, st["a1"], B, H2, W2, Co, Co, bias=True)
             d_a0 = self.bn_bwd(st["bn1"], d_a1)
             Cc = Cin + ec_ch
             d_pc = self.conv3_bwd(pre + "conv1", d_a0, st["pc"], B, H2, W2, Cc, Co, bias=True)
             Hc, Wc = H2 // 2, W2 // 2
             if i == 0:
-                ops.upsample_bwd(d_pc, d_context, B, Hc, Wc, Cin, H2, W2, Cc, 0, accumulate=False)
-                have_ctx = True
+                ops.ped_gather_bwd(d_pc, d_context, B, Hc, Wc, Cin, H2, W2, Cc, 0)
                 d_next = None
             else:
                 d_next = torch.empty((B * Hc * Wc, Cin), dtype=T, device=dev)
-                ops.upsample_bwd(d_pc, d_next, B, Hc, Wc, Cin, H2, W2, Cc, 0, accumulate=False)
+                ops.ped_gather_bwd(d_pc, d_next, B, Hc, Wc, Cin, H2, W2, Cc, 0)
             if ec_ch:
-                ops.upsample_bwd(d_pc, d_edge_f, B, h, w, 64, H2, W2, Cc, Cin, accumulate=True)
-        # --- EFE
-        if dedge is not None:
-            ops.head1x1_bwd(dedge.to(T).contiguous().view(M), c["edge_f"], P["edge_detector.edge_conv.weight"].view(64), d_edge_f,
-                            G("edge_detector.edge_conv.weight").view(64), G("edge_detector.edge_conv.bias"), M, 64, True)
+                ops.ped_gather_bwd(d_pc, d_edge_f, B, h, w, 64, H2, W2, Cc, Cin, accumulate=edge_acc)
+                edge_acc = True
+        have_ctx = True
+        # --- EFE: BN backward with the edge head's gradient formed on the fly
         if dextra and dextra.get("edge_features") is not None:
             d_edge_f = ops.add(d_edge_f, dextra["edge_features"].to(T).contiguous().view(M, 64))
-        d_ec = self.bn_bwd(c["bn_ef"], d_edge_f)
+        bn_ef = c["bn_ef"]
+        de = dedge.to(T).contiguous().view(M) if dedge is not None else torch.zeros(M, dtype=T, device=dev)
+        d_ec = ops.bn_bwd_head(d_edge_f, bn_ef.x, de, P["edge_detector.edge_conv.weight"].view(64), bn_ef.ss, bn_ef.mi,
+                               P["edge_detector.bn1.weight"], G("edge_detector.bn1.weight"), G("edge_detector.bn1.bias"),
+                               G("edge_detector.edge_conv.weight").view(64), G("edge_detector.edge_conv.bias"), 64)
         d_ctx2 = self.conv3_bwd("edge_detector.conv1", d_ec, c["context"], B, h, w, 256, 64, bias=False)
         d_context = ops.add(d_context, d_ctx2) if have_ctx else d_ctx2
         if dextra and dextra.get("context") is not None:
@@ -525,13 +618,19 @@ class Engine:
                              dscale, G("fusion.se_block.fc.0.weight"), G("fusion.se_block.fc.2.weight"))
         d_f1 = ops.chan_scale_bwd(d_fused, c["scale"], dgap, B, HW, 512)
         d_f0 = self.bn_bwd(c["bn_f"], d_f1)
-        d_cat = self.lin_bwd("fusion.conv1x1", d_f0, c["cat"], bias=False)
-        Ct = C2 + C3 + C4
+        # fusion conv backward per source: d_y2 = d_f0, d_y3 / d_y4 = the bilinear adjoints of d_f0 (512 channels at the coarse
+        # resolutions), then one dgrad + one wgrad GEMM per source (the wgrads write their column slice of the [512, 2016] gradient)
         s3s, s4s = c["s_shapes"]
-        d_s2 = torch.empty((B, h, w, C2), dtype=T, device=dev)
-        ops.copy_channels(d_cat, d_s2, M, C2, Ct, 0, C2, 0)
-        d_s3 = torch.empty(s3s, dtype=T, device=dev)
-        ops.upsample_bwd(d_cat, d_s3, B, s3s[1], s3s[2], C3, h, w, Ct, C2)
-        d_s4 = torch.empty(s4s, dtype=T, device=dev)
-        ops.upsample_bwd(d_cat, d_s4, B, s4s[1], s4s[2], C4, h, w, Ct, C2 + C3)
+        d_y3 = torch.empty((B * s3s[1] * s3s[2], 512), dtype=T, device=dev)
+        ops.ped_gather_bwd(d_f0, d_y3, B, s3s[1], s3s[2], 512, h, w, 512, 0)
+        d_y4 = torch.empty((B * s4s[1] * s4s[2], 512), dtype=T, device=dev)
+        ops.ped_gather_bwd(d_f0, d_y4, B, s4s[1], s4s[2], 512, h, w, 512, 0)
+        gw = G(FUSION_W).view(512, C2 + C3 + C4)
+        outs = []
+        for tag, dyk, xk in ((":s2", d_f0, c["s2"]), (":s3", d_y3, c["s3"]), (":s4", d_y4, c["s4"])):
+            a, b = self.fusion_split()[tag]
+            xk2 = xk.reshape(-1, b - a)
+            self._wgrad(lambda dyk=dyk, xk2=xk2, a=a, b=b: ops.gemm_tn(dyk, xk2, gw[:, a:b]), dyk, xk2)
+            outs.append(ops.gemm_nt(dyk, W[FUSION_W + tag + "T"]))
+        d_s2, d_s3, d_s4 = outs[0].view(B, h, w, C2), outs[1].view(s3s), outs[2].view(s4s)
         return [d_s2, d_s3, d_s4]

@@ -73,8 +73,66 @@ def zeros_f32(shape, device) -> Tensor:
     return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
+# ---- scratch of the deterministic reductions (include/spegnet_hip.h "Deterministic reductions") ------------------------------
+# Counters: 32-bit words that are zero before their first use and that every launch leaves zero again, so ONE persistent zeroed block
+# per device serves every launch; slots rotate so that launches on different streams do not meet on a slot.  Partials: plain scratch.
+_COUNTERS = {}
+_COUNTER_WORDS = 16384
+
+
+def red_counters(device, n: int) -> int:
+    """device pointer to n zeroed counter words"""
+    dev = torch.device(device)
+    ent = _COUNTERS.get(dev.index)
+    if ent is None:
+        ent = _COUNTERS[dev.index] = [torch.zeros(_COUNTER_WORDS, dtype=torch.int32, device=dev), 0]
+    n = (int(n) + 15) // 16 * 16
+    off = ent[1] if ent[1] + n <= _COUNTER_WORDS else 0
+    ent[1] = off + n
+    return ent[0].data_ptr() + 4 * off
+
+
+def red_scratch(device, nfloats: int) -> Tensor:
+    return torch.empty(max(int(nfloats), 64), dtype=torch.float32, device=device)
+
+
+def _red(x: Tensor, C: int, nimg: int):
+    """(scratch tensor, its float count, counters pointer) for a column reduction over C channels of x's dtype"""
+    lib, dt = _lib.load(), dcode(x)
+    n = lib.spg_reduce_workspace_floats(dt, C, nimg)
+    ws = red_scratch(x.device, n)
+    return ws, n, red_counters(x.device, lib.spg_reduce_counters(dt, C, nimg))
+
+
 # ---- optional live kernel timing (bench.py roofline leg): HIP events on the launch stream -----------------------
-PROFILE = None  # set to a list -> every gemm_nt appends (kind, flops, start_event, end_event)
+PROFILE = None  # set to a list -> instrumented ops append (name, bound, algorithmic work, start_event, end_event)
+
+
+class _prof:
+    """HIP events around one op when ops.PROFILE is a list.  bound: "mfma" (work = FLOPs) or "hbm" (work = algorithmic bytes: every
+    operand of the op read / written once per pass the op makes over it)."""
+    __slots__ = ("name", "bound", "work", "e0")
+
+    def __init__(self, name: str, bound: str, work: float):
+        self.name, self.bound, self.work, self.e0 = name, bound, work, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.append((self.name, self.bound, float(self.work), self.e0, e1))
+        return False
+
+
+def _nb(*ts) -> int:
+    """bytes of the given tensors (None skipped)"""
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 # ---- GEMM family ---------------------------------------------------------------------------------------
@@ -97,14 +155,10 @@ def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = ACT_
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     assert out.numel() == M * N and w.dtype == x.dtype
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.call("spg_gemm_nt", dcode(x), _p(_c(x)), _p(_c(w)), _p(_c(out)), _p(preact_out), _p(bias), _p(residual),
-              _p(gelu_h), M, N, K, ldx, N, act, 1 if conv else 0, B, H, W, Ci, _stream())
-    if PROFILE is not None:
-        e1.record()
-        PROFILE.append(("conv3x3" if conv else "dense", x.dtype, 2.0 * M * N * K, e0, e1))
+    tag = "bf16" if x.dtype == torch.bfloat16 else "f32"
+    with _prof(f"gemm_nt<{tag},{'conv3x3' if conv else 'dense'}>", "mfma", 2.0 * M * N * K):
+        _lib.call("spg_gemm_nt", dcode(x), _p(_c(x)), _p(_c(w)), _p(_c(out)), _p(preact_out), _p(bias), _p(residual),
+                  _p(gelu_h), M, N, K, ldx, N, act, 1 if conv else 0, B, H, W, Ci, _stream())
     return out
 
 
@@ -122,11 +176,20 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
         K = 9 * Ci
         assert B * H * W == M and x.numel() == M * Ci
         ldx = Ci
-    assert dw.dtype == torch.float32 and dw.numel() == N * K, (dw.shape, N, K)
+    # dw may be a column slice of a wider gradient matrix (rows N, unit column stride): its row stride goes down as ldw
+    assert dw.dtype == torch.float32 and dw.numel() == N * K and dw.is_cuda, (dw.shape, N, K)
+    if dw.dim() == 2 and dw.shape == (N, K) and dw.stride(1) == 1:
+        ldw = dw.stride(0)
+    else:
+        ldw = K
+        _c(dw)
+    assert ldw % 4 == 0 or ldw == K, ldw
     wsb = _lib.load().spg_gemm_tn_workspace_bytes(dcode(x), M, N, K)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
-    _lib.call("spg_gemm_tn", dcode(x), _p(_c(dy)), _p(_c(x)), _p(_c(dw)), _p(dbias), _p(ws), wsb, M, N, K, N, ldx, K,
-              1 if conv else 0, B, H, W, Ci, _stream())
+    tag = "bf16" if x.dtype == torch.bfloat16 else "f32"
+    with _prof(f"gemm_tn<{tag},{'conv3x3' if conv else 'dense'}> (+reduce)", "mfma", 2.0 * M * N * K):
+        _lib.call("spg_gemm_tn", dcode(x), _p(_c(dy)), _p(_c(x)), dw.data_ptr(), _p(dbias), _p(ws), wsb, M, N, K, N, ldx, ldw,
+                  1 if conv else 0, B, H, W, Ci, _stream())
 
 
 def set_cu_budget(n: int) -> None:
@@ -164,9 +227,10 @@ def gemm_tn_group(jobs, defer: Optional[list] = None) -> None:
             desc = ctypes.create_string_buffer(lib.spg_gemm_tn_group_desc_bytes()) if defer is not None else None
             P, I = ctypes.c_void_p * n, ctypes.c_int * n
             Ns, Ks = I(*[j[4] for j in part]), I(*[j[5] for j in part])
-            _lib.call("spg_gemm_tn_group", SPG_BF16, n, P(*[_p(j[0]) for j in part]), P(*[_p(j[1]) for j in part]),
-                      P(*[_p(j[2]) for j in part]), P(*[_p(j[3]) for j in part]), M, Ns, Ks, Ns, Ks, Ks, _p(ws), wsb,
-                      ctypes.addressof(desc) if desc is not None else None, _stream())
+            with _prof("gemm_tn_group<bf16> (one trunk block's wgrads)", "mfma", sum(2.0 * M * j[4] * j[5] for j in part)):
+                _lib.call("spg_gemm_tn_group", SPG_BF16, n, P(*[_p(j[0]) for j in part]), P(*[_p(j[1]) for j in part]),
+                          P(*[_p(j[2]) for j in part]), P(*[_p(j[3]) for j in part]), M, Ns, Ks, Ns, Ks, Ks, _p(ws), wsb,
+                          ctypes.addressof(desc) if desc is not None else None, _stream())
             if defer is not None:
                 defer.append((desc, ws))
 
@@ -216,8 +280,9 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
     y = torch.empty_like(x)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-    _lib.call("spg_layernorm_fwd", dcode(x), _p(_c(x)), _p(f32(gamma)), _p(f32(beta)), _p(y), _p(mean), _p(rstd), M, C, eps,
-              _stream())
+    with _prof("layernorm_fwd", "hbm", _nb(x, y)):
+        _lib.call("spg_layernorm_fwd", dcode(x), _p(_c(x)), _p(f32(gamma)), _p(f32(beta)), _p(y), _p(mean), _p(rstd), M, C, eps,
+                  _stream())
     return y, mean, rstd
 
 
@@ -226,8 +291,10 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     C = x.shape[-1]
     M = x.numel() // C
     dx = torch.empty_like(x)
-    _lib.call("spg_layernorm_bwd", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(gamma)), _p(mean), _p(rstd), _p(dres), _p(dx),
-              _p(f32(dgamma) if dgamma is not None else None), _p(f32(dbeta) if dbeta is not None else None), M, C, _stream())
+    ws, n, cnt = _red(x, C, 0) if dgamma is not None else (None, 0, None)
+    with _prof("layernorm_bwd (dx)" if dgamma is None else "layernorm_bwd (dx + params)", "hbm", _nb(x, dy, dres, dx) + (_nb(x, dy) if dgamma is not None else 0)):
+        _lib.call("spg_layernorm_bwd", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(gamma)), _p(mean), _p(rstd), _p(dres), _p(dx),
+                  _p(f32(dgamma) if dgamma is not None else None), _p(f32(dbeta) if dbeta is not None else None), M, C, _p(ws), n, cnt, _stream())
     return dx
 
 
@@ -255,8 +322,12 @@ def layernorm_param_grads_batch(jobs) -> None:
         part = sub[i:i + LN_BATCH_MAX]
         n = len(part)
         P, I = ctypes.c_void_p * n, ctypes.c_int * n
+        Cs = I(*[j[7] for j in part])
+        nws = _lib.load().spg_layernorm_param_grads_batch_workspace_floats(n, Cs)
+        dev = jobs[0][1].device
+        ws = red_scratch(dev, nws)
         _lib.call("spg_layernorm_param_grads_batch", dt, n, *[P(*[j[k] for j in part]) for k in range(6)],
-                  I(*[j[6] for j in part]), I(*[j[7] for j in part]), I(*[j[8] for j in part]), _stream())
+                  I(*[j[6] for j in part]), Cs, I(*[j[8] for j in part]), _p(ws), nws, red_counters(dev, n), _stream())
 
 
 def attn_fwd(qkv: Tensor, bias_t: Tensor, B: int, H: int, W: int, heads: int, hd: int, ws: int,
@@ -265,8 +336,14 @@ def attn_fwd(qkv: Tensor, bias_t: Tensor, B: int, H: int, W: int, heads: int, hd
     Hq, Wq = (H // 2, W // 2) if q_pooled is not None else (H, W)
     out = torch.empty((B, Hq, Wq, heads * hd), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, Hq, Wq, heads), dtype=torch.float32, device=qkv.device)
-    _lib.call("spg_attn_fwd", dcode(qkv), _p(_c(qkv)), _p(q_pooled), _p(_c(bias_t)), _p(out), _p(lse), B, H, W, heads, hd, ws,
-              _stream())
+    # FLOPs of windowed attention: 4 * Lq * Lk * hd per head and window (QK^T + PV)
+    wsz = ws if ws > 0 else max(H, W)
+    nwin = ((H + wsz - 1) // wsz) * ((W + wsz - 1) // wsz) if ws > 0 else 1
+    lk = (wsz * wsz) if ws > 0 else H * W
+    lq = lk // 4 if q_pooled is not None else lk
+    with _prof("attn_fwd", "mfma", 4.0 * B * nwin * heads * lq * lk * hd):
+        _lib.call("spg_attn_fwd", dcode(qkv), _p(_c(qkv)), _p(q_pooled), _p(_c(bias_t)), _p(out), _p(lse), B, H, W, heads, hd, ws,
+                  _stream())
     return out, lse
 
 
@@ -276,8 +353,13 @@ def attn_bwd(qkv: Tensor, bias_t: Tensor, out: Tensor, dout: Tensor, lse: Tensor
     dqkv = torch.empty_like(qkv)
     dqp = torch.empty_like(q_pooled) if q_pooled is not None else None
     delta = torch.empty_like(lse)
-    _lib.call("spg_attn_bwd", dcode(qkv), _p(_c(qkv)), _p(q_pooled), _p(_c(bias_t)), _p(_c(out)), _p(_c(dout)), _p(lse),
-              _p(dqkv), _p(dqp), _p(f32(dbias_pad)), _p(delta), B, H, W, heads, hd, ws, _stream())
+    wsz = ws if ws > 0 else max(H, W)
+    nwin = ((H + wsz - 1) // wsz) * ((W + wsz - 1) // wsz) if ws > 0 else 1
+    lk = (wsz * wsz) if ws > 0 else H * W
+    lq = lk // 4 if q_pooled is not None else lk
+    with _prof("attn_bwd (dq + dk/dv)", "mfma", 10.0 * B * nwin * heads * lq * lk * hd):
+        _lib.call("spg_attn_bwd", dcode(qkv), _p(_c(qkv)), _p(q_pooled), _p(_c(bias_t)), _p(_c(out)), _p(_c(dout)), _p(lse),
+                  _p(dqkv), _p(dqp), _p(f32(dbias_pad)), _p(delta), B, H, W, heads, hd, ws, _stream())
     return dqkv, dqp
 
 
@@ -313,21 +395,43 @@ def preprocess_image(img_u8_hwc: Tensor, size, mean, std) -> Tensor:
     return out
 
 
+def preprocess_batch(base_u8: Tensor, offs, sizes, size, mean, std) -> Tensor:
+    """Batched device input pipeline: uint8 HWC images of different sizes packed in `base_u8` (image i at byte offs[i], sizes[i] =
+    (H, W)) -> f32 [B,3,OH,OW] (/255, antialiased bilinear resize, normalise), one launch per 64 images."""
+    import ctypes
+    assert base_u8.dtype == torch.uint8 and base_u8.is_cuda
+    OH, OW = (size, size) if isinstance(size, int) else size
+    B = len(sizes)
+    out = torch.empty((B, 3, OH, OW), dtype=torch.float32, device=base_u8.device)
+    F3 = ctypes.c_float * 3
+    m3, s3 = F3(*[float(v) for v in mean]), F3(*[float(v) for v in std])
+    for i in range(0, B, 64):
+        n = min(64, B - i)
+        L, I = ctypes.c_long * n, ctypes.c_int * n
+        _lib.call("spg_preprocess_batch", _p(base_u8), L(*[int(o) for o in offs[i:i + n]]), I(*[int(s[0]) for s in sizes[i:i + n]]),
+                  I(*[int(s[1]) for s in sizes[i:i + n]]), out[i:].data_ptr(), n, OH, OW, m3, s3, _stream())
+    return out
+
+
 # ---- reductions / elementwise ---------------------------------------------------------------------------
-def colsum(x: Tensor, out: Tensor) -> None:
+def colsum(x: Tensor, out: Tensor, accumulate: bool = True) -> None:
+    """out[c] (+)= sum_m x[m][c] (deterministic)"""
     C = x.shape[-1]
-    _lib.call("spg_colsum", dcode(x), _p(_c(x)), _p(f32(out)), x.numel() // C, C, C, _stream())
+    ws, n, cnt = _red(x, C, 0)
+    _lib.call("spg_colsum", dcode(x), _p(_c(x)), _p(f32(out)), x.numel() // C, C, C, 1 if accumulate else 0, _p(ws), n, cnt, _stream())
 
 
 def gap_sum(x: Tensor, B: int, HW: int, C: int) -> Tensor:
-    out = zeros_f32((B, C), x.device)
-    _lib.call("spg_gap_sum", dcode(x), _p(_c(x)), _p(out), B, HW, C, _stream())
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    ws, n, cnt = _red(x, C, B)
+    _lib.call("spg_gap_sum", dcode(x), _p(_c(x)), _p(out), B, HW, C, _p(ws), n, cnt, _stream())
     return out
 
 
 def chan_prod_sum(a: Tensor, b: Tensor, B: int, HW: int, C: int) -> Tensor:
-    out = zeros_f32((B, C), a.device)
-    _lib.call("spg_chan_prod_sum", dcode(a), _p(_c(a)), _p(_c(b)), _p(out), B, HW, C, _stream())
+    out = torch.empty((B, C), dtype=torch.float32, device=a.device)
+    ws, n, cnt = _red(a, C, B)
+    _lib.call("spg_chan_prod_sum", dcode(a), _p(_c(a)), _p(_c(b)), _p(out), B, HW, C, _p(ws), n, cnt, _stream())
     return out
 
 
@@ -344,9 +448,26 @@ def copy_channels(x: Tensor, y: Tensor, M: int, C: int, ldx: int, cx0: int, ldy:
 
 # ---- BatchNorm ------------------------------------------------------------------------------------------
 def bn_stats(x: Tensor, C: int) -> Tensor:
-    stats = zeros_f32(2 * C, x.device)
-    _lib.call("spg_bn_stats", dcode(x), _p(_c(x)), _p(stats), x.numel() // C, C, _stream())
+    stats = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    ws, n, cnt = _red(x, C, 0)
+    _lib.call("spg_bn_stats", dcode(x), _p(_c(x)), _p(stats), x.numel() // C, C, _p(ws), n, cnt, _stream())
     return stats
+
+
+def bn_stats_finalize(x: Tensor, C: int, gamma: Tensor, beta: Tensor, rmean: Optional[Tensor], rvar: Optional[Tensor],
+                      nbt: Optional[Tensor], eps: float = 1e-5, momentum: float = 0.1):
+    """Training-mode BatchNorm statistics in ONE launch: deterministic batch sums, and the workgroup that finishes a channel slab
+    also writes scale/shift, mean/invstd, the running statistics and num_batches_tracked += 1.  Returns (scale_shift, mean_invstd)."""
+    M = x.numel() // C
+    buf = torch.empty(6 * C, dtype=torch.float32, device=x.device)
+    stats, ss, mi = buf[:2 * C], buf[2 * C:4 * C], buf[4 * C:]
+    ws, n, cnt = _red(x, C, 0)
+    if nbt is not None:
+        assert nbt.dtype == torch.int64
+    with _prof("bn_stats_finalize", "hbm", _nb(x)):
+        _lib.call("spg_bn_stats_finalize", dcode(x), _p(_c(x)), _p(stats), _p(f32(gamma)), _p(f32(beta)), _p(rmean), _p(rvar), _p(nbt),
+                  _p(ss), _p(mi), M, C, eps, momentum, _p(ws), n, cnt, _stream())
+    return ss, mi
 
 
 def bn_finalize(stats: Optional[Tensor], gamma: Tensor, beta: Tensor, rmean: Optional[Tensor], rvar: Optional[Tensor], M: int,
@@ -362,17 +483,20 @@ def bn_finalize(stats: Optional[Tensor], gamma: Tensor, beta: Tensor, rmean: Opt
 def bn_apply(x: Tensor, ss: Tensor, C: int, relu: bool, out: Optional[Tensor] = None) -> Tensor:
     if out is None:
         out = torch.empty_like(x)
-    _lib.call("spg_bn_apply", dcode(x), _p(_c(x)), _p(ss), _p(out), x.numel() // C, C, 1 if relu else 0, _stream())
+    with _prof("bn_apply", "hbm", _nb(x, out)):
+        _lib.call("spg_bn_apply", dcode(x), _p(_c(x)), _p(ss), _p(out), x.numel() // C, C, 1 if relu else 0, _stream())
     return out
 
 
 def bn_bwd(dy: Tensor, x: Tensor, ss: Tensor, mi: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor, C: int, relu: bool) -> Tensor:
     M = x.numel() // C
-    sums = zeros_f32(2 * C, x.device)
-    _lib.call("spg_bn_bwd_reduce", dcode(x), _p(_c(dy)), _p(_c(x)), _p(ss), _p(mi), _p(sums), M, C, 1 if relu else 0, _stream())
+    sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    ws, n, cnt = _red(x, C, 0)
     dx = torch.empty_like(x)
-    _lib.call("spg_bn_bwd_apply", dcode(x), _p(dy), _p(x), _p(ss), _p(mi), _p(f32(gamma)), _p(sums), _p(dx), _p(f32(dgamma)),
-              _p(f32(dbeta)), M, C, 1 if relu else 0, _stream())
+    with _prof("bn_bwd (reduce + apply)", "hbm", 2 * _nb(x, dy) + _nb(dx)):
+        _lib.call("spg_bn_bwd_reduce", dcode(x), _p(_c(dy)), _p(_c(x)), _p(ss), _p(mi), _p(sums), M, C, 1 if relu else 0, _p(ws), n, cnt, _stream())
+        _lib.call("spg_bn_bwd_apply", dcode(x), _p(dy), _p(x), _p(ss), _p(mi), _p(f32(gamma)), _p(sums), _p(dx), _p(f32(dgamma)),
+                  _p(f32(dbeta)), M, C, 1 if relu else 0, _stream())
     return dx
 
 
@@ -398,8 +522,10 @@ def se_fc_bwd(gap, w1, w2, hidden, scale, dscale, dw1, dw2) -> Tensor:
     B, C = gap.shape
     R = w1.shape[0]
     dgap = torch.empty_like(gap)
+    n = B * (C + R)
+    ws = red_scratch(gap.device, n)
     _lib.call("spg_se_fc_bwd", _p(gap), _p(f32(w1)), _p(f32(w2)), _p(hidden), _p(scale), _p(f32(dscale)), _p(dgap), _p(f32(dw1)),
-              _p(f32(dw2)), B, C, R, _stream())
+              _p(f32(dw2)), B, C, R, _p(ws), n, red_counters(gap.device, 1), _stream())
     return dgap
 
 
@@ -422,7 +548,9 @@ def dwconv3x3(x: Tensor, w: Tensor, B: int, H: int, W: int, C: int, dil: int, fl
 
 
 def dwconv3x3_wgrad(dy: Tensor, x: Tensor, dw: Tensor, B: int, H: int, W: int, C: int, dil: int) -> None:
-    _lib.call("spg_dwconv3x3_wgrad", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(dw)), B, H, W, C, dil, _stream())
+    n = 64 * 9 * C
+    ws = red_scratch(x.device, n)
+    _lib.call("spg_dwconv3x3_wgrad", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(dw)), B, H, W, C, dil, _p(ws), n, red_counters(x.device, 1), _stream())
 
 
 def easpp_fuse(br, glob: Tensor, w: Tensor, B: int, HW: int, C: int) -> Tensor:
@@ -434,9 +562,11 @@ def easpp_fuse(br, glob: Tensor, w: Tensor, B: int, HW: int, C: int) -> Tensor:
 
 def easpp_fuse_bwd(dy: Tensor, br, glob: Tensor, w: Tensor, dw: Tensor, B: int, HW: int, C: int):
     d = [torch.empty_like(b) for b in br]
-    dglob = torch.zeros_like(glob)
+    dglob = torch.empty_like(glob)
+    n = 32 * B * 6 * C
+    ws = red_scratch(dy.device, n)
     _lib.call("spg_easpp_fuse_bwd", dcode(dy), _p(_c(dy)), _p(br[0]), _p(br[1]), _p(br[2]), _p(br[3]), _p(glob), _p(f32(w)),
-              _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(dglob), _p(f32(dw)), B, HW, C, _stream())
+              _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(dglob), _p(f32(dw)), B, HW, C, _p(ws), n, red_counters(dy.device, 1), _stream())
     return d, dglob
 
 
@@ -447,5 +577,57 @@ def head1x1(x: Tensor, w: Tensor, b: Tensor, M: int, C: int) -> Tensor:
 
 
 def head1x1_bwd(dy: Tensor, x: Tensor, w: Tensor, dx: Tensor, dw: Tensor, db: Tensor, M: int, C: int, accumulate: bool) -> None:
+    n = _lib.load().spg_head1x1_bwd_workspace_floats(C)
+    ws = red_scratch(x.device, n)
     _lib.call("spg_head1x1_bwd", dcode(x), _p(_c(dy)), _p(_c(x)), _p(f32(w)), _p(dx), _p(f32(dw)), _p(f32(db)), M, C,
-              1 if accumulate else 0, _stream())
+              1 if accumulate else 0, _p(ws), n, red_counters(x.device, 1), _stream())
+
+
+# ---- fused CFI / EFE / PED element kernels (csrc/head.hip) ---------------------------------------------------------------------
+def bn_apply_head(x: Tensor, ss: Tensor, w: Tensor, b: Tensor, C: int, relu: bool = True, write_y: bool = True):
+    """y = relu(x*scale+shift) (None when write_y is False: never stored) and pred[m] = w . y[m] + b, one pass over x."""
+    M = x.numel() // C
+    y = torch.empty_like(x) if write_y else None
+    pred = torch.empty(M, dtype=x.dtype, device=x.device)
+    with _prof("bn_apply_head" + ("" if write_y else " (y not stored)"), "hbm", _nb(x, y, pred)):
+        _lib.call("spg_bn_apply_head", dcode(x), _p(_c(x)), _p(ss), _p(f32(w)), _p(f32(b)), _p(y), _p(pred), M, C, 1 if relu else 0, _stream())
+    return y, pred
+
+
+def ped_gather(x: Tensor, x_ss: Optional[Tensor], B: int, hx: int, wx: int, Cx: int, edge: Optional[Tensor], he: int, we: int, Ce: int) -> Tensor:
+    """cat[up2(act(x)), up(edge)] as [B*2hx*2wx, Cx+Ce]; act = relu(x*scale+shift) when x_ss is given."""
+    H, W = 2 * hx, 2 * wx
+    y = torch.empty((B * H * W, Cx + Ce), dtype=x.dtype, device=x.device)
+    with _prof("ped_gather (bn+relu+up2+concat)", "hbm", _nb(x, edge, y)):
+        _lib.call("spg_ped_gather", dcode(x), _p(_c(x)), _p(x_ss), hx, wx, Cx, _p(edge), he, we, Ce, _p(y), B, H, W, _stream())
+    return y
+
+
+def ped_gather_bwd(dy: Tensor, dx: Tensor, B: int, h: int, w: int, C: int, H: int, W: int, ldy: int, c0: int, accumulate: bool = False) -> None:
+    es = dy.element_size()
+    with _prof("ped_gather_bwd", "hbm", B * H * W * C * es + B * h * w * C * es * (2 if accumulate else 1)):
+        _lib.call("spg_ped_gather_bwd", dcode(dy), _p(_c(dy)), _p(dx), B, h, w, C, H, W, ldy, c0, 1 if accumulate else 0, _stream())
+
+
+def bn_bwd_head(dnext: Optional[Tensor], x: Tensor, dpred: Tensor, head_w: Tensor, ss: Tensor, mi: Tensor, gamma: Tensor, dgamma: Tensor,
+                dbeta: Tensor, dhead_w: Tensor, dhead_b: Tensor, C: int) -> Tensor:
+    """BatchNorm backward (ReLU recomputed) whose incoming gradient is dnext + dpred (x) head_w, plus the head's parameter gradients."""
+    M = x.numel() // C
+    lib, dt = _lib.load(), dcode(x)
+    n = lib.spg_bn_bwd_head_workspace_floats(dt, C)
+    ws = red_scratch(x.device, n)
+    sums = torch.empty(3 * C + 1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    with _prof("bn_bwd_head (reduce + apply)", "hbm", 2 * _nb(x, dnext, dpred) + _nb(dx)):
+        _lib.call("spg_bn_bwd_head", dt, _p(dnext), _p(_c(x)), _p(_c(dpred)), _p(f32(head_w)), _p(ss), _p(mi), _p(f32(gamma)), _p(sums), _p(dx),
+                  _p(f32(dgamma)), _p(f32(dbeta)), _p(f32(dhead_w)), _p(f32(dhead_b)), M, C, _p(ws), n,
+                  red_counters(x.device, lib.spg_bn_bwd_head_counters(dt, C)), _stream())
+    return dx
+
+
+def cfi_combine(y2: Tensor, y3: Tensor, y4: Tensor, B: int, H: int, W: int, h3: int, w3: int, h4: int, w4: int, C: int) -> Tensor:
+    """y2 + up(y3) + up(y4): the CFI fusion conv evaluated per source resolution (no 2016-channel concat)."""
+    out = torch.empty_like(y2)
+    with _prof("cfi_combine", "hbm", _nb(y2, y3, y4, out)):
+        _lib.call("spg_cfi_combine", dcode(y2), _p(_c(y2)), _p(_c(y3)), _p(_c(y4)), _p(out), B, H, W, h3, w3, h4, w4, C, _stream())
+    return out

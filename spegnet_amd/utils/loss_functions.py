@@ -31,17 +31,22 @@ class _FusedCODLoss(torch.autograd.Function):
         dt = _lib.SPG_BF16 if preds[0].dtype == torch.bfloat16 else _lib.SPG_F32
         assert all(p.dtype == preds[0].dtype for p in preds)
         st = torch.cuda.current_stream().cuda_stream
-        buf = torch.zeros(B * 4 + 4 * B * 3 + 3, dtype=torch.float32, device=dev)
+        from .. import ops
+        # every sum below is a deterministic reduction (partials + fixed-order finish): nothing needs zeroing
+        buf = torch.empty(B * 4 + 4 * B * 3 + 3, dtype=torch.float32, device=dev)
         stats, seg_sums, edge_sums, out = buf[:B * 4], buf[B * 4:B * 4 + 9 * B], buf[B * 13:B * 16], buf[B * 16:]
         wmap = torch.empty((B, S, S), dtype=torch.float32, device=dev)
-        _lib.call("spg_loss_weight_map", masks.data_ptr(), edges.data_ptr(), wmap.data_ptr(), stats.data_ptr(), B, S, float(bw), st)
+        nws = _lib.load().spg_loss_workspace_floats(B, S)
+        ws = ops.red_scratch(dev, nws)   # the five launches are stream-ordered: one scratch serves them all
+        _lib.call("spg_loss_weight_map", masks.data_ptr(), edges.data_ptr(), wmap.data_ptr(), stats.data_ptr(), B, S, float(bw),
+                  ws.data_ptr(), nws, ops.red_counters(dev, B), st)
         for i in range(3):
             h, w = preds[i].shape[-2:]
             _lib.call("spg_loss_reduce", dt, preds[i].data_ptr(), masks.data_ptr(), wmap.data_ptr(), stats.data_ptr(),
-                      seg_sums[i * 3 * B:].data_ptr(), B, S, h, w, 0, 0.0, 0.0, st)
+                      seg_sums[i * 3 * B:].data_ptr(), B, S, h, w, 0, 0.0, 0.0, ws.data_ptr(), nws, ops.red_counters(dev, B), st)
         h, w = preds[3].shape[-2:]
         _lib.call("spg_loss_reduce", dt, preds[3].data_ptr(), edges.data_ptr(), None, stats.data_ptr(), edge_sums.data_ptr(), B, S, h, w,
-                  1, float(alpha), float(gamma), st)
+                  1, float(alpha), float(gamma), ws.data_ptr(), nws, ops.red_counters(dev, B), st)
         _lib.call("spg_loss_finalize", stats.data_ptr(), seg_sums.data_ptr(), edge_sums.data_ptr(), out.data_ptr(), B, S, float(sw[0]),
                   float(sw[1]), float(sw[2]), float(bce_w), float(iou_w), float(edge_w), st)
         ctx.saved = (preds, masks, edges, wmap, stats, seg_sums, edge_sums, cfg, dt)

@@ -155,7 +155,9 @@ def gen_trunk():
     from transformers.models.sam2.modeling_sam2 import Sam2HieraDetModel
     out = {}
     for tag, (cfg, S, B) in {"tiny_64": (O.HIERA_TINY_TEST, 64, 2), "tiny_96": (O.HIERA_TINY_TEST, 96, 1),
-                             "large_64": (O.HIERA_L, 64, 1), "large_128": (O.HIERA_L, 128, 1)}.items():
+                             "large_64": (O.HIERA_L, 64, 1), "large_128": (O.HIERA_L, 128, 1),
+                             # 384 px: the BASELINE resolution -- stage 3 pads 24 -> 32 (window 16), stage 4 pads 12 -> 16 (window 8)
+                             "large_384": (O.HIERA_L, 384, 1)}.items():
         dims = [cfg["embed_dim"] * 2 ** i for i in range(4)]
         heads = [cfg["num_heads"] * 2 ** i for i in range(4)]
         hc = Sam2HieraDetConfig(hidden_size=cfg["embed_dim"], num_attention_heads=cfg["num_heads"],

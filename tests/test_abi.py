@@ -49,12 +49,13 @@ def test_ctypes_signatures_match_header():
     decls = parse_header()
     table = dict(_lib.SIGNATURES)
     table.update(_lib._OPTIONAL)
+    table.update({k: v[1] for k, v in _lib.QUERIES.items()})
     for name, sig in decls.items():
-        if name in ("spg_version", "spg_gemm_tn_workspace_bytes", "spg_gemm_tn_group_workspace_bytes", "spg_gemm_tn_group_desc_bytes"):
+        if name == "spg_version":
             continue
         assert name in table, f"{name} has no ctypes signature"
         assert table[name] == sig, f"{name}: ctypes {table[name]} != header {sig}"
-    for name in _lib.SIGNATURES:
+    for name in list(_lib.SIGNATURES) + list(_lib.QUERIES):
         assert name in decls, f"{name} bound in _lib.py but not declared in the header"
 
 

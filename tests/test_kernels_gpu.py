@@ -119,6 +119,10 @@ def test_gemm_tn(ops, dt, M, N, K):
     [(300, 200, 144)],                                                                # one small ragged problem, fewer steps than CUs * 2
     [(1000, 136, 72), (77, 432, 144), (5000, 1000, 200), (64, 16, 32), (130, 8, 8)],   # ragged N / K / M, tiles cut several times
     [(9000, 128, 128)],                                                               # one tile shared by many workgroups
+    # few rows: more tiles than CUs AND fewer remainder steps than CUs -- most workgroups have an empty remainder share and write no
+    # slab slot (round 1 folded their stale slots into the gradient: wrong qkv gradients at 128 / 256 px)
+    [(256, 576, 2304), (256, 2304, 576), (256, 576, 576), (256, 1728, 576)],
+    [(512, 576, 2304), (512, 2304, 576), (512, 576, 576), (512, 1728, 576)],
 ])
 @pytest.mark.parametrize("defer", [False, True])
 def test_gemm_tn_group(ops, shapes, defer):
@@ -132,6 +136,10 @@ def test_gemm_tn_group(ops, shapes, defer):
         dw, db = dw0.clone(), (db0.clone() if i % 2 == 0 else None)
         jobs.append((dy, x, dw, db))
         refs.append((dw0 + dy.float().t() @ x.float(), (db0 + dy.float().sum(0)) if db is not None else None))
+    # poison the block the caching allocator will hand out as the launch's scratch: results must not depend on its contents
+    from spegnet_amd import _lib
+    poison = torch.full((_lib.load().spg_gemm_tn_group_workspace_bytes() // 4,), float("nan"), device="cuda")
+    del poison
     if defer:
         pending = []
         ops.gemm_tn_group(jobs, pending)
@@ -486,6 +494,126 @@ def test_small_utils(ops, dt):
     assert torch.equal(y[:, 32:48], x[:, 16:32]) and float(y[:, :32].abs().max()) == 0
     a, b = rnd(64, 40, seed=2).to(dt), rnd(64, 40, seed=3).to(dt)
     check(ops.add(a, b).float(), a.float() + b.float(), tol(dt, 1e-7, 8e-3), "add")
+
+
+# ------------------------------------------------------------------------------------------- fused CFI / EFE / PED kernels (csrc/head.hip)
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,C", [(500, 64), (2304, 512), (6, 128)])
+def test_bn_stats_finalize_one_launch(ops, dt, M, C):
+    """bn_stats + bn_finalize (+ num_batches_tracked) folded into one launch == the two-launch form, and == torch batch_norm."""
+    x = (rnd(M, C, seed=1) * 1.5 + 0.3).to(dt)
+    g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    rm, rv = 0.1 * rnd(C, seed=4), 1 + 0.1 * rnd(C, seed=5).abs()
+    rm2, rv2 = rm.clone(), rv.clone()
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    ss_ref, mi_ref = ops.bn_finalize(ops.bn_stats(x, C), g, b, rm2, rv2, M, True)
+    ss, mi = ops.bn_stats_finalize(x, C, g, b, rm, rv, nbt)
+    ss2, _ = ops.bn_stats_finalize(x, C, g, b, rm.clone(), rv.clone(), nbt)
+    assert torch.equal(ss, ss_ref) and torch.equal(mi, mi_ref) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
+    assert torch.equal(ss, ss2), "identical inputs must give bit-identical batch statistics (deterministic reduction)"
+    assert int(nbt) == 2
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C", [64, 128, 256])
+@pytest.mark.parametrize("write_y", [True, False])
+def test_bn_apply_head(ops, dt, C, write_y):
+    M = 1000
+    x = (rnd(M, C, seed=1) * 1.5 + 0.3).to(dt)
+    ss = torch.cat([1 + 0.1 * rnd(C, seed=2), 0.2 * rnd(C, seed=3)])
+    w, b = rnd(C, seed=4) * 0.2, rnd(1, seed=5)
+    y_ref = ops.bn_apply(x, ss, C, True)
+    y, pred = ops.bn_apply_head(x, ss, w, b, C, relu=True, write_y=write_y)
+    if write_y:
+        assert torch.equal(y, y_ref)
+        check(pred.float(), ops.head1x1(y_ref, w, b, M, C).float(), tol(dt, 1e-5, 1e-2), "bn_apply_head pred")
+    else:
+        assert y is None
+        ref = torch.relu(x.float() * ss[:C] + ss[C:]) @ w + b
+        check(pred.float(), ref, tol(dt, 1e-5, 1e-2), "bn_apply_head pred (y not stored)")
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_cfi_fusion_without_concat(ops, dt):
+    """conv1x1(cat[s2, up(s3), up(s4)]) == s2.W2^T + up(s3.W3^T) + up(s4.W4^T) (feature_integration.py:229-239): three GEMMs at the
+    sources' own resolutions + cfi_combine against the reference formulation in torch."""
+    B, h, w, C2, C3, C4, N = 2, 16, 24, 32, 64, 128, 64
+    s2, s3, s4 = rnd(B, h, w, C2, seed=1).to(dt), rnd(B, h // 2, w // 2, C3, seed=2).to(dt), rnd(B, h // 4, w // 4, C4, seed=3).to(dt)
+    Wf = (rnd(N, C2 + C3 + C4, seed=4) * 0.1).to(dt)
+    up = lambda t: F.interpolate(t.float().permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=False)
+    cat = torch.cat([s2.float().permute(0, 3, 1, 2), up(s3), up(s4)], 1)
+    ref = F.conv2d(cat, Wf.float()[:, :, None, None]).permute(0, 2, 3, 1).reshape(B * h * w, N)
+    y2 = ops.gemm_nt(s2.view(-1, C2), Wf[:, :C2].contiguous())
+    y3 = ops.gemm_nt(s3.view(-1, C3), Wf[:, C2:C2 + C3].contiguous())
+    y4 = ops.gemm_nt(s4.view(-1, C4), Wf[:, C2 + C3:].contiguous())
+    out = ops.cfi_combine(y2, y3, y4, B, h, w, h // 2, w // 2, h // 4, w // 4, N)
+    check(out.float(), ref, tol(dt, 2e-5, 2e-2), "cfi fusion (split by source)")
+    # wgrad into a column slice of the full [N, C2+C3+C4] gradient (row stride = full width)
+    dy = rnd(B * h * w, N, seed=5).to(dt)
+    gw = torch.zeros(N, C2 + C3 + C4, device="cuda")
+    ops.gemm_tn(dy, s2.view(-1, C2), gw[:, :C2])
+    check(gw[:, :C2], dy.float().t() @ s2.view(-1, C2).float(), tol(dt, 2e-5, 1e-2), "wgrad into a column slice")
+    assert float(gw[:, C2:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("hx,Cx,he,Ce,bn", [(12, 64, 12, 16, True), (12, 32, 6, 16, False), (7, 16, 0, 0, True), (24, 256, 24, 64, True)])
+def test_ped_gather_fwd_bwd(ops, dt, hx, Cx, he, Ce, bn):
+    """cat[up2(relu(bn(x))), up_s(edge)] in one launch == bn_apply + two upsample launches (which are pinned to F.interpolate above);
+    the adjoint == the generic upsample_bwd (s = 2 and 4, channel offsets, accumulate)."""
+    B, wx = 2, hx + 4 if hx % 2 == 0 else hx + 3
+    H, W = 2 * hx, 2 * wx
+    we = (W // (H // he)) if he else 0
+    x = rnd(B, hx, wx, Cx, seed=1).to(dt)
+    ss = torch.cat([1 + 0.1 * rnd(Cx, seed=2), 0.2 * rnd(Cx, seed=3)]) if bn else None
+    edge = rnd(B, he, we, Ce, seed=4).to(dt) if Ce else None
+    pc = ops.ped_gather(x, ss, B, hx, wx, Cx, edge, he, we, Ce)
+    xa = ops.bn_apply(x, ss, Cx, True) if bn else x
+    ref = torch.zeros((B * H * W, Cx + Ce), dtype=dt, device="cuda")
+    ops.upsample_into(xa, ref, B, hx, wx, Cx, H, W, Cx + Ce, 0)
+    if Ce:
+        ops.upsample_into(edge, ref, B, he, we, Ce, H, W, Cx + Ce, Cx)
+    check(pc.float(), ref.float(), tol(dt, 1e-6, 8e-3), "ped_gather")
+    # torch cross-check of the whole thing
+    act = torch.relu(x.float() * ss[:Cx] + ss[Cx:]) if bn else x.float()
+    t = F.interpolate(act.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).reshape(B * H * W, Cx)
+    check(pc[:, :Cx].float(), t, tol(dt, 1e-5, 1.5e-2), "ped_gather vs F.interpolate")
+    dy = rnd(B * H * W, Cx + Ce, seed=6).to(dt)
+    for (h_, w_, C_, c0) in ([(hx, wx, Cx, 0)] + ([(he, we, Ce, Cx)] if Ce else [])):
+        for acc in (False, True):
+            d0 = rnd(B, h_, w_, C_, seed=7).to(dt)
+            d_ref, d_new = d0.clone(), d0.clone()
+            ops.upsample_bwd(dy, d_ref, B, h_, w_, C_, H, W, Cx + Ce, c0, accumulate=acc)
+            ops.ped_gather_bwd(dy, d_new, B, h_, w_, C_, H, W, Cx + Ce, c0, accumulate=acc)
+            check(d_new.float(), d_ref.float(), tol(dt, 1e-5, 1e-2), f"ped_gather_bwd C={C_} acc={acc}")
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,C,with_next", [(1000, 64, False), (700, 128, True), (2304, 256, True)])
+def test_bn_bwd_head(ops, dt, M, C, with_next):
+    """BN backward with the head's rank-one gradient formed on the fly == head1x1_bwd (dx, dw, db) followed by bn_bwd."""
+    x = (rnd(M, C, seed=1) * 1.5 + 0.3).to(dt)
+    g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    ss, mi = ops.bn_stats_finalize(x, C, g, b, None, None, None)
+    hw = rnd(C, seed=4) * 0.2
+    dpred = rnd(M, seed=5).to(dt)
+    dnext = rnd(M, C, seed=6).to(dt) if with_next else None
+    # reference: materialise y and d_y
+    y = ops.bn_apply(x, ss, C, True)
+    d_y = dnext.clone() if with_next else torch.zeros(M, C, dtype=dt, device="cuda")
+    dw_ref, db_ref = torch.zeros(C, device="cuda"), torch.zeros(1, device="cuda")
+    ops.head1x1_bwd(dpred, y, hw, d_y, dw_ref, db_ref, M, C, accumulate=True)
+    dg_ref, dbt_ref = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx_ref = ops.bn_bwd(d_y, x, ss, mi, g, dg_ref, dbt_ref, C, True)
+    dg, dbt, dw, db = (torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(1, device="cuda"))
+    dx = ops.bn_bwd_head(dnext, x, dpred, hw, ss, mi, g, dg, dbt, dw, db, C)
+    check(dx.float(), dx_ref.float(), tol(dt, 2e-4, 3e-2), "bn_bwd_head dx")
+    check(dg, dg_ref, tol(dt, 1e-4, 3e-2), "dgamma")
+    check(dbt, dbt_ref, tol(dt, 1e-4, 3e-2), "dbeta")
+    check(dw, dw_ref, tol(dt, 1e-4, 2e-2), "head dw")
+    check(db, db_ref, tol(dt, 1e-4, 2e-2), "head db")
+    dx2 = ops.bn_bwd_head(dnext, x, dpred, hw, ss, mi, g, dg.clone(), dbt.clone(), dw.clone(), db.clone(), C)
+    assert torch.equal(dx, dx2), "deterministic reduction: identical inputs, identical dx"
 
 
 # ------------------------------------------------------------------------------------------- fused CODLoss

@@ -21,6 +21,20 @@ def make_model(variant, dtype, seed=3, train=False):
     return m, sd, cfg
 
 
+def mask_report(p, r, tag):
+    """Both mask artefacts of SURVEY 3.1 as counts: (logit > 0) [== sigmoid > 0.5] and uint8(sigmoid * 255) (reference utils/metrics.py:205).
+    Returns (threshold disagreements, of them outside the rounding band, uint8 disagreements, max uint8 step, pixels)."""
+    p, r = p.float().cpu(), r.float().cpu()
+    dis = (p > 0) != (r > 0)
+    band = r.abs() <= 1e-3 * r.abs().max()          # logits within fp32 rounding of the decision boundary
+    q_p, q_r = (torch.sigmoid(p) * 255).to(torch.uint8), (torch.sigmoid(r) * 255).to(torch.uint8)
+    dq = (q_p.int() - q_r.int()).abs()
+    rep = dict(pixels=p.numel(), thr_diff=int(dis.sum()), thr_diff_outside_band=int((dis & ~band).sum()), band_pixels=int(band.sum()),
+               u8_diff=int((dq > 0).sum()), u8_max_step=int(dq.max()))
+    print(f"mask agreement {tag}: {rep}")
+    return rep
+
+
 def cmp_outputs(out, ref, tol, tag):
     errs = {}
     for i in range(3):
@@ -46,11 +60,12 @@ def test_forward_eval_fp32_matches_oracle(variant, S, B):
         assert a.shape == b.shape
         assert rel_err(a.float(), b) < 1e-3
     cmp_outputs(out, ref, 1e-3, f"{variant}@{S}")
-    # thresholded mask: bit-exact wherever the oracle's logit is not within rounding of zero
-    p, r = out["predictions"][2].float().cpu(), ref["predictions"][2]
-    sure = r.abs() > 1e-3 * r.abs().max()
-    assert torch.equal((p > 0)[sure], (r > 0)[sure])
-    assert sure.float().mean() > 0.99
+    # thresholded mask: bit-exact wherever the oracle's logit is not within rounding of zero (counts are printed);
+    # uint8(sigmoid*255): a pixel may sit on a quantisation step, never more than one step away
+    rep = mask_report(out["predictions"][2], ref["predictions"][2], f"fp32 {variant}@{S}")
+    assert rep["thr_diff_outside_band"] == 0
+    assert rep["band_pixels"] < 0.01 * rep["pixels"]
+    assert rep["u8_max_step"] <= 1 and rep["u8_diff"] <= 0.002 * rep["pixels"], rep
 
 
 def test_forward_384_fp32_matches_oracle_and_golden(golden):
@@ -60,9 +75,17 @@ def test_forward_384_fp32_matches_oracle_and_golden(golden):
         ref = O.spegnet_forward(sd, x, training=False, cfg=cfg)
         out = m(x.cuda())
     errs = cmp_outputs(out, ref, 1e-3, "large@384")
-    p, r = out["predictions"][2].float().cpu(), ref["predictions"][2]
-    sure = r.abs() > 1e-3 * r.abs().max()
-    assert torch.equal((p > 0)[sure], (r > 0)[sure])
+    rep = mask_report(out["predictions"][2], ref["predictions"][2], "fp32 large@384")
+    assert rep["thr_diff_outside_band"] == 0 and rep["band_pixels"] < 0.01 * rep["pixels"]
+    assert rep["u8_max_step"] <= 1 and rep["u8_diff"] <= 0.002 * rep["pixels"], rep
+    # the trunk at 384 px against the independent HF implementation (padded windows 24 -> 32, 12 -> 16)
+    rec = golden("trunk_hf.pt")["large_384"]
+    xh = torch.randn(rec["B"], 3, 384, 384, generator=torch.Generator().manual_seed(rec["in_seed"]))
+    with torch.no_grad():
+        feats = m.encoder(xh.cuda())
+    assert rel_err(feats[3].float(), rec["feat_s4"]) < 1e-3
+    assert rel_err(feats[2].float()[:, ::8], rec["feat_s3_slice"]) < 1e-3
+    assert rel_err(feats[1].float()[:, ::16], rec["feat_s2_slice"]) < 1e-3
     assert out["predictions"][2].shape == (1, 1, 384, 384) and out["edge"].shape == (1, 1, 48, 48)
     print("rel errs @384 fp32:", errs)
 
@@ -75,6 +98,8 @@ def test_forward_bf16_close_to_oracle(variant, S, B):
         ref = O.spegnet_forward(sd, x, training=False, cfg=cfg)
         out = m(x.cuda())
     cmp_outputs(out, ref, 6e-2, f"bf16 {variant}@{S}")
+    rep = mask_report(out["predictions"][2], ref["predictions"][2], f"bf16 {variant}@{S}")   # reported, bounded loosely: bf16 is not the parity mode
+    assert rep["thr_diff"] <= 0.02 * rep["pixels"], rep
 
 
 def oracle_loss_and_grads(sd, cfg, x, masks, edges, loss_cfg, dtype=torch.float32):
@@ -110,7 +135,7 @@ def test_train_forward_backward_fp32_matches_oracle(variant, S, B):
     losses = crit.forward_batched(out["predictions"], out["edge"], torch.stack(masks).cuda(), torch.stack(edges).cuda())
     for k in ("loss", "seg_loss", "edge_loss"):
         assert abs(float(losses[k]) - float(l64[k])) < 1e-4 * abs(float(l64[k])), k
-    # running statistics after exactly one train-mode forward (checked here: the gradient retries below run more forwards)
+    # running statistics after exactly one train-mode forward
     st = m.state_dict()
     for k in ("fusion.bn.running_mean", "context.global_branch.2.running_var", "decoder.decoder_blocks.2.bn2.running_var"):
         assert rel_err(st[k].float(), ref_sd[k]) < 1e-3, k
@@ -126,32 +151,128 @@ def test_train_forward_backward_fp32_matches_oracle(variant, S, B):
         return v[min(len(v) - 1, int(q * len(v)))]
     o80, omed = pct(e_o32, 0.8), pct(e_o32, 0.5)
 
-    # Train-mode BatchNorm on a handful of samples (the e-ASPP global branch normalises B values per channel) is ill-conditioned in
-    # fp32: which way the float atomics of a reduction happen to round shifts a normalised activation visibly, and every gradient
-    # upstream of it with it.  Identical inputs therefore give a few discrete outcomes (tools/diag_grad_dist.py: median per-parameter
-    # error 8e-4, 1.2e-3 or 7e-3 against fp64 -- the fp32 ORACLE's own worst parameter is off by 1.3e-2); the kernels themselves are
-    # bit-reproducible (tools/diag_tn_repro.py).  So: every run must stay inside loose bounds, and at least one of three runs must be as
-    # close to fp64 as the fp32 oracle is (x3) -- a wrong kernel fails all of them.
-    tight_ok, report = False, []
-    for attempt in range(3):
-        if attempt:
-            out = m(x.cuda())
-            losses = crit.forward_batched(out["predictions"], out["edge"], torch.stack(masks).cuda(), torch.stack(edges).cuda())
-        for p in m.parameters():
-            p.grad = None
-        losses["loss"].backward()
-        e_hip = {}
-        for k, p in m.named_parameters():
-            if g64[k] is not None:
-                e_hip[k] = float((p.grad.cpu().double() - g64[k]).abs().max()) / max(float(g64[k].abs().max()), 1e-3 * gmax)
-        h95, h80, hmed, hmax = pct(e_hip, 0.95), pct(e_hip, 0.8), pct(e_hip, 0.5), max(e_hip.values())
-        top = dict(sorted(e_hip.items(), key=lambda kv: -kv[1])[:5])
-        report.append(f"run {attempt}: median {hmed:.2e} p80 {h80:.2e} p95 {h95:.2e} max {hmax:.2e}")
-        assert h80 < 3e-2 and h95 < 5e-2 and hmax < 0.5, f"gradient error outside the loose bounds: {report[-1]}; top {top}"
-        if h80 < 3 * o80 + 2e-3 and hmed < 3 * omed + 5e-4:
-            tight_ok = True
-            break
-    assert tight_ok, f"no run as close to fp64 as the fp32 oracle (x3; oracle median {omed:.2e} p80 {o80:.2e}): {report}"
+    # One run, tight bound: every cross-workgroup reduction is a fixed-order sum (no float atomics), so identical inputs give one
+    # outcome and the HIP fp32 path has to be as close to fp64 as the fp32 oracle itself is (x3).
+    for p in m.parameters():
+        p.grad = None
+    losses["loss"].backward()
+    e_hip = {}
+    for k, p in m.named_parameters():
+        if g64[k] is not None:
+            e_hip[k] = float((p.grad.cpu().double() - g64[k]).abs().max()) / max(float(g64[k].abs().max()), 1e-3 * gmax)
+    h95, h80, hmed, hmax = pct(e_hip, 0.95), pct(e_hip, 0.8), pct(e_hip, 0.5), max(e_hip.values())
+    top = dict(sorted(e_hip.items(), key=lambda kv: -kv[1])[:5])
+    rep = f"median {hmed:.2e} p80 {h80:.2e} p95 {h95:.2e} max {hmax:.2e} (oracle fp32: median {omed:.2e} p80 {o80:.2e}); top {top}"
+    print("fp32 gradient error vs fp64:", rep)
+    assert h80 < 3 * o80 + 2e-3 and hmed < 3 * omed + 5e-4 and hmax < 0.5, rep
+
+
+def _train_once(m, crit, x, masks, edges):
+    for p in m.parameters():
+        p.grad = None
+    out = m(x)
+    losses = crit.forward_batched(out["predictions"], out["edge"], masks, edges)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    return out, losses
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_train_forward_backward_is_bit_reproducible(dtype):
+    """Two train-mode forward+backward passes on identical inputs and parameters in one process: outputs, loss, BatchNorm running
+    statistics and every gradient whose reduction is a fixed-order sum must be BIT-identical (the forward BN statistics, GAP means and
+    BN-backward sums used to be finished with float atomics).  The remaining order-dependent sums are bias gradients added by the
+    weight-gradient GEMMs / padded attention windows: parameter-only, last-bit noise, bounded here at 1e-5 relative."""
+    from spegnet_amd.utils.loss_functions import CODLoss
+    runs = []
+    x, masks, edges = O.synthetic_batch(4, 128, seed=21)
+    xs, ms, es = x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda()
+    for rep in range(2):
+        m, sd, cfg = make_model("large", dtype, train=True)
+        crit = CODLoss().cuda()
+        out, losses = _train_once(m, crit, xs, ms, es)
+        st = {k: v.detach().clone() for k, v in m.state_dict().items() if "running_" in k}
+        runs.append((_detach_out(out), {k: v.detach().clone() for k, v in losses.items()}, st,
+                     {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    (o0, l0, s0, g0), (o1, l1, s1, g1) = runs
+    for a, b in zip(o0["predictions"] + [o0["edge"]] + list(o0["features"].values()), o1["predictions"] + [o1["edge"]] + list(o1["features"].values())):
+        assert torch.equal(a, b)
+    for k in l0:
+        assert torch.equal(l0[k], l1[k]), k
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    exact = loose = 0
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k in g0:
+        if torch.equal(g0[k], g1[k]):
+            exact += 1
+            continue
+        assert k.endswith(".bias"), f"{k}: gradient differs between two identical runs"
+        scale = max(float(g0[k].abs().max()), 1e-3 * gmax)
+        assert float((g0[k].float() - g1[k].float()).abs().max()) < 1e-5 * scale, k
+        loose += 1
+    print(f"bit-identical gradients: {exact} of {exact + loose} parameters ({loose} order-dependent bias sums)")
+
+
+def test_train_backward_bf16_gradients_close_to_oracle():
+    """The bf16 kernels (the shipped fast path: pipelined NT / grouped TN GEMMs, resident-window attention) composed into the whole
+    Hiera-L backward at 128 px: per-parameter cosine and relative norm against the fp32 oracle's gradients."""
+    from spegnet_amd.utils.loss_functions import CODLoss
+    m, sd, cfg = make_model("large", "bf16", train=True)
+    x, masks, edges = O.synthetic_batch(4, 128, seed=20)
+    _, ref_losses, g32, _ = oracle_loss_and_grads(sd, cfg, x, masks, edges, O.LOSS_DEFAULT_YAML)
+    crit = CODLoss(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in O.LOSS_DEFAULT_YAML.items()}).cuda()
+    out, losses = _train_once(m, crit, x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda())
+    assert abs(float(losses["loss"]) - float(ref_losses["loss"])) < 3e-2 * abs(float(ref_losses["loss"]))
+    gmax = max(float(g.abs().max()) for g in g32.values() if g is not None)
+    cos, rn, big = {}, {}, 0
+    for k, p in m.named_parameters():
+        r = g32[k]
+        if r is None or float(r.abs().max()) < 1e-3 * gmax:      # gradients that are rounding noise in the oracle itself
+            continue
+        big += 1
+        a, b = p.grad.detach().cpu().double().flatten(), r.double().flatten()
+        cos[k] = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
+        rn[k] = float((a - b).norm() / b.norm())
+    cs, rs = sorted(cos.values()), sorted(rn.values())
+    rep = (f"{big} parameters: cosine min {cs[0]:.4f} p05 {cs[int(0.05 * len(cs))]:.4f} median {cs[len(cs) // 2]:.4f}; "
+           f"relative L2 error median {rs[len(rs) // 2]:.3f} p95 {rs[int(0.95 * len(rs))]:.3f} max {rs[-1]:.3f}")
+    print("bf16 gradients vs fp32 oracle:", rep)
+    worst = dict(sorted(cos.items(), key=lambda kv: kv[1])[:5])
+    # Yardstick (CPU, fp32 oracle arithmetic, ONLY the weights and the input rounded to bf16 once): cosine min 0.939 / p05 0.956 / median
+    # 0.964 against the unrounded gradients at this size -- a randomly initialised net with train-mode BatchNorm over 4 samples is that
+    # ill-conditioned.  The bf16 path additionally rounds every activation of 48 blocks, so ~0.90 is its expected level; a wrong kernel
+    # shows up as a parameter (or everything upstream of it) near zero or negative cosine.
+    assert cs[len(cs) // 2] > 0.85 and cs[int(0.05 * len(cs))] > 0.80 and cs[0] > 0.6, (rep, worst)
+    assert rs[len(rs) // 2] < 0.6 and rs[-1] < 0.9, rep
+
+
+def test_config2_train_step_matches_oracle():
+    """BASELINE config #2 at full size: batch 8 @384x384, bf16, hipGraph-captured step (what bench.py times).  Loss and global gradient
+    norm of the first step against the fp32 CPU oracle on the same batch and weights (the oracle step takes ~30 s of CPU)."""
+    from spegnet_amd.engine.arena import Arena
+    from spegnet_amd.engine.trainer import TrainStep
+    from spegnet_amd.utils.loss_functions import CODLoss
+    m, sd, cfg = make_model("large", "bf16", seed=3, train=True)
+    arena = Arena(m)
+    m.mark_params_changed()
+    arena.set_hyper(1e-4, 1e-5, 0.05)
+    crit = CODLoss(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in O.LOSS_DEFAULT_YAML.items()}).cuda()
+    step = TrainStep(m, crit, arena, grad_clip=1.0, capture=True)
+    x, masks, edges = O.synthetic_batch(8, 384, seed=70)
+    osd = {k: v.clone() for k, v in sd.items()}
+    ref_l, ref_norm, _ = O.train_step(osd, {}, x, masks, edges, base_lr=1e-4, wd=1e-5, enc_ratio=0.05, clip=1.0, cfg=cfg)
+    got = step(x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda())
+    torch.cuda.synchronize()
+    loss, gn = float(got["loss"]), float(arena.gnorm_sq.sqrt())
+    print(f"config #2 first step: loss {loss:.5f} (oracle {ref_l['loss']:.5f}), grad norm {gn:.4f} (oracle {ref_norm:.4f})")
+    assert abs(loss - ref_l["loss"]) < 2e-2 * abs(ref_l["loss"])
+    assert abs(float(got["seg_loss"]) - ref_l["seg_loss"]) < 2e-2 * abs(ref_l["seg_loss"])
+    assert abs(gn - ref_norm) < 0.1 * ref_norm
+    # a second replay on a new batch must run (static shapes) and stay finite
+    x2, m2, e2 = O.synthetic_batch(8, 384, seed=71)
+    l2 = float(step(x2.cuda(), torch.stack(m2).cuda(), torch.stack(e2).cuda())["loss"])
+    assert l2 == l2
 
 
 @pytest.mark.parametrize("capture", [False, True])
@@ -191,6 +312,40 @@ def test_train_steps_match_oracle(capture):
     assert bad / tot < 0.01, f"{bad}/{tot} parameter elements updated differently from the oracle"
     for k in ("fusion.bn.running_mean", "decoder.decoder_blocks.1.bn1.running_var"):
         assert rel_err(st[k].float(), osd[k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_adamw_pack_equals_adamw_then_pack(dtype):
+    """The fused optimizer (AdamW that also writes the compute-dtype weight copies, spg_adamw_pack) must leave parameters, moments and
+    EVERY packed copy bit-identical to the plain AdamW kernel followed by the separate re-pack."""
+    from spegnet_amd.engine.arena import Arena
+    res = []
+    for fused in (False, True):
+        m, sd, cfg = make_model("tiny", dtype, train=True)
+        arena = Arena(m)
+        m.mark_params_changed()
+        arena.set_hyper(1e-3, 1e-2, 0.5)
+        eng = m.engine
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for it in range(2):
+            arena.g.copy_(torch.randn(arena.size, device="cuda", generator=g) * 1e-2)
+            arena._clean = False
+            if fused:
+                arena.step(1.0, packer=eng)
+            else:
+                arena.step(1.0)
+                eng.pack()
+        torch.cuda.synchronize()
+        # (the random gradient above also fills the alignment padding between parameters, which only the plain kernel updates: compare
+        # the parameters' own ranges)
+        sl = [(arena.offsets[n], prm.numel()) for n, prm in m.named_parameters()]
+        res.append((torch.cat([arena.p[o:o + k] for o, k in sl]), torch.cat([arena.m[o:o + k] for o, k in sl]),
+                    torch.cat([arena.v[o:o + k] for o, k in sl]), {k: v.clone() for k, v in eng.W.items()}))
+    (p0, m0, v0, w0), (p1, m1, v1, w1) = res
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert set(w0) == set(w1) and len(w0) > 20
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
 
 
 def test_train_step_bf16_runs_and_decreases_loss():

@@ -93,7 +93,7 @@ def test_codloss_matches_reference(golden, cfg, name):
     assert torch.allclose(wm[:, :6, :6], rec["wmap0_corner"], atol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["tiny_64", "tiny_96", "large_64", "large_128"])
+@pytest.mark.parametrize("tag", ["tiny_64", "tiny_96", "large_64", "large_128", "large_384"])
 def test_trunk_matches_hf_crosscheck(golden, tag):
     """Secondary pin (the reference's own trunk lives in the absent `sam2` package)."""
     rec = golden("trunk_hf.pt")[tag]
