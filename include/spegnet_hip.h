@@ -40,13 +40,16 @@ const char* spg_last_error(void);
  *   conv3x3 != 0: X is NHWC [B,H,W,Ci], M=B*H*W, K=9*Ci, k = tap*Ci+ci (pad 1, stride 1), W packed [N][9*Ci].
  * spg_gemm_tn: dW[N,K] += dY[M,N]^T . X[M,K]   (f32 atomic accumulation; same conv3x3 gather on X);
  *   dbias != NULL: also dbias[n] += sum_m dY[m][n] (the bias gradient, fused so dY is read once)
- *   replaces the weight-gradient half of linear/conv backward (engine/trainer.py:402 .backward()).    */
+ *   replaces the weight-gradient half of linear/conv backward (engine/trainer.py:402 .backward()).
+ * cu_budget (every GEMM entry point): number of CUs the persistent grid of THIS launch is sized for, 0 = all.  The kernels fill a
+ *   CU completely, so a caller that overlaps them with another resident kernel (RCCL's all-reduce) leaves it some CUs instead of
+ *   paying a second round.  A per-call argument: the library keeps no mutable state between calls.                               */
 int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, void* C2, const float* bias,
                 const void* residual, const void* gelu_h, int M, int N, int K, int ldx, int ldc, int act,
-                int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream);
+                int conv3x3, int B, int H, int Wd, int Ci, int cu_budget, spg_stream_t stream);
 int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, void* workspace, long workspace_bytes,
                 int M, int N, int K, int ldy, int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci,
-                spg_stream_t stream);
+                int cu_budget, spg_stream_t stream);
 /* bytes of caller-owned scratch that lets the M-splits of spg_gemm_tn write partial slabs with plain stores (+ one reduce
  * launch) instead of f32 atomics; 0 = not split.  workspace may be NULL (atomics are used).                             */
 long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K);
@@ -58,7 +61,7 @@ long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K);
  * of sam2's MultiScaleBlock).                                                                                                     */
 int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias,
                       int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, void* workspace,
-                      long workspace_bytes, void* reduce_desc_out, spg_stream_t stream);
+                      long workspace_bytes, void* reduce_desc_out, int cu_budget, spg_stream_t stream);
 /* reduce_desc_out != NULL (a HOST buffer of spg_gemm_tn_group_desc_bytes()): the second kernel is not launched; the caller keeps the
  * workspace and later folds up to 6 such launches at once with spg_gemm_tn_group_reduce_batch (descs / workspaces: HOST arrays of n
  * pointers: host descriptors, device workspaces).  The gradients are complete only after that call; a gradient buffer may appear
@@ -66,10 +69,6 @@ int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* c
 long spg_gemm_tn_group_desc_bytes(void);
 int spg_gemm_tn_group_reduce_batch(int n, const void* const* descs, const void* const* workspaces, spg_stream_t stream);
 long spg_gemm_tn_group_workspace_bytes(void);
-/* Number of CUs the persistent GEMM grids of the FOLLOWING launches are sized for (0 = all).  The kernels fill a CU completely, so a
- * caller that overlaps them with another resident kernel (RCCL's all-reduce) leaves it some CUs instead of paying a second round.   */
-int spg_set_cu_budget(int n);
-
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
  * spg_pack_matrix: dst[r][c] = src[r][c] (transpose=0) or dst[c][r] = src[r][c] (transpose=1), src f32 [R,C].
  * spg_pack_conv3x3: torch [Co,Ci,3,3] f32 -> fwd pack [Co][tap][Ci] and dgrad pack [Ci][tap'][Co] (tap' flipped).
@@ -166,6 +165,12 @@ int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, float* r
 int spg_bn_stats_finalize(int dtype, const void* x, float* stats, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, long long* num_batches_tracked, float* scale_shift, float* mean_invstd, long M, int C,
                           float eps, float momentum, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
+/* the same for FOUR BatchNorms of C/4 channels each over one [M, C] tensor (the e-ASPP branches stored branch-major in one tensor):
+ * gamma4 ... num_batches_tracked4 are HOST arrays of 4 device pointers (running_* / num_batches_tracked arrays or entries may be NULL). */
+int spg_bn_stats_finalize4(int dtype, const void* x, float* stats, const float* const* gamma4, const float* const* beta4,
+                           float* const* running_mean4, float* const* running_var4, long long* const* num_batches_tracked4, float* scale_shift,
+                           float* mean_invstd, long M, int C, float eps, float momentum, float* red_ws, long red_ws_floats,
+                           unsigned* red_counters, spg_stream_t stream);
 int spg_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* scale_shift, float* mean_invstd, long M, int C, float eps,
                     float momentum, int training, spg_stream_t stream);
@@ -243,6 +248,37 @@ int spg_bn_bwd_head_counters(int dtype, int C);
 int spg_bn_bwd_head(int dtype, const void* dnext, const void* x, const void* dpred, const float* head_w, const float* scale_shift,
                     const float* mean_invstd, const float* gamma, float* sums, void* dx, float* dgamma, float* dbeta, float* dhead_w,
                     float* dhead_b, long M, int C, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
+
+/* ---- e-ASPP middle, branch-batched (csrc/easpp.hip; feature_integration.py:397-412) -----------------------------------------------
+ * The four dilated depth-wise branches share ONE tensor dcat [M, 4C] in the reference's branch-major concat order.
+ * dwconv4: dcat[p][br*C+c] = dilated depth-wise 3x3 of x[B,H,W,C] with w4[br] (f32 [C][9]), dilation dil4[br] = padding (HOST arrays of 4).
+ * dwconv4_dgrad: dx[p][c] = gadd[b][c] (f32 [B,C] or NULL: the global-average-pool adjoint) + sum over branches of the flipped convolution
+ *   of dy[M,4C].   dwconv4_wgrad: dw4[br] (f32 [C][9]) += ...; deterministic: red_ws 4*64*9*C floats, 4 zeroed counters.
+ * easpp_fuse_bn: y[p][g] = sum_j w[g][j] * cat[p][5g+j], cat = [relu(dcat*scale+shift) | glob[b]] (grouped 1x1, groups = C, branch-major
+ *   quirk SURVEY 2.2 C8) with the four branch BatchNorms' apply + ReLU folded in (scale_shift f32 [2*4C]).
+ * easpp_fuse_bn_bwd: gradient of that w.r.t. dcat THROUGH the branch BatchNorms (training statistics) in one reduce + apply pair:
+ *   ddcat[M,4C]; dgamma4/dbeta4 (four f32 [C], +=), dw[cc] += for cc < 4C (the global-branch part of dw and dglob: easpp_global_bwd).
+ * easpp_global_fwd/bwd: the global branch (GAP -> 1x1 conv C->C -> BatchNorm over the B values -> ReLU, :335-345,401-408) as one
+ *   single-workgroup kernel each way; gsum = per-image column sums of the reduced map (spg_gap_sum), S = those of the fusion conv's
+ *   output gradient; gadd = d(GAP input)/HW for dwconv4_dgrad.  B <= 64.                                                              */
+int spg_dwconv4(int dtype, const void* x, const float* const* w4, const int* dil4, void* dcat, int B, int H, int W, int C, spg_stream_t stream);
+int spg_dwconv4_dgrad(int dtype, const void* dy, const float* const* w4, const int* dil4, const float* gadd, void* dx, int B, int H, int W, int C,
+                      spg_stream_t stream);
+int spg_dwconv4_wgrad(int dtype, const void* dy, const void* x, const int* dil4, float* const* dw4, int B, int H, int W, int C, float* red_ws,
+                      long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
+int spg_easpp_fuse_bn(int dtype, const void* dcat, const float* scale_shift, const float* glob, const float* w, void* y, int B, long HW, int C,
+                      spg_stream_t stream);
+long spg_easpp_fuse_bn_bwd_workspace_floats(int dtype, int C);
+int spg_easpp_fuse_bn_bwd_counters(int dtype, int C);
+int spg_easpp_fuse_bn_bwd(int dtype, const void* dfu, const void* dcat, const float* w, const float* scale_shift, const float* mean_invstd,
+                          const float* const* gamma4, float* const* dgamma4, float* const* dbeta4, float* sums, void* ddcat, float* dw, int B,
+                          long HW, int C, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
+int spg_easpp_global_fwd(const float* gsum, const float* Wg, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, float* gm, float* gl0, float* glob, float* scale_shift, float* mean_invstd, int B, int C,
+                         long HW, float eps, float momentum, int training, spg_stream_t stream);
+int spg_easpp_global_bwd(const float* S, const float* glob, const float* gl0, const float* gm, const float* wf, const float* Wg,
+                         const float* gamma, const float* mean_invstd, float* dwf, float* dWg, float* dgamma, float* dbeta, float* gadd, int B,
+                         int C, long HW, int training, spg_stream_t stream);
 
 /* ---- CODLoss, fixed-size ground truth (utils/loss_functions.py:114-295 + resize loop engine/trainer.py:358-383) ----------
  * weight_map: w = 1 + bw*(|Laplace3x3 m| + |avgpool31 m - m|); stats[b] = {sum m, sum w, sum edge_gt, -} (overwritten).

@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspegnet_hip.so")
+# SPG_LIBRARY=<path>: tools/ point this at libspegnet_hip_dev.so (python spegnet_amd/build.py --dev), the build that still contains the
+# superseded kernel families and their ablation switches; the product library is the default and the only one tests / bench load
+LIB_PATH = os.environ.get("SPG_LIBRARY") or os.path.join(_HERE, "libspegnet_hip.so")
 
 SPG_F32, SPG_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
@@ -18,11 +20,10 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 # name -> argument type string (p pointer, i int, l long, f float); every function returns int
 SIGNATURES = {
-    "spg_gemm_nt": "ipppppppiiiiiiiiiiip",
-    "spg_gemm_tn": "ipppppliiiiiiiiiiip",
-    "spg_gemm_tn_group": "ii" "pppp" "i" "ppppp" "plpp",
+    "spg_gemm_nt": "ipppppppiiiiiiiiiiiip",
+    "spg_gemm_tn": "ipppppliiiiiiiiiiiip",
+    "spg_gemm_tn_group": "ii" "pppp" "i" "ppppp" "plp" "i" "p",
     "spg_gemm_tn_group_reduce_batch": "ippp",
-    "spg_set_cu_budget": "i",
     "spg_pack_matrix": "ippiiip",
     "spg_pack_batch": "ipiip",
     "spg_pack_conv3x3": "ipppiip",
@@ -45,6 +46,7 @@ SIGNATURES = {
     "spg_copy_channels": "ipp" "liiiiiip",
     "spg_bn_stats": "ipp" "li" "plp" "p",
     "spg_bn_stats_finalize": "ipp" "ppppppp" "liff" "plp" "p",
+    "spg_bn_stats_finalize4": "ipp" "ppppppp" "liff" "plp" "p",
     "spg_bn_finalize": "ppppppp" "liffip",
     "spg_bn_apply": "ippp" "liip",
     "spg_bn_bwd_reduce": "ippppp" "lii" "plp" "p",
@@ -61,6 +63,13 @@ SIGNATURES = {
     "spg_easpp_fuse_bwd": "ipppppppppppp" "p" "ili" "plp" "p",
     "spg_head1x1": "ipppp" "lip",
     "spg_head1x1_bwd": "ipppppp" "lii" "plp" "p",
+    "spg_dwconv4": "ipppp" "iiii" "p",
+    "spg_dwconv4_dgrad": "ippppp" "iiii" "p",
+    "spg_dwconv4_wgrad": "ipppp" "iiii" "plp" "p",
+    "spg_easpp_fuse_bn": "ippppp" "ili" "p",
+    "spg_easpp_fuse_bn_bwd": "ippppppppppp" "ili" "plp" "p",
+    "spg_easpp_global_fwd": "pppppppppppp" "iilffi" "p",
+    "spg_easpp_global_bwd": "ppppppppppppp" "iili" "p",
     "spg_cfi_combine": "ipppp" "iiiiiiii" "p",
     "spg_bn_apply_head": "ippppp" "p" "lii" "p",
     "spg_ped_gather": "ipp" "iii" "p" "iii" "p" "iii" "p",
@@ -85,6 +94,8 @@ QUERIES = {
     "spg_loss_workspace_floats": ("l", "ii"),
     "spg_head1x1_bwd_workspace_floats": ("l", "i"),
     "spg_bn_bwd_head_workspace_floats": ("l", "ii"),
+    "spg_easpp_fuse_bn_bwd_workspace_floats": ("l", "ii"),
+    "spg_easpp_fuse_bn_bwd_counters": ("i", "ii"),
     "spg_bn_bwd_head_counters": ("i", "ii"),
 }
 _OPTIONAL = {}

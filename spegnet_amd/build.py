@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspegnet_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "attention.hip", "norm.hip", "elem.hip", "head.hip", "loss.hip", "optim.hip"]
+SOURCES = ["core.hip", "gemm.hip", "attention.hip", "norm.hip", "elem.hip", "head.hip", "easpp.hip", "loss.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-munsafe-fp-atomics"]
 
 
@@ -18,8 +18,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
+    """dev=True (tools/ only, `python spegnet_amd/build.py --dev`): also compiles the superseded / experimental kernel families and the
+    SPG_* ablation switches of csrc/gemm.hip (-DSPG_DEV_KERNELS) into libspegnet_hip_dev.so; the product library has neither."""
+    global LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if dev:
+        return _build_dev(hipcc, verbose)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "spegnet_hip.h")]
     objdir = os.path.join(HERE, "build")
@@ -47,5 +52,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def _build_dev(hipcc, verbose):
+    objdir = os.path.join(HERE, "build", "dev")
+    os.makedirs(objdir, exist_ok=True)
+    lib = os.path.join(HERE, "libspegnet_hip_dev.so")
+    objs = []
+    for src in [s_ for s_ in SOURCES if os.path.exists(os.path.join(CSRC, s_))]:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-DSPG_DEV_KERNELS", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        objs.append(obj)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

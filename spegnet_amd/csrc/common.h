@@ -176,6 +176,49 @@ __device__ __forceinline__ void finish_partials(const float* __restrict__ part, 
   }
 }
 
+// The same finish for whole partial ROWS of ldp floats (ldp % 4 == 0): res[0..ldp) (LDS) = sum over the nblk rows, fixed order.
+// A lane reads 16 bytes of a row, so one wave-instruction covers 1 KiB of a row, and eight row loads stay in flight per lane:
+// the last workgroup streams the partials instead of waiting out one memory latency per row (with 4-byte column loads the
+// finish of 1024 x 256 partials cost more than the reduction it finishes).  scratch: NT * 4 floats of LDS; ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void finish_rows(const float* __restrict__ part, int nblk, int ldp, float* res, float* scratch) {
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nq = ldp >> 2;
+  for (int q0 = 0; q0 < nq; q0 += 64) {
+    const int q = q0 + lane;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (q < nq) {
+      const float* col = part + q * 4;
+      int b = w;
+      for (; b + 7 * NW < nblk; b += 8 * NW) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(col + (long)b * ldp);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(col + (long)(b + NW) * ldp);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(col + (long)(b + 2 * NW) * ldp);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(col + (long)(b + 3 * NW) * ldp);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(col + (long)(b + 4 * NW) * ldp);
+        const f32x4 v5 = *reinterpret_cast<const f32x4*>(col + (long)(b + 5 * NW) * ldp);
+        const f32x4 v6 = *reinterpret_cast<const f32x4*>(col + (long)(b + 6 * NW) * ldp);
+        const f32x4 v7 = *reinterpret_cast<const f32x4*>(col + (long)(b + 7 * NW) * ldp);
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+      }
+      for (; b < nblk; b += NW) a0 += *reinterpret_cast<const f32x4*>(col + (long)b * ldp);
+    }
+    const f32x4 s = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(scratch + threadIdx.x * 4) = s;
+    __syncthreads();
+    if (w == 0 && q < nq) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(scratch + lane * 4);
+#pragma unroll
+      for (int i = 1; i < NW; ++i) t += *reinterpret_cast<const f32x4*>(scratch + (i * 64 + lane) * 4);
+      *reinterpret_cast<f32x4*>(res + q * 4) = t;
+    }
+  }
+  __syncthreads();
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace spg

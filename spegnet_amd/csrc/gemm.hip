@@ -17,7 +17,15 @@
 #include <type_traits>
 #include "common.h"
 
+// SPG_DEV_KERNELS (tools/ builds only, `python spegnet_amd/build.py --dev`): the superseded / experimental kernel families kept for A/B
+// measurements (register-staged NT kernel, 4-wave DMA kernel, deferred-epilogue and ablation instances of the pipelined kernels, the
+// 8-wave staged wgrad kernel, the 256 x 128 "wide" grouped wgrad kernel) and the SPG_* environment switches that select them
+// (DESIGN.md 3.1).  The product library is built WITHOUT it: it contains none of those kernels and reads no environment variable.
 namespace spg {
+
+#ifdef SPG_DEV_KERNELS
+static int dev_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#endif
 
 constexpr int BM = 128, BN = 128, ROWB = 128;  // tile rows, LDS row bytes
 constexpr int NT_THREADS = 256;
@@ -158,6 +166,7 @@ struct NtEpi {
   int act;
 };
 
+#ifdef SPG_DEV_KERNELS
 template <typename T, bool CONV>
 __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                              T* __restrict__ C, NtEpi epi, int M, int N, int K,
@@ -316,6 +325,8 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict
     if (half == 0) __syncthreads();
   }
 }
+#endif  // SPG_DEV_KERNELS (register-staged NT kernel)
+
 
 // ------------------------------------------------------------------------------------------------
 // gemm_nt, LDS-DMA pipeline (the default): persistent workgroups (one per CU) walk their tiles; operands stream
@@ -1741,6 +1752,7 @@ __global__ __launch_bounds__(256) void tn_group_reduce_batch_kernel(TnReduceBatc
   tn_group_reduce_body(b.g[z], b.slabs[z], b.G[z], blockIdx.x + 1, blockIdx.y, gridDim.y);
 }
 
+#ifdef SPG_DEV_KERNELS
 // ------------------------------------------------------------------------------------------------
 // gemm_tn_wide_kernel: the grouped wgrad kernel with 256 x 128 (n x k) or 128 x 256 macro-tiles, chosen per problem on the host.
 // The grouped 128 x 128 kernel is fill-bound (81 of 99 us without any MFMA): a macro-tile moves 48 KiB per 64-row
@@ -2056,6 +2068,8 @@ __global__ __launch_bounds__(256) void tnw_reduce_kernel(TnwGroup g, const float
   }
 }
 
+#endif  // SPG_DEV_KERNELS (wide grouped wgrad kernel)
+
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
@@ -2147,34 +2161,43 @@ __global__ void unpack_conv3x3_grad_kernel(const float* __restrict__ packed, flo
 
 // CUs the persistent GEMM grids are sized for.  These kernels occupy a CU completely (160 KiB LDS, every VGPR), so when another
 // long-running kernel holds some CUs -- RCCL's all-reduce while it overlaps the backward pass -- a grid sized to all 256 needs a second
-// round for the displaced workgroups (2x for every GEMM that overlaps the collective).  spg_set_cu_budget(n) lowers the count for the
-// launches that follow (the multi-GPU trainer sets it around the graph segments that run beside a collective, engine/trainer.py);
-// SPG_CUS=<n> caps it for the whole process.
-static int g_cu_budget = 0;
-static int num_cus() {
+// round for the displaced workgroups (2x for every GEMM that overlaps the collective).  Every GEMM entry point therefore takes a
+// cu_budget argument (0 = all CUs): per call, no process-global state (the multi-GPU trainer passes it for the graph segments that
+// run beside a collective, engine/trainer.py).
+static int hw_cus() {
   static int hw = 0;
   if (hw == 0) {
     int dev = 0;
     hipDeviceProp_t p;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) hw = p.multiProcessorCount;
     if (hw <= 0) hw = 256;
-    const char* e = getenv("SPG_CUS");
-    if (e) { const int v = atoi(e); if (v >= 8 && v < hw) hw = v; }
+#ifdef SPG_DEV_KERNELS
+    const int v = dev_env("SPG_CUS", 0);
+    if (v >= 8 && v < hw) hw = v;
+#endif
   }
-  return (g_cu_budget >= 8 && g_cu_budget < hw) ? g_cu_budget : hw;
+  return hw;
 }
-static int gemm_variant() {  // SPG_GEMM=staged selects the register-staged kernel (A/B runs); default = LDS-DMA pipeline
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SPG_GEMM");
-    v = (e && strcmp(e, "staged") == 0) ? 0 : 1;
+static inline int num_cus(int budget = 0) {
+  const int hw = hw_cus();
+  return (budget >= 8 && budget < hw) ? budget : hw;
+}
+// tile width (32 * nb columns) of the persistent NT kernels: minimise rounds(tiles / CUs) x per-tile cost (MFMA work ~ nb, X fill + fixed ~ 1.5)
+static inline int pick_nb(int N, int tiles_m, int cus) {
+  int nb = 4;
+  float best = 1e30f;
+  for (int c = 4; c >= 2; --c) {
+    const long t = (long)cdiv(N, 32 * c) * tiles_m;
+    const float cost = (float)cdiv(t, cus) * ((float)c + 1.5f);
+    if (cost < best * 0.999f) { best = cost; nb = c; }
   }
-  return v;
+  return nb;
 }
 
+#ifdef SPG_DEV_KERNELS
 template <typename T>
 static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, int N, int K, int ldx, int ldc, int conv,
-                     ConvGeom g, hipStream_t s) {
+                     ConvGeom g, hipStream_t s, int cu_budget) {
   const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, BM);
   const int nwg = tiles_n * tiles_m;
   const long xb = (conv ? (long)M * g.Ci : (long)M * ldx) * (long)sizeof(T), wb = (long)N * K * (long)sizeof(T);
@@ -2182,14 +2205,14 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     set_error("gemm_nt: operand larger than 4 GiB (X %ld B, W %ld B) is not addressable by one buffer descriptor", xb, wb);
     return SPG_ERR_UNSUPPORTED;
   }
-  if (gemm_variant() == 1) {
+  if (dev_env("SPG_GEMM_STAGED", 0) == 0) {
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
       hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
       attr_set = true;
     }
-    const int grid = nwg < num_cus() ? nwg : num_cus();
+    const int grid = nwg < num_cus(cu_budget) ? nwg : num_cus(cu_budget);
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("SPG_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
     if ((dbg >= 1 && dbg <= 4) && !conv && getenv("SPG_GEMM_PIPE") && atoi(getenv("SPG_GEMM_PIPE")) == 0) {  // ablations of the plain 8-wave DMA kernel
@@ -2232,13 +2255,13 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
           float best = 1e30f;
           for (int c = 4; c >= 2; --c) {
             const long t = (long)cdiv(N, 32 * c) * tiles_m;
-            const float cost = (float)cdiv(t, num_cus()) * ((float)c + 1.5f);
+            const float cost = (float)cdiv(t, num_cus(cu_budget)) * ((float)c + 1.5f);
             if (cost < best * 0.999f) { best = cost; nb = c; }
           }
         }
         const int tn_ = cdiv(N, 32 * nb);
         const int nwg_ = tn_ * tiles_m;
-        const int gridp = nwg_ < num_cus() ? nwg_ : num_cus();
+        const int gridp = nwg_ < num_cus(cu_budget) ? nwg_ : num_cus(cu_budget);
         PipeEpi pe;
         pe.c_bytes = (unsigned)cb;
         pe.c2_bytes = epi.C2 ? (unsigned)cb : 0u;
@@ -2301,13 +2324,13 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
         float best = 1e30f;
         for (int c = 4; c >= 2; --c) {
           const long t = (long)cdiv(N, 32 * c) * tiles_m;
-          const float cost = (float)cdiv(t, num_cus()) * ((float)c + 1.5f);
+          const float cost = (float)cdiv(t, num_cus(cu_budget)) * ((float)c + 1.5f);
           if (cost < best * 0.999f) { best = cost; nb = c; }
         }
       }
       const int tn_ = cdiv(N, 32 * nb);
       const int nwg_ = tn_ * tiles_m;
-      const int grid8 = nwg_ < num_cus() ? nwg_ : num_cus();
+      const int grid8 = nwg_ < num_cus(cu_budget) ? nwg_ : num_cus(cu_budget);
 #define SPG_LAUNCH8(C_, NB_) hipLaunchKernelGGL((gemm_nt_dma_kernel<T, C_, 0, 4, NB_>), dim3(grid8), dim3(512), LDS8, s, (const T*)X, (const T*)W, \
                            (T*)C, epi, M, N, K, ldx, ldc, g, tn_, nwg_, (unsigned)xb, (unsigned)wb)
       if (conv) { if (nb == 4) SPG_LAUNCH8(true, 4); else if (nb == 3) SPG_LAUNCH8(true, 3); else SPG_LAUNCH8(true, 2); }
@@ -2333,6 +2356,76 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
   return check_launch("gemm_nt");
 }
 
+#else
+// Product dispatch: the pipelined persistent kernel for bf16 problems it has an instance for, the 8-wave LDS-DMA kernel for everything
+// else (fp32 parity mode; bf16 with ReLU, one K step, or rows that are not 8-element aligned).
+template <typename T>
+static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, int N, int K, int ldx, int ldc, int conv,
+                     ConvGeom g, hipStream_t s, int cu_budget) {
+  const int tiles_m = cdiv(M, BM);
+  const int cus = num_cus(cu_budget);
+  const long xb = (conv ? (long)M * g.Ci : (long)M * ldx) * (long)sizeof(T), wb = (long)N * K * (long)sizeof(T);
+  if (xb >= 0xFFFFFFF0L || wb >= 0xFFFFFFF0L) {
+    set_error("gemm_nt: operand larger than 4 GiB (X %ld B, W %ld B) is not addressable by one buffer descriptor", xb, wb);
+    return SPG_ERR_UNSUPPORTED;
+  }
+  const int nb = pick_nb(N, tiles_m, cus);
+  const int tn_ = cdiv(N, 32 * nb);
+  const int nwg_ = tn_ * tiles_m;
+  const int grid = nwg_ < cus ? nwg_ : cus;
+  if constexpr (sizeof(T) == 2) {
+    // pipelined kernel: bf16, >= 2 K steps per tile, 8-element-aligned rows, operands addressable by 32-bit offsets, and an
+    // epilogue it has an instance for (ReLU, or GELU together with gelu_h, go to the plain DMA kernel below)
+    const long cb = ((long)(M - 1) * ldc + N) * 2;
+    const int pact = epi.gelu_h ? PIPE_ACT_HH : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : PIPE_ACT_NONE);
+    const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE) && (epi.C2 == nullptr || pact == PIPE_ACT_GELU) &&
+                        !(conv && pact != PIPE_ACT_NONE);
+    if (K > ROWB / (int)sizeof(T) && N % 8 == 0 && ldc % 8 == 0 && cb < 0xFFFFFFF0L && epi_ok) {
+      PipeEpi pe;
+      pe.c_bytes = (unsigned)cb;
+      pe.c2_bytes = epi.C2 ? (unsigned)cb : 0u;
+      pe.r_bytes = epi.residual ? (unsigned)cb : 0u;
+      pe.h_bytes = epi.gelu_h ? (unsigned)cb : 0u;
+      pe.bias_bytes = epi.bias ? (unsigned)N * 4u : 0u;
+#define SPG_LAUNCHP(C_, A_, NB_)                                                                                                             \
+  do {                                                                                                                                     \
+    static bool attr_ = false;                                                                                                             \
+    if (!attr_) {                                                                                                                          \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pipe_kernel<T, C_, A_, NB_, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          PIPE_LDS_BYTES);                                                                                                 \
+      attr_ = true;                                                                                                                        \
+    }                                                                                                                                      \
+    hipLaunchKernelGGL((gemm_nt_pipe_kernel<T, C_, A_, NB_, false, 0>), dim3(grid), dim3(512), PIPE_LDS_BYTES, s, (const T*)X, (const T*)W,  \
+                       (T*)C, epi, pe, M, N, K, ldx, ldc, g, tn_, nwg_, (unsigned)xb, (unsigned)wb);                                       \
+  } while (0)
+#define SPG_LAUNCHP_NB(C_, A_) \
+  do { if (nb == 4) SPG_LAUNCHP(C_, A_, 4); else if (nb == 3) SPG_LAUNCHP(C_, A_, 3); else SPG_LAUNCHP(C_, A_, 2); } while (0)
+      if (conv) SPG_LAUNCHP_NB(true, PIPE_ACT_NONE);
+      else if (pact == PIPE_ACT_GELU) SPG_LAUNCHP_NB(false, PIPE_ACT_GELU);
+      else if (pact == PIPE_ACT_HH) SPG_LAUNCHP_NB(false, PIPE_ACT_HH);
+      else SPG_LAUNCHP_NB(false, PIPE_ACT_NONE);
+#undef SPG_LAUNCHP_NB
+#undef SPG_LAUNCHP
+      return check_launch("gemm_nt(pipe)");
+    }
+  }
+  constexpr int LDS8 = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
+  static bool attr8 = false;
+  if (!attr8) {
+#define SPG_SET_ATTR(C_, NB_) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, C_, 0, 4, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8)
+    SPG_SET_ATTR(true, 4); SPG_SET_ATTR(false, 4); SPG_SET_ATTR(true, 3); SPG_SET_ATTR(false, 3); SPG_SET_ATTR(true, 2); SPG_SET_ATTR(false, 2);
+#undef SPG_SET_ATTR
+    attr8 = true;
+  }
+#define SPG_LAUNCH8(C_, NB_) hipLaunchKernelGGL((gemm_nt_dma_kernel<T, C_, 0, 4, NB_>), dim3(grid), dim3(512), LDS8, s, (const T*)X, (const T*)W, \
+                           (T*)C, epi, M, N, K, ldx, ldc, g, tn_, nwg_, (unsigned)xb, (unsigned)wb)
+  if (conv) { if (nb == 4) SPG_LAUNCH8(true, 4); else if (nb == 3) SPG_LAUNCH8(true, 3); else SPG_LAUNCH8(true, 2); }
+  else { if (nb == 4) SPG_LAUNCH8(false, 4); else if (nb == 3) SPG_LAUNCH8(false, 3); else SPG_LAUNCH8(false, 2); }
+#undef SPG_LAUNCH8
+  return check_launch("gemm_nt(dma8)");
+}
+#endif  // SPG_DEV_KERNELS
+
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int splits, long nk4,
                                                         int K, int ldw) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < nk4; i += (long)gridDim.x * 256) {
@@ -2349,8 +2442,11 @@ template <typename T>
 static void tn_split_plan(int M, int N, int K, int* splits, int* m_per_split) {
   constexpr int MSTEP = ROWB / (int)sizeof(T);
   const int tiles = cdiv(N, 128) * cdiv(K, 128);
-  static int target = 0;
-  if (target == 0) { const char* e = getenv("SPG_TN_TARGET"); target = e ? atoi(e) : 384; }
+#ifdef SPG_DEV_KERNELS
+  static const int target = dev_env("SPG_TN_TARGET", 384);
+#else
+  constexpr int target = 384;
+#endif
   int sp = cdiv(target, tiles);  // blocks ~ target
   const int max_splits = cdiv(M, 4 * MSTEP);
   if (sp > max_splits) sp = max_splits;
@@ -2362,7 +2458,7 @@ static void tn_split_plan(int M, int N, int K, int* splits, int* m_per_split) {
 
 template <typename T>
 static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx, int ldw, int conv,
-                     ConvGeom g, hipStream_t s, float* dbias, float* ws, size_t ws_bytes) {
+                     ConvGeom g, hipStream_t s, float* dbias, float* ws, size_t ws_bytes, int cu_budget) {
   constexpr int MSTEP = ROWB / (int)sizeof(T);
   const int tiles_n = cdiv(N, 128), tiles_k = cdiv(K, 128);
   const int tiles = tiles_n * tiles_k;
@@ -2377,14 +2473,14 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
     set_error("gemm_tn: operand larger than 4 GiB is not addressable by one buffer descriptor");
     return SPG_ERR_UNSUPPORTED;
   }
-  static int tnv = -1;
-  if (tnv < 0) {   // default: pipelined kernel where it applies; SPG_GEMM_TN=staged selects the register-staged kernel for A/B runs
-    const char* e = getenv("SPG_GEMM_TN");
-    tnv = (e && strcmp(e, "staged") == 0) ? 0 : 2;
-  }
+#ifdef SPG_DEV_KERNELS
+  static const int tnv = dev_env("SPG_GEMM_TN_STAGED", 0) ? 0 : 2;   // A/B runs: the register-staged kernel for bf16 too
+#else
+  constexpr int tnv = 2;                                             // pipelined kernel wherever it applies
+#endif
   if constexpr (sizeof(T) == 2) {
     if (tnv == 2 && K % 4 == 0 && ws && (!conv || M < (1 << 24))) {
-      int sp = num_cus() / tiles;                      // one unit per workgroup is the balanced case
+      int sp = num_cus(cu_budget) / tiles;             // one unit per workgroup is the balanced case
       if (sp > max_splits) sp = max_splits;
       if (sp < 1) sp = 1;
       const int mps = cdiv(cdiv(M, sp), MSTEP) * MSTEP;
@@ -2392,7 +2488,7 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
       const size_t need = (size_t)sp * N * K * sizeof(float);
       if (ws_bytes >= need && need < 0xFFFFFFF0UL) {
         const int units = tiles * sp;
-        const int grid = units < num_cus() ? units : num_cus();
+        const int grid = units < num_cus(cu_budget) ? units : num_cus(cu_budget);
         constexpr int LDSP = 4 * 32768;
         static bool attrp = false;
         if (!attrp) {
@@ -2416,9 +2512,8 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
       }
     }
   }
-  static int waves = -1;
-  if (waves < 0) { const char* e = getenv("SPG_TN_WAVES"); waves = e ? atoi(e) : 4; }
-  if (waves == 8) {
+#ifdef SPG_DEV_KERNELS
+  if (dev_env("SPG_TN_WAVES", 4) == 8) {
     if (conv)
       hipLaunchKernelGGL((gemm_tn_kernel<T, true, 4>), dim3(tiles, splits), dim3(512), lds, s, (const T*)dY,
                          (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias, nullptr);
@@ -2427,6 +2522,7 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
                          (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias, nullptr);
     return check_launch("gemm_tn(8w)");
   }
+#endif
   if (conv)
     hipLaunchKernelGGL((gemm_tn_kernel<T, true>), dim3(tiles, splits), dim3(NT_THREADS), lds, s, (const T*)dY,
                        (const T*)X, dW, M, N, K, ldy, ldx, ldw, g, tiles_k, m_per_split, (unsigned)yb, (unsigned)xb, dbias, slabs);
@@ -2448,7 +2544,7 @@ using namespace spg;
 
 extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, void* C2, const float* bias,
                            const void* residual, const void* gelu_h, int M, int N, int K, int ldx, int ldc, int act,
-                           int conv3x3, int B, int H, int Wd, int Ci, spg_stream_t stream) {
+                           int conv3x3, int B, int H, int Wd, int Ci, int cu_budget, spg_stream_t stream) {
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "gemm_nt: bad dtype %d", dtype);
   SPG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
@@ -2462,28 +2558,27 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
   }
   NtEpi epi{bias, residual, gelu_h, C2, act};
   hipStream_t s = (hipStream_t)stream;
-  return dtype == SPG_BF16 ? launch_nt<bf16_t>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s)
-                           : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s);
+  return dtype == SPG_BF16 ? launch_nt<bf16_t>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget)
+                           : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget);
 }
 
-extern "C" int spg_set_cu_budget(int n) {   // 0 (or anything outside [8, #CUs)) = all CUs
-  g_cu_budget = n;
-  return SPG_OK;
-}
-
+#ifdef SPG_DEV_KERNELS
 extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus() * 2 * TNW_SLOT_FLOATS * (long)sizeof(float); }   // covers both kernels
+#else
+extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus() * 2 * TN_SLOT_FLOATS * (long)sizeof(float); }
+#endif
 
 extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW,
                                  float* const* dbias, int M, const int* N, const int* K, const int* ldy, const int* ldx,
-                                 const int* ldw, void* workspace, long workspace_bytes, void* reduce_desc_out, spg_stream_t stream) {
+                                 const int* ldw, void* workspace, long workspace_bytes, void* reduce_desc_out, int cu_budget,
+                                 spg_stream_t stream) {
   SPG_REQUIRE(dtype == SPG_BF16, "gemm_tn_group: bf16 only (dtype %d)", dtype);
   SPG_REQUIRE(njobs >= 1 && njobs <= TN_GROUP_MAX, "gemm_tn_group: 1..%d problems, got %d", TN_GROUP_MAX, njobs);
   SPG_REQUIRE(M > 0, "gemm_tn_group: empty M");
-  static int wide = -1;
+#ifdef SPG_DEV_KERNELS
   // opt-in (SPG_TN_GROUP_WIDE=1): measured no faster than the 128 x 128 grouped kernel on the stage-3 / stage-4 blocks (97.1 vs 96.5,
   // 96.7 vs 92.6 us), better only at stage 1 (139 vs 157 us) -- see the kernel's header and DESIGN.md 3.1
-  if (wide < 0) { const char* e = getenv("SPG_TN_GROUP_WIDE"); wide = e ? atoi(e) : 0; }
-  if (wide) {
+  if (dev_env("SPG_TN_GROUP_WIDE", 0)) {
     TnwGroup gw;
     long wtiles = 0;
     for (int i = 0; i < njobs; ++i) {
@@ -2508,15 +2603,14 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
     SPG_REQUIRE(wtiles * S < 0x7FFFFFFFL, "gemm_tn_group: too many steps");
     gw.njobs = njobs; gw.M = M; gw.S = S; gw.T = (int)wtiles;
     const long total_steps = wtiles * S;
-    const int G = total_steps < num_cus() ? (int)total_steps : num_cus();
+    const int G = total_steps < num_cus(cu_budget) ? (int)total_steps : num_cus(cu_budget);
     gw.W = (int)(wtiles / G);
     gw.RS = (int)((wtiles - (long)gw.W * G) * S);
     const long need = (long)G * 2 * TNW_SLOT_FLOATS * (long)sizeof(float);
     SPG_REQUIRE(workspace && workspace_bytes >= need, "gemm_tn_group: workspace of %ld bytes needed (got %ld)", need, workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     constexpr int LDSW = 3 * 3 * 16384;
-    static int dbgw = -1;
-    if (dbgw < 0) { const char* e = getenv("SPG_TN_GROUP_DEBUG"); dbgw = e ? atoi(e) : 0; }
+    static const int dbgw = dev_env("SPG_TN_GROUP_DEBUG", 0);
     static bool attrw = false;
     if (!attrw) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<bf16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
@@ -2531,6 +2625,7 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
     hipLaunchKernelGGL(tnw_reduce_kernel, dim3(G - 1, 16), dim3(256), 0, s, gw, (const float*)workspace, G);
     return check_launch("gemm_tn_group(wide reduce)");
   }
+#endif  // SPG_DEV_KERNELS
   TnGroup g;
   long tiles = 0;
   for (int i = 0; i < njobs; ++i) {
@@ -2552,7 +2647,7 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   SPG_REQUIRE(tiles * S < 0x7FFFFFFFL, "gemm_tn_group: too many steps");
   g.njobs = njobs; g.M = M; g.S = S; g.T = (int)tiles;
   const long total_steps = tiles * S;
-  const int G = total_steps < num_cus() ? (int)total_steps : num_cus();
+  const int G = total_steps < num_cus(cu_budget) ? (int)total_steps : num_cus(cu_budget);
   g.W = (int)(tiles / G);
   g.RS = (int)((tiles - (long)g.W * G) * S);
   const long need = (long)G * 2 * TN_SLOT_FLOATS * (long)sizeof(float);
@@ -2564,12 +2659,12 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     attr = true;
   }
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("SPG_TN_GROUP_DEBUG"); dbg = e ? atoi(e) : 0; }
-  if (dbg == 2) {
+#ifdef SPG_DEV_KERNELS
+  if (dev_env("SPG_TN_GROUP_DEBUG", 0) == 2) {   // no-MFMA ablation (wrong results by construction): dev builds only
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   } else
+#endif
   hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   int rc = check_launch("gemm_tn_group");
   if (reduce_desc_out) {     // deferred: the caller collects descriptors and folds the slabs later (spg_gemm_tn_group_reduce_batch)
@@ -2616,7 +2711,7 @@ extern "C" long spg_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {
 }
 
 extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, void* workspace, long workspace_bytes,
-                           int M, int N, int K, int ldy, int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci,
+                           int M, int N, int K, int ldy, int ldx, int ldw, int conv3x3, int B, int H, int Wd, int Ci, int cu_budget,
                            spg_stream_t stream) {
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "gemm_tn: bad dtype %d", dtype);
@@ -2629,8 +2724,8 @@ extern "C" int spg_gemm_tn(int dtype, const void* dY, const void* X, float* dW, 
     SPG_REQUIRE(ldx % vec == 0 && ldx >= K, "gemm_tn: bad ldx=%d", ldx);
   }
   hipStream_t s = (hipStream_t)stream;
-  return dtype == SPG_BF16 ? launch_tn<bf16_t>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias, (float*)workspace, (size_t)workspace_bytes)
-                           : launch_tn<float>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias, (float*)workspace, (size_t)workspace_bytes);
+  return dtype == SPG_BF16 ? launch_tn<bf16_t>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias, (float*)workspace, (size_t)workspace_bytes, cu_budget)
+                           : launch_tn<float>(dY, X, dW, M, N, K, ldy, ldx, ldw, conv3x3, g, s, dbias, (float*)workspace, (size_t)workspace_bytes, cu_budget);
 }
 
 extern "C" int spg_pack_matrix(int dtype, const float* src, void* dst, int R, int C, int transpose, spg_stream_t stream) {

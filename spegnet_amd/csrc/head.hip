@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void ped_gather_bwd_kernel(const T* __restrict
 // Grid (row blocks, 1, channel slabs) as colreduce_kernel (norm.hip); partial layout [slab][row block][4][SW].
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr int HB_SLAB_CHUNKS = 16;
-constexpr int HB_MAX_GX = 1024;
+constexpr int HB_MAX_GX = 512;
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_head_reduce_kernel(const T* __restrict__ dnext, const T* __restrict__ x, const T* __restrict__ dpred,
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void bn_bwd_head_reduce_kernel(const T* __rest
     mu[e] = mi[c]; is[e] = mi[C + c]; sc[e] = ss[c]; sh[e] = ss[C + c]; wv[e] = hw[c];
   }
   if (active) {
+#pragma unroll 4
     for (long r = r0 + rl; r < r1; r += rpar) {
       float xv[VEC], dv[VEC];
       unpack16<T>(ld16(x + r * C + ch * VEC), xv);
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(256) void bn_bwd_head_reduce_kernel(const T* __rest
       }
     }
   }
-  __shared__ float red[3][256 * 8];
+  __shared__ __attribute__((aligned(16))) float red[3][256 * 8];
+  __shared__ __attribute__((aligned(16))) float fscr[256 * 4];
   __shared__ float redb[256];
   __shared__ unsigned s_last;
 #pragma unroll
@@ -268,25 +270,30 @@ __global__ __launch_bounds__(256) void bn_bwd_head_reduce_kernel(const T* __rest
   redb[threadIdx.x] = sb;
   __syncthreads();
   const int SW = nchs * VEC;
+  const int ldp = 3 * SW + 4;                          // partial row: [3][SW] sums + the head-bias sum (+ pad to 16 bytes)
   const int gx = gridDim.x;
-  float* mypart = part + (((long)slab * gx) + blockIdx.x) * (4 * SW);
+  float* mypart = part + (((long)slab * gx) + blockIdx.x) * ldp;
   for (int c = threadIdx.x; c < SW; c += 256) {
     float t0 = 0.f, t1 = 0.f, t2 = 0.f;
     for (int r = 0; r < rpar; ++r) { t0 += red[0][r * SW + c]; t1 += red[1][r * SW + c]; t2 += red[2][r * SW + c]; }
     st_part(mypart + c, t0); st_part(mypart + SW + c, t1); st_part(mypart + 2 * SW + c, t2);
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 4) {
     float t = 0.f;
-    for (int r = 0; r < 256; ++r) t += redb[r];
-    st_part(mypart + 3 * SW, t);
+    if (threadIdx.x == 0) for (int r = 0; r < 256; ++r) t += redb[r];
+    st_part(mypart + 3 * SW + threadIdx.x, t);
   }
   if (!arrive_last(counters + slab, (unsigned)gx, &s_last)) return;
-  const float* pbase = part + ((long)slab * gx) * (4 * SW);
+  const float* pbase = part + ((long)slab * gx) * ldp;
   const int ncols = min(SW, C - slab * SW);
-  finish_partials<256>(pbase, gx, 4 * SW, ncols, sums + slab * SW, 0, &red[0][0]);
-  finish_partials<256>(pbase + SW, gx, 4 * SW, ncols, sums + C + slab * SW, 0, &red[0][0]);
-  finish_partials<256>(pbase + 2 * SW, gx, 4 * SW, ncols, sums + 2 * C + slab * SW, 0, &red[0][0]);
-  if (slab == 0) finish_partials<256>(pbase + 3 * SW, gx, 4 * SW, 1, sums + 3 * C, 0, &red[0][0]);
+  float* res = &red[0][0];
+  finish_rows<256>(pbase, gx, ldp, res, fscr);
+  for (int cl = threadIdx.x; cl < ncols; cl += 256) {
+    sums[slab * SW + cl] = res[cl];
+    sums[C + slab * SW + cl] = res[SW + cl];
+    sums[2 * C + slab * SW + cl] = res[2 * SW + cl];
+  }
+  if (slab == 0 && threadIdx.x == 0) sums[3 * C] = res[3 * SW];
 }
 
 // dx = gamma*invstd*(dy' - s0/M - xhat*s1/M);  block 0 also: dgamma += s1, dbeta += s0, dw_head += s2, db_head += sb
@@ -480,7 +487,7 @@ extern "C" long spg_bn_bwd_head_workspace_floats(int dtype, int C) {
   const int v = vec_of_h(dtype), nch = C / v, nchs = nch < HB_SLAB_CHUNKS ? nch : HB_SLAB_CHUNKS, nslabs = cdiv(nch, nchs);
   long cap = 2048 / nslabs;
   if (cap > HB_MAX_GX) cap = HB_MAX_GX;
-  return cap * nslabs * 4L * nchs * v;
+  return cap * nslabs * (3L * nchs * v + 4);
 }
 extern "C" int spg_bn_bwd_head_counters(int dtype, int C) {
   const int v = vec_of_h(dtype), nch = C / v, nchs = nch < HB_SLAB_CHUNKS ? nch : HB_SLAB_CHUNKS;
@@ -495,7 +502,7 @@ extern "C" int spg_bn_bwd_head(int dtype, const void* dnext, const void* x, cons
   SPG_REQUIRE(C % v == 0 && C / v <= 256, "bn_bwd_head: C=%d must be a multiple of %d and <= %d", C, v, 256 * v);
   SPG_REQUIRE(x && dpred && head_w && scale_shift && mean_invstd && gamma && sums && dx && dgamma && dbeta && dhead_w && dhead_b, "bn_bwd_head: null argument");
   const HbPlan p = hb_plan(M, C / v);
-  const long need = (long)p.gx * p.nslabs * 4 * p.nchs * v;
+  const long need = (long)p.gx * p.nslabs * (3 * p.nchs * v + 4);
   SPG_REQUIRE(red_ws && red_counters_ && red_ws_floats >= need, "bn_bwd_head: reduction workspace of %ld floats required, got %ld", need, red_ws_floats);
   hipStream_t s = (hipStream_t)stream;
   const long rpb = bn_rows_per_block_h(M, C / v);

@@ -118,12 +118,15 @@ enum { RED_SUM = 0, RED_SUM_SQ = 1, RED_BN_BWD = 2, RED_PROD = 3, RED_LN = 4 };
 // optional BatchNorm finalize folded into the last workgroup of a RED_SUM_SQ reduction (gamma == nullptr: none): batch mean / biased
 // variance -> scale_shift, mean_invstd, running statistics (unbiased variance), num_batches_tracked += 1 -- what bn_finalize_kernel does
 // in its own launch (and a torch kernel for the counter)
+// Up to 4 BatchNorms of gc channels each may share one reduction over 4*gc channels (the e-ASPP branches): channel c belongs to
+// parameter group c / gc.
 struct BnFin {
-  const float* gamma; const float* beta; float* rmean; float* rvar; long long* nbt; float* ss; float* mi;
+  const float* gamma[4]; const float* beta[4]; float* rmean[4]; float* rvar[4]; long long* nbt[4]; float* ss; float* mi;
   float eps, momentum;
+  int gc;       // channels per parameter group (== C for a single BatchNorm)
 };
 constexpr int RED_SLAB_CHUNKS = 16;
-constexpr int RED_MAX_GX = 1024;
+constexpr int RED_MAX_GX = 512;
 constexpr int RED_MAX_BLOCKS = 2048;
 
 template <typename T, int MODE>
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
     }
   }
   if (active) {
+#pragma unroll 4
     for (long r = r0 + rl; r < r1; r += rpar) {
       float av[VEC];
       unpack16<T>(ld16(a + (base + r) * lda + ch * VEC), av);
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
       }
     }
   }
-  __shared__ float red[2][256 * 8];
+  __shared__ __attribute__((aligned(16))) float red[2][256 * 8];
+  __shared__ __attribute__((aligned(16))) float fscr[256 * 4];
   __shared__ unsigned s_last;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x * VEC + e] = s0[e]; red[1][threadIdx.x * VEC + e] = s1[e]; }
@@ -211,29 +216,34 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
   if (!arrive_last(counters + blockIdx.y * nslabs + slab, (unsigned)gx, &s_last)) return;
   const float* pbase = part + (((long)blockIdx.y * nslabs + slab) * gx) * (K * SW);
   const int ncols = min(SW, C - slab * SW);
-  float* o = out + (long)blockIdx.y * C * K + slab * SW;
-  finish_partials<256>(pbase, gx, K * SW, ncols, o, accumulate, &red[0][0]);
-  if (TWO) finish_partials<256>(pbase + SW, gx, K * SW, ncols, (out1 ? out1 : out + (long)blockIdx.y * C * K + C) + slab * SW, accumulate, &red[0][0]);
+  float* res = &red[0][0];                                  // [K][SW] totals of this slab
+  finish_rows<256>(pbase, gx, K * SW, res, fscr);
+  float* o0 = out + (long)blockIdx.y * C * K + slab * SW;
+  float* o1 = (out1 ? out1 : out + (long)blockIdx.y * C * K + C) + slab * SW;
+  for (int cl = threadIdx.x; cl < ncols; cl += 256) {
+    o0[cl] = accumulate ? o0[cl] + res[cl] : res[cl];
+    if (TWO) o1[cl] = accumulate ? o1[cl] + res[SW + cl] : res[SW + cl];
+  }
   if constexpr (MODE == RED_SUM_SQ) {
-    if (fin.gamma) {            // this slab's channels: the sums were just written by threads of wave 0 of THIS block
-      __syncthreads();
+    if (fin.gamma[0]) {         // BatchNorm finalize of this slab's channels, straight from the totals in LDS
       const float Mf = (float)rows_total;
       for (int cl = threadIdx.x; cl < ncols; cl += 256) {
         const int c = slab * SW + cl;
-        const float mu = out[c] / Mf;
-        const float var = fmaxf(out[C + c] / Mf - mu * mu, 0.f);
-        if (fin.rmean) {
-          fin.rmean[c] = (1.f - fin.momentum) * fin.rmean[c] + fin.momentum * mu;
+        const int grp = c / fin.gc, cg = c - grp * fin.gc;
+        const float mu = res[cl] / Mf;
+        const float var = fmaxf(res[SW + cl] / Mf - mu * mu, 0.f);
+        if (fin.rmean[grp]) {
+          fin.rmean[grp][cg] = (1.f - fin.momentum) * fin.rmean[grp][cg] + fin.momentum * mu;
           const float unb = rows_total > 1 ? var * (Mf / (Mf - 1.f)) : var;
-          fin.rvar[c] = (1.f - fin.momentum) * fin.rvar[c] + fin.momentum * unb;
+          fin.rvar[grp][cg] = (1.f - fin.momentum) * fin.rvar[grp][cg] + fin.momentum * unb;
         }
         const float is = rsqrtf(var + fin.eps);
-        const float sc = fin.gamma[c] * is;
+        const float sc = fin.gamma[grp][cg] * is;
         fin.ss[c] = sc;
-        fin.ss[C + c] = fin.beta[c] - mu * sc;
+        fin.ss[C + c] = fin.beta[grp][cg] - mu * sc;
         if (fin.mi) { fin.mi[c] = mu; fin.mi[C + c] = is; }
       }
-      if (slab == 0 && threadIdx.x == 0 && fin.nbt) fin.nbt[0] += 1;
+      if (slab == 0 && threadIdx.x < 4 && threadIdx.x * fin.gc < C && fin.nbt[threadIdx.x]) fin.nbt[threadIdx.x][0] += 1;
     }
   }
 }
@@ -274,7 +284,7 @@ struct RedWs { float* part; long floats; unsigned* counters; };
 template <typename T, int MODE>
 static int launch_colreduce(const void* a, const void* b, const float* p0, const float* p1, float* out, long M, int C,
                             int lda, int nimg, long img_rows, int relu, RedWs ws, int accumulate, hipStream_t s, const char* what,
-                            float* out1 = nullptr, BnFin fin = BnFin{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f}) {
+                            float* out1 = nullptr, BnFin fin = BnFin{}) {
   constexpr int VEC = ST<T>::VEC;
   if (C % VEC != 0 || lda % VEC != 0) {
     set_error("%s: C=%d (lda=%d) must be a multiple of %d", what, C, lda, VEC);
@@ -482,7 +492,8 @@ __global__ __launch_bounds__(256) void ln_param_batch_kernel(LnBatch bt, float* 
       for (int e = 0; e < VEC; ++e) { s0[e] += dv[e]; s1[e] += dv[e] * (xv[e] - mu) * rs; }
     }
   }
-  __shared__ float red[2][256 * 8];
+  __shared__ __attribute__((aligned(16))) float red[2][256 * 8];
+  __shared__ __attribute__((aligned(16))) float fscr[256 * 4];
   __shared__ unsigned s_last;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x * VEC + e] = s0[e]; red[1][threadIdx.x * VEC + e] = s1[e]; }
@@ -495,8 +506,9 @@ __global__ __launch_bounds__(256) void ln_param_batch_kernel(LnBatch bt, float* 
     st_part(mypart + C + c, t1);
   }
   if (!arrive_last(counters + j, (unsigned)jb.nblk, &s_last)) return;
-  finish_partials<256>(part + jb.poff, jb.nblk, 2 * C, C, jb.dbeta, 1, &red[0][0]);
-  finish_partials<256>(part + jb.poff + C, jb.nblk, 2 * C, C, jb.dgamma, 1, &red[0][0]);
+  float* res = &red[0][0];                                  // [2][C] totals (C <= 2048: exactly red's size)
+  finish_rows<256>(part + jb.poff, jb.nblk, 2 * C, res, fscr);
+  for (int c = threadIdx.x; c < C; c += 256) { jb.dbeta[c] += res[c]; jb.dgamma[c] += res[C + c]; }
 }
 
 /* scratch: LN_BATCH_BLOCKS * 2 * sum(C[i]) floats of partials and njobs zeroed counters */
@@ -570,9 +582,31 @@ extern "C" int spg_bn_stats_finalize(int dtype, const void* x, float* stats, con
   SPG_REQUIRE(gamma && beta && scale_shift && stats, "bn_stats_finalize: gamma, beta, stats and scale_shift are required");
   hipStream_t s = (hipStream_t)stream;
   const RedWs ws{red_ws, red_ws_floats, red_counters_};
-  const BnFin fin{gamma, beta, running_mean, running_var, num_batches_tracked, scale_shift, mean_invstd, eps, momentum};
+  BnFin fin{};
+  fin.gamma[0] = gamma; fin.beta[0] = beta; fin.rmean[0] = running_mean; fin.rvar[0] = running_var; fin.nbt[0] = num_batches_tracked;
+  fin.ss = scale_shift; fin.mi = mean_invstd; fin.eps = eps; fin.momentum = momentum; fin.gc = C;
   return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats_finalize", nullptr, fin)),
                     (launch_colreduce<float, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats_finalize", nullptr, fin)));
+}
+
+// the same for four BatchNorms of C/4 channels each over one [M, C] tensor (the e-ASPP branches stored branch-major): HOST arrays of 4 pointers
+extern "C" int spg_bn_stats_finalize4(int dtype, const void* x, float* stats, const float* const* gamma4, const float* const* beta4,
+                                      float* const* running_mean4, float* const* running_var4, long long* const* num_batches_tracked4,
+                                      float* scale_shift, float* mean_invstd, long M, int C, float eps, float momentum, float* red_ws,
+                                      long red_ws_floats, unsigned* red_counters_, spg_stream_t stream) {
+  SPG_REQUIRE(gamma4 && beta4 && scale_shift && stats && C % 4 == 0, "bn_stats_finalize4: C=%d must be 4 groups", C);
+  hipStream_t s = (hipStream_t)stream;
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  BnFin fin{};
+  for (int i = 0; i < 4; ++i) {
+    SPG_REQUIRE(gamma4[i] && beta4[i], "bn_stats_finalize4: group %d has no parameters", i);
+    fin.gamma[i] = gamma4[i]; fin.beta[i] = beta4[i];
+    fin.rmean[i] = running_mean4 ? running_mean4[i] : nullptr; fin.rvar[i] = running_var4 ? running_var4[i] : nullptr;
+    fin.nbt[i] = num_batches_tracked4 ? num_batches_tracked4[i] : nullptr;
+  }
+  fin.ss = scale_shift; fin.mi = mean_invstd; fin.eps = eps; fin.momentum = momentum; fin.gc = C / 4;
+  return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats_finalize4", nullptr, fin)),
+                    (launch_colreduce<float, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats_finalize4", nullptr, fin)));
 }
 
 extern "C" int spg_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,

@@ -28,7 +28,7 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL's resident all-reduce blocks and the persistent GEMM kernels (which fill a CU completely) would fight for CUs while a
         # collective overlaps the backward pass: RCCL is capped to 16 channels here and the trainer sizes the GEMM grids that run
-        # beside a collective to COMM_CU_BUDGET CUs (engine/trainer.py; spg_set_cu_budget).  862 MB of fp32 gradients per step have
+        # beside a collective to COMM_CU_BUDGET CUs (engine/trainer.py; the cu_budget argument of the GEMM entry points).  862 MB of fp32 gradients per step have
         # > 20 ms of backward to hide in, so 16 channels are plenty.  A default only (set the variable to override).
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         # "nccl" IS RCCL on ROCm.  SPG_DIST_BACKEND=gloo exists only to rehearse the N>1 code path with several ranks on ONE GPU

@@ -60,7 +60,7 @@ class TrainStep:
         if sync is not None and not capture:
             ends = arena.unit_ends
             model.engine.unit_cb = lambda k: sync.ready(ends[k])
-            ops.set_cu_budget(COMM_CU_BUDGET)     # eager: bucket all-reduces overlap the whole trunk backward
+            model.cu_budget = COMM_CU_BUDGET      # eager: bucket all-reduces overlap the whole backward (applied per call, see SPEGNet)
 
     # ---- pieces -------------------------------------------------------------------------------------------
     def _fwd_bwd(self, images, masks, edges):
@@ -156,24 +156,21 @@ class TrainStep:
         self.segments = []
         # CU budget per segment (grid sizes are frozen at capture): the first segment and the optimizer run with no collective in
         # flight -> all CUs; segments 2.. replay while the previous range is being all-reduced -> leave RCCL its CUs
-        comm_cus = COMM_CU_BUDGET if self.world > 1 else 0
-        ops.set_cu_budget(0)
+        comm_cus = COMM_CU_BUDGET if (self.world > 1 or self.force_segmented) else 0
         g0 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g0):
+        with ops.cu_budget(0), torch.cuda.graph(g0):
             self.losses = self._seg_first(*self.static, plan[0][0], plan[0][1])
         self.segments.append(g0)
         pool = g0.pool()
-        ops.set_cu_budget(comm_cus)
         for k, (lo, hi, _) in enumerate(plan[1:], start=1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with ops.cu_budget(comm_cus), torch.cuda.graph(g, pool=pool):
                 eng.trunk_bwd_blocks(lo, hi)
                 if k == len(plan) - 1:
                     eng.trunk_bwd_end()
             self.segments.append(g)
-        ops.set_cu_budget(0)
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=pool):
+        with ops.cu_budget(0), torch.cuda.graph(self.graph_b, pool=pool):
             self._opt(1.0 / self.world)
         self._plan = plan
         self.graph = g0

@@ -45,9 +45,9 @@ class Engine:
         # Operands are held until join_wgrad(), which every backward piece calls before it returns.  Off by default: on one MI355X
         # the two chip-sized branches contend (226.0 vs 232.2 img/s, see engine/trainer.py).
         self.wgrad_async = False
-        self.group_wgrads = os.environ.get("SPG_TN_GROUP", "1") != "0"   # trunk blocks: one grouped wgrad launch per block
+        self.group_wgrads = True    # trunk blocks: one grouped wgrad launch per block (False: per-layer launches, for A/B runs)
         self._wg_jobs = None
-        self.batch_ln_params = os.environ.get("SPG_LN_BATCH", "1") != "0"   # trunk: LayerNorm dgamma / dbeta in batched launches
+        self.batch_ln_params = True  # trunk: LayerNorm dgamma / dbeta in batched launches
         self._ln_jobs = []
         self._tn_defer = []
         self._side = None
@@ -491,15 +491,26 @@ class Engine:
         # --- e-ASPP
         r0 = ops.gemm_nt(fused, W["context.reduce.0.weight"])
         r1, c["bn_r"] = self.bn_fwd("context.reduce.1.", r0, 128, True, training, save)
-        brs, bn_b, dws = [], [], []
-        for i, dil in enumerate(EASPP_RATES):
-            d = ops.dwconv3x3(r1, P[f"context.branches.{i}.0.weight"].view(128, 9), B, h, w, 128, dil)
-            y, st = self.bn_fwd(f"context.branches.{i}.1.", d, 128, True, training, save)
-            brs.append(y); bn_b.append(st)
-        gm = ops.gap_sum(r1, B, HW, 128) / HW                                    # [B,128] fp32
-        gl0 = ops.gemm_nt(gm, P["context.global_branch.1.weight"].view(128, 128))  # fp32 MFMA on 8 rows
-        glob, c["bn_g"] = self.bn_fwd("context.global_branch.2.", gl0, 128, True, training, save)
-        fu0 = ops.easpp_fuse(brs, glob, P["context.fusion.0.weight"].view(128, 5), B, HW, 128)
+        # e-ASPP middle, branch-batched (csrc/easpp.hip): the four dilated depth-wise branches share ONE tensor dcat [M, 512] in the
+        # reference's branch-major concat order; their BatchNorm statistics come from one reduction, their BN-apply + ReLU is folded into
+        # the grouped 1x1 fusion conv, and the global branch is one single-workgroup kernel
+        wd4 = [P[f"context.branches.{i}.0.weight"].view(128, 9) for i in range(4)]
+        dcat = ops.dwconv4(r1, wd4, EASPP_RATES, B, h, w, 128)
+        bnn = [f"context.branches.{i}.1." for i in range(4)]
+        if training:
+            ss_b, mi_b = ops.bn_stats_finalize4(dcat, 512, [P[n + "weight"] for n in bnn], [P[n + "bias"] for n in bnn],
+                                                [P[n + "running_mean"] for n in bnn], [P[n + "running_var"] for n in bnn],
+                                                [P[n + "num_batches_tracked"] for n in bnn])
+        else:
+            fin = [ops.bn_finalize(None, P[n + "weight"], P[n + "bias"], P[n + "running_mean"], P[n + "running_var"], M, False) for n in bnn]
+            ss_b = torch.cat([f[0][:128] for f in fin] + [f[0][128:] for f in fin])
+            mi_b = None
+        gs = ops.gap_sum(r1, B, HW, 128)
+        gn = "context.global_branch.2."
+        gm, gl0, glob, ss_g, mi_g = ops.easpp_global_fwd(gs, P["context.global_branch.1.weight"].view(128, 128), P[gn + "weight"], P[gn + "bias"],
+                                                         P[gn + "running_mean"], P[gn + "running_var"], P[gn + "num_batches_tracked"], B, 128, HW,
+                                                         training)
+        fu0 = ops.easpp_fuse_bn(dcat, ss_b, glob, P["context.fusion.0.weight"].view(128, 5), B, HW, 128)
         fu1, c["bn_u"] = self.bn_fwd("context.fusion.1.", fu0, 128, True, training, save)
         e0 = ops.gemm_nt(fu1, W["context.expand.0.weight"])
         context, c["bn_e"] = self.bn_fwd("context.expand.1.", e0, 256, True, training, save)
@@ -530,8 +541,8 @@ class Engine:
         out = {"predictions": preds, "edge": edge.view(B, 1, h, w), "context": context.view(B, h, w, 256),
                "fused": fused.view(B, h, w, 512), "edge_features": edge_f.view(B, h, w, 64)}
         if save:
-            c.update(s2=s2, s3=s3, s4=s4, f1=f1, gap=gap, hidden=hidden, scale=scale, fused=fused, r1=r1, brs=brs, bn_b=bn_b, gm=gm,
-                     glob=glob, fu1=fu1, context=context, edge_f=edge_f, stages=stages)
+            c.update(s2=s2, s3=s3, s4=s4, f1=f1, gap=gap, hidden=hidden, scale=scale, fused=fused, r1=r1, dcat=dcat, ss_b=ss_b, mi_b=mi_b, gm=gm,
+                     gl0=gl0, glob=glob, mi_g=mi_g, fu1=fu1, context=context, edge_f=edge_f, stages=stages)
         return out, (c if save else None)
 
     def head_bwd(self, c, dpreds: List[Optional[Tensor]], dedge: Optional[Tensor], dextra: Optional[dict] = None):
@@ -592,22 +603,18 @@ class Engine:
         d_e0 = self.bn_bwd(c["bn_e"], d_context)
         d_fu1 = self.lin_bwd("context.expand.0", d_e0, c["fu1"], bias=False)
         d_fu0 = self.bn_bwd(c["bn_u"], d_fu1)
-        d_brs, d_glob = ops.easpp_fuse_bwd(d_fu0, c["brs"], c["glob"], P["context.fusion.0.weight"].view(128, 5),
-                                           G("context.fusion.0.weight").view(128, 5), B, HW, 128)
-        d_gl0 = self.bn_bwd(c["bn_g"], d_glob)                                   # fp32 [B,128]
-        ops.gemm_tn(d_gl0, c["gm"], G("context.global_branch.1.weight").view(128, 128))
-        wg_t = P["context.global_branch.1.weight"].view(128, 128).t().contiguous()
-        d_gm = ops.gemm_nt(d_gl0, wg_t)                                            # [B,128] fp32
-        d_r1 = None
-        for i, dil in enumerate(EASPP_RATES):
-            d_d = self.bn_bwd(c["bn_b"][i], d_brs[i])
-            wd = P[f"context.branches.{i}.0.weight"].view(128, 9)
-            ops.dwconv3x3_wgrad(d_d, c["r1"], G(f"context.branches.{i}.0.weight").view(128, 9), B, h, w, 128, dil)
-            dx = ops.dwconv3x3(d_d, wd, B, h, w, 128, dil, flip=True)
-            d_r1 = dx if d_r1 is None else ops.add(d_r1, dx)
-        # global-average-pool adjoint: + d_gm[b][c] / HW on every pixel (scale = 1 -> chan_scale_bwd with ones)
-        ones = torch.ones((B, 128), dtype=torch.float32, device=dev)
-        d_r1 = ops.chan_scale_bwd(d_r1, ones, d_gm, B, HW, 128)
+        # fusion conv + branch BatchNorms + global branch + depth-wise convs, branch-batched (mirrors head_fwd)
+        wf, dwf = P["context.fusion.0.weight"].view(640), G("context.fusion.0.weight").view(640)
+        S = ops.gap_sum(d_fu0, B, HW, 128)
+        gn = "context.global_branch.2."
+        gadd = ops.easpp_global_bwd(S, c["glob"], c["gl0"], c["gm"], wf, P["context.global_branch.1.weight"].view(128, 128), P[gn + "weight"],
+                                    c["mi_g"], dwf, G("context.global_branch.1.weight").view(128, 128), G(gn + "weight"), G(gn + "bias"), B, 128, HW)
+        bnn = [f"context.branches.{i}.1." for i in range(4)]
+        d_dcat = ops.easpp_fuse_bn_bwd(d_fu0, c["dcat"], wf, c["ss_b"], c["mi_b"], [P[n + "weight"] for n in bnn], [G(n + "weight") for n in bnn],
+                                       [G(n + "bias") for n in bnn], dwf, B, HW, 128)
+        wd4 = [P[f"context.branches.{i}.0.weight"].view(128, 9) for i in range(4)]
+        ops.dwconv4_wgrad(d_dcat, c["r1"], EASPP_RATES, [G(f"context.branches.{i}.0.weight").view(128, 9) for i in range(4)], B, h, w, 128)
+        d_r1 = ops.dwconv4_dgrad(d_dcat, wd4, EASPP_RATES, gadd, B, h, w, 128)
         d_r0 = self.bn_bwd(c["bn_r"], d_r1)
         d_fused = self.lin_bwd("context.reduce.0", d_r0, c["fused"], bias=False)
         if dextra and dextra.get("fused") is not None:

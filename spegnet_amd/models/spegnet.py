@@ -18,6 +18,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .engine import Engine
 from .params import BUFFER_KINDS, HIERA_CONFIGS, ParamTree, build_tree, param_specs
 
@@ -84,8 +85,9 @@ class _SpegnetFn(torch.autograd.Function):
     def forward(ctx, model, x, hook):
         eng = model.engine
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward (no host-side zero checks)
-        feats, tctx = eng.trunk_fwd(x, True, True)
-        out, hctx = eng.head_fwd(feats[1:4], True, True)
+        with ops.cu_budget(model.cu_budget):
+            feats, tctx = eng.trunk_fwd(x, True, True)
+            out, hctx = eng.head_fwd(feats[1:4], True, True)
         ctx.model, ctx.tctx, ctx.hctx = model, tctx, hctx
         ctx.feat_shapes = [f.shape for f in feats]
         p = out["predictions"]
@@ -96,8 +98,9 @@ class _SpegnetFn(torch.autograd.Function):
         model = ctx.model
         eng = model.engine
         extra = {k: v for k, v in (("context", gc), ("fused", gf), ("edge_features", gef)) if v is not None} or None
-        d = eng.head_bwd(ctx.hctx, [g1, g2, g3], ge, extra)
-        eng.trunk_bwd(ctx.tctx, [None] + d)
+        with ops.cu_budget(model.cu_budget):   # (runs on autograd's thread: the budget travels with the model, not with a thread)
+            d = eng.head_bwd(ctx.hctx, [g1, g2, g3], ge, extra)
+            eng.trunk_bwd(ctx.tctx, [None] + d)
         ctx.tctx = ctx.hctx = None
         if model._post_backward is not None:
             model._post_backward()
@@ -133,6 +136,7 @@ class SPEGNet(nn.Module):
         self._param_version = 0
         self._post_backward = None
         self._hook = None
+        self.cu_budget = 0     # CUs the GEMM grids of this model's eager forward / backward are sized for (0 = all)
         ckpt = enc_cfg.get('checkpoint_path')
         if ckpt and os.path.exists(ckpt):
             self.load_encoder_checkpoint(ckpt)

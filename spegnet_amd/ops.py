@@ -158,7 +158,7 @@ def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = ACT_
     tag = "bf16" if x.dtype == torch.bfloat16 else "f32"
     with _prof(f"gemm_nt<{tag},{'conv3x3' if conv else 'dense'}>", "mfma", 2.0 * M * N * K):
         _lib.call("spg_gemm_nt", dcode(x), _p(_c(x)), _p(_c(w)), _p(_c(out)), _p(preact_out), _p(bias), _p(residual),
-                  _p(gelu_h), M, N, K, ldx, N, act, 1 if conv else 0, B, H, W, Ci, _stream())
+                  _p(gelu_h), M, N, K, ldx, N, act, 1 if conv else 0, B, H, W, Ci, cu_budget_now(), _stream())
     return out
 
 
@@ -189,12 +189,35 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
     tag = "bf16" if x.dtype == torch.bfloat16 else "f32"
     with _prof(f"gemm_tn<{tag},{'conv3x3' if conv else 'dense'}> (+reduce)", "mfma", 2.0 * M * N * K):
         _lib.call("spg_gemm_tn", dcode(x), _p(_c(dy)), _p(_c(x)), dw.data_ptr(), _p(dbias), _p(ws), wsb, M, N, K, N, ldx, ldw,
-                  1 if conv else 0, B, H, W, Ci, _stream())
+                  1 if conv else 0, B, H, W, Ci, cu_budget_now(), _stream())
+
+
+# CUs the persistent GEMM grids are sized for (0 = all): a per-call argument of the C ABI; this thread-local only carries the caller's
+# choice (the multi-GPU trainer lowers it around the graph segments that run beside a collective) down to the calls made inside it.
+import contextlib
+import threading
+
+_TLS = threading.local()
+
+
+def cu_budget_now() -> int:
+    return getattr(_TLS, "cu_budget", 0)
+
+
+@contextlib.contextmanager
+def cu_budget(n: int):
+    """with ops.cu_budget(240): ... -- GEMM launches inside size their grids for n CUs (restored on exit, also on exceptions)."""
+    prev = cu_budget_now()
+    _TLS.cu_budget = int(n)
+    try:
+        yield
+    finally:
+        _TLS.cu_budget = prev
 
 
 def set_cu_budget(n: int) -> None:
-    """CUs the persistent GEMM grids of the following launches are sized for (0 = all); see spg_set_cu_budget."""
-    _lib.call("spg_set_cu_budget", int(n))
+    """Sets this thread's CU budget until changed again (prefer the cu_budget() context manager)."""
+    _TLS.cu_budget = int(n)
 
 
 TN_GROUP_MAX = 8
@@ -230,7 +253,7 @@ def gemm_tn_group(jobs, defer: Optional[list] = None) -> None:
             with _prof("gemm_tn_group<bf16> (one trunk block's wgrads)", "mfma", sum(2.0 * M * j[4] * j[5] for j in part)):
                 _lib.call("spg_gemm_tn_group", SPG_BF16, n, P(*[_p(j[0]) for j in part]), P(*[_p(j[1]) for j in part]),
                           P(*[_p(j[2]) for j in part]), P(*[_p(j[3]) for j in part]), M, Ns, Ks, Ns, Ks, Ks, _p(ws), wsb,
-                          ctypes.addressof(desc) if desc is not None else None, _stream())
+                          ctypes.addressof(desc) if desc is not None else None, cu_budget_now(), _stream())
             if defer is not None:
                 defer.append((desc, ws))
 
@@ -631,3 +654,87 @@ def cfi_combine(y2: Tensor, y3: Tensor, y4: Tensor, B: int, H: int, W: int, h3: 
     with _prof("cfi_combine", "hbm", _nb(y2, y3, y4, out)):
         _lib.call("spg_cfi_combine", dcode(y2), _p(_c(y2)), _p(_c(y3)), _p(_c(y4)), _p(out), B, H, W, h3, w3, h4, w4, C, _stream())
     return out
+
+
+# ---- e-ASPP middle, branch-batched (csrc/easpp.hip) ---------------------------------------------------------------------------
+def _p4(ts):
+    import ctypes
+    return (ctypes.c_void_p * 4)(*[_p(t) for t in ts])
+
+
+def _i4(vs):
+    import ctypes
+    return (ctypes.c_int * 4)(*[int(v) for v in vs])
+
+
+def dwconv4(x: Tensor, w4, dil4, B: int, H: int, W: int, C: int) -> Tensor:
+    """the four dilated depth-wise 3x3 branches in one launch -> dcat [B*H*W, 4C] (branch-major concat order)"""
+    dcat = torch.empty((B * H * W, 4 * C), dtype=x.dtype, device=x.device)
+    with _prof("dwconv4 (4 dilated depth-wise 3x3)", "hbm", _nb(x, dcat)):
+        _lib.call("spg_dwconv4", dcode(x), _p(_c(x)), _p4([f32(w) for w in w4]), _i4(dil4), _p(dcat), B, H, W, C, _stream())
+    return dcat
+
+
+def dwconv4_dgrad(dy: Tensor, w4, dil4, gadd: Optional[Tensor], B: int, H: int, W: int, C: int) -> Tensor:
+    dx = torch.empty((B * H * W, C), dtype=dy.dtype, device=dy.device)
+    with _prof("dwconv4_dgrad (+GAP adjoint)", "hbm", _nb(dy, dx)):
+        _lib.call("spg_dwconv4_dgrad", dcode(dy), _p(_c(dy)), _p4([f32(w) for w in w4]), _i4(dil4), _p(gadd), _p(dx), B, H, W, C, _stream())
+    return dx
+
+
+def dwconv4_wgrad(dy: Tensor, x: Tensor, dil4, dw4, B: int, H: int, W: int, C: int) -> None:
+    n = 4 * 64 * 9 * C
+    ws = red_scratch(x.device, n)
+    with _prof("dwconv4_wgrad", "hbm", _nb(dy, x)):
+        _lib.call("spg_dwconv4_wgrad", dcode(x), _p(_c(dy)), _p(_c(x)), _i4(dil4), _p4([f32(w) for w in dw4]), B, H, W, C, _p(ws), n,
+                  red_counters(x.device, 4), _stream())
+
+
+def bn_stats_finalize4(x: Tensor, C: int, gamma4, beta4, rmean4, rvar4, nbt4, eps: float = 1e-5, momentum: float = 0.1):
+    """batch statistics + finalize of FOUR BatchNorms of C/4 channels each over one [M, C] tensor, one launch"""
+    M = x.numel() // C
+    buf = torch.empty(6 * C, dtype=torch.float32, device=x.device)
+    stats, ss, mi = buf[:2 * C], buf[2 * C:4 * C], buf[4 * C:]
+    ws, n, cnt = _red(x, C, 0)
+    with _prof("bn_stats_finalize", "hbm", _nb(x)):
+        _lib.call("spg_bn_stats_finalize4", dcode(x), _p(_c(x)), _p(stats), _p4(gamma4), _p4(beta4), _p4(rmean4) if rmean4 else None,
+                  _p4(rvar4) if rvar4 else None, _p4(nbt4) if nbt4 else None, _p(ss), _p(mi), M, C, eps, momentum, _p(ws), n, cnt, _stream())
+    return ss, mi
+
+
+def easpp_fuse_bn(dcat: Tensor, ss: Tensor, glob: Tensor, w: Tensor, B: int, HW: int, C: int) -> Tensor:
+    y = torch.empty((B * HW, C), dtype=dcat.dtype, device=dcat.device)
+    with _prof("easpp_fuse_bn (branch BN+ReLU + grouped 1x1)", "hbm", _nb(dcat, y)):
+        _lib.call("spg_easpp_fuse_bn", dcode(dcat), _p(_c(dcat)), _p(ss), _p(f32(glob)), _p(f32(w)), _p(y), B, HW, C, _stream())
+    return y
+
+
+def easpp_fuse_bn_bwd(dfu: Tensor, dcat: Tensor, w: Tensor, ss: Tensor, mi: Tensor, gamma4, dgamma4, dbeta4, dw: Tensor, B: int, HW: int, C: int) -> Tensor:
+    lib, dt = _lib.load(), dcode(dcat)
+    n = lib.spg_easpp_fuse_bn_bwd_workspace_floats(dt, C)
+    ws = red_scratch(dcat.device, n)
+    sums = torch.empty(12 * C, dtype=torch.float32, device=dcat.device)
+    ddcat = torch.empty_like(dcat)
+    with _prof("easpp_fuse_bn_bwd (reduce + apply)", "hbm", 2 * _nb(dcat, dfu) + _nb(ddcat)):
+        _lib.call("spg_easpp_fuse_bn_bwd", dt, _p(_c(dfu)), _p(_c(dcat)), _p(f32(w)), _p(ss), _p(mi), _p4(gamma4), _p4(dgamma4), _p4(dbeta4),
+                  _p(sums), _p(ddcat), _p(f32(dw)), B, HW, C, _p(ws), n, red_counters(dcat.device, lib.spg_easpp_fuse_bn_bwd_counters(dt, C)), _stream())
+    return ddcat
+
+
+def easpp_global_fwd(gsum: Tensor, Wg: Tensor, gamma: Tensor, beta: Tensor, rmean, rvar, nbt, B: int, C: int, HW: int, training: bool,
+                     eps: float = 1e-5, momentum: float = 0.1):
+    """returns (gm, gl0, glob, ss, mi): mean, pre-BN 1x1 output, activated global features [B,C], BN scale/shift and mean/invstd"""
+    buf = torch.empty(3 * B * C + 4 * C, dtype=torch.float32, device=gsum.device)
+    gm, gl0, glob = buf[:B * C].view(B, C), buf[B * C:2 * B * C].view(B, C), buf[2 * B * C:3 * B * C].view(B, C)
+    ss, mi = buf[3 * B * C:3 * B * C + 2 * C], buf[3 * B * C + 2 * C:]
+    _lib.call("spg_easpp_global_fwd", _p(f32(gsum)), _p(f32(Wg)), _p(f32(gamma)), _p(f32(beta)), _p(rmean), _p(rvar), _p(nbt), _p(gm), _p(gl0),
+              _p(glob), _p(ss), _p(mi), B, C, HW, eps, momentum, 1 if training else 0, _stream())
+    return gm, gl0, glob, ss, mi
+
+
+def easpp_global_bwd(S: Tensor, glob: Tensor, gl0: Tensor, gm: Tensor, wf: Tensor, Wg: Tensor, gamma: Tensor, mi: Tensor, dwf: Tensor, dWg: Tensor,
+                     dgamma: Tensor, dbeta: Tensor, B: int, C: int, HW: int, training: bool = True) -> Tensor:
+    gadd = torch.empty((B, C), dtype=torch.float32, device=S.device)
+    _lib.call("spg_easpp_global_bwd", _p(f32(S)), _p(glob), _p(gl0), _p(gm), _p(f32(wf)), _p(f32(Wg)), _p(f32(gamma)), _p(mi), _p(f32(dwf)),
+              _p(f32(dWg)), _p(f32(dgamma)), _p(f32(dbeta)), _p(gadd), B, C, HW, 1 if training else 0, _stream())
+    return gadd

@@ -62,6 +62,6 @@ def test_ctypes_signatures_match_header():
 def test_bad_arguments_fail_loudly():
     from spegnet_amd import _lib
     with pytest.raises(RuntimeError, match="K=.*multiple"):
-        _lib.call("spg_gemm_nt", _lib.SPG_BF16, None, None, None, None, None, None, None, 8, 8, 7, 8, 8, 0, 0, 0, 0, 0, 0, None)
+        _lib.call("spg_gemm_nt", _lib.SPG_BF16, None, None, None, None, None, None, None, 8, 8, 7, 8, 8, 0, 0, 0, 0, 0, 0, 0, None)
     with pytest.raises(RuntimeError, match="unsupported head_dim"):
         _lib.call("spg_attn_fwd", _lib.SPG_F32, None, None, None, None, None, 1, 8, 8, 1, 24, 8, None)

@@ -616,6 +616,65 @@ def test_bn_bwd_head(ops, dt, M, C, with_next):
     assert torch.equal(dx, dx2), "deterministic reduction: identical inputs, identical dx"
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_easpp_middle_branch_batched(ops, dt):
+    """The branch-batched e-ASPP middle (dwconv4 -> BN statistics of the 4 branches in one reduction -> global branch kernel -> grouped 1x1
+    with the branch BN + ReLU folded in) and its backward against torch autograd of the reference formulation
+    (feature_integration.py:397-412: 4 x [dilated depth-wise conv, BN, ReLU], [GAP, 1x1, BN, ReLU, broadcast], cat, grouped 1x1)."""
+    B, h, w, C = 4, 10, 12, 32
+    rates = (1, 2, 3, 5)
+    HW = h * w
+    r1 = rnd(B, h, w, C, seed=1).abs().to(dt)
+    wd = [rnd(C, 9, seed=10 + i) * 0.3 for i in range(4)]
+    gb = [(1 + 0.1 * rnd(C, seed=20 + i), 0.1 * rnd(C, seed=30 + i)) for i in range(4)]
+    Wg = rnd(C, C, seed=40) * 0.2
+    gg, bg = 1 + 0.1 * rnd(C, seed=41), 0.1 * rnd(C, seed=42)
+    wf = rnd(C, 5, seed=43) * 0.4
+    dy = rnd(B * HW, C, seed=44).to(dt)
+    # ---- torch reference (fp32, from the same rounded inputs)
+    leaves = [r1.float().clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in wd] + \
+             [t.clone().requires_grad_(True) for pair in gb for t in pair] + [t.clone().requires_grad_(True) for t in (Wg, gg, bg, wf)]
+    x_t, wd_t, gb_t = leaves[0], leaves[1:5], leaves[5:13]
+    Wg_t, gg_t, bg_t, wf_t = leaves[13:]
+    xn = x_t.permute(0, 3, 1, 2)
+    brs = []
+    for i, d in enumerate(rates):
+        z = F.conv2d(xn, wd_t[i].view(C, 1, 3, 3), padding=d, dilation=d, groups=C)
+        brs.append(F.relu(F.batch_norm(z, None, None, gb_t[2 * i], gb_t[2 * i + 1], True, 0.1, 1e-5)))
+    g0 = F.conv2d(xn.mean((2, 3), keepdim=True), Wg_t.view(C, C, 1, 1))
+    g1 = F.relu(F.batch_norm(g0, None, None, gg_t, bg_t, True, 0.1, 1e-5)).expand(B, C, h, w)
+    fu = F.conv2d(torch.cat(brs + [g1], 1), wf_t.view(C, 5, 1, 1), groups=C).permute(0, 2, 3, 1).reshape(B * HW, C)
+    (fu * dy.float()).sum().backward()
+    # ---- HIP path
+    dcat = ops.dwconv4(r1, wd, rates, B, h, w, C)
+    ss_b, mi_b = ops.bn_stats_finalize4(dcat, 4 * C, [p[0] for p in gb], [p[1] for p in gb], None, None, None)
+    gs = ops.gap_sum(r1, B, HW, C)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    gm, gl0, glob, ss_g, mi_g = ops.easpp_global_fwd(gs, Wg, gg, bg, rm, rv, nbt, B, C, HW, True)
+    fu0 = ops.easpp_fuse_bn(dcat, ss_b, glob, wf, B, HW, C)
+    check(fu0.float(), fu.detach(), tol(dt, 3e-4, 3e-2), "e-ASPP middle forward")   # (BatchNorm over B = 4 values per channel amplifies rounding)
+    assert int(nbt) == 1
+    z = lambda *sh: torch.zeros(*sh, device="cuda")
+    dwf, dWg, dgg, dbg = z(C * 5), z(C, C), z(C), z(C)
+    dgam, dbet, dwd = [z(C) for _ in range(4)], [z(C) for _ in range(4)], [z(C, 9) for _ in range(4)]
+    S = ops.gap_sum(dy, B, HW, C)
+    gadd = ops.easpp_global_bwd(S, glob, gl0, gm, wf.view(-1), Wg, gg, mi_g, dwf, dWg, dgg, dbg, B, C, HW)
+    d_dcat = ops.easpp_fuse_bn_bwd(dy, dcat, wf.view(-1), ss_b, mi_b, [p[0] for p in gb], dgam, dbet, dwf, B, HW, C)
+    ops.dwconv4_wgrad(d_dcat, r1, rates, dwd, B, h, w, C)
+    d_r1 = ops.dwconv4_dgrad(d_dcat, wd, rates, gadd, B, h, w, C)
+    t = tol(dt, 2e-3, 5e-2)
+    check(d_r1.float().view(B, h, w, C), x_t.grad, t, "d r1")
+    check(dwf.view(C, 5), wf_t.grad, t, "d fusion weight")
+    check(dWg, Wg_t.grad, t, "d global 1x1 weight")
+    check(dgg, gg_t.grad, t, "d global BN gamma")
+    check(dbg, bg_t.grad, t, "d global BN beta")
+    for i in range(4):
+        check(dwd[i], wd_t[i].grad, t, f"d depth-wise weight {i}")
+        check(dgam[i], gb_t[2 * i].grad, t, f"d branch BN gamma {i}")
+        check(dbet[i], gb_t[2 * i + 1].grad, t, f"d branch BN beta {i}")
+
+
 # ------------------------------------------------------------------------------------------- fused CODLoss
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("case", ["rand", "zeros", "ones"])
