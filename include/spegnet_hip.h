@@ -116,9 +116,9 @@ int spg_maxpool2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int
                      spg_stream_t stream);
 int spg_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int ldc,
                      int c0, spg_stream_t stream);
-/* patch embedding input gather: image f32/T NCHW [B,3,S,S] -> im2col rows [B*(S/4)^2, Kpad] (k = c*49+ky*7+kx,
+/* patch embedding input gather: image f32 NCHW [B,3,H,W] (H, W % 4 == 0) -> im2col rows [B*(H/4)*(W/4), Kpad] (k = c*49+ky*7+kx,
  * zero padded to Kpad), so that patch-embed is a spg_gemm_nt; pos-embed add is the GEMM's residual.          */
-int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int S, int Kpad, spg_stream_t stream);
+int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int H, int W, int Kpad, spg_stream_t stream);
 /* device input pipeline (reference: CODImageProcessor.process_image, utils/image_processor.py:118-131): uint8 HWC [H,W,3] (device) ->
  * float / 255 -> antialiased bilinear resize to OH x OW (ATen _upsample_bilinear2d_aa, align_corners = false) -> (v - mean) / std,
  * written as f32 CHW [3,OH,OW].  mean3 / std3 are HOST arrays of three floats.                                                   */

@@ -35,7 +35,7 @@ SIGNATURES = {
     "spg_attn_bwd": "ippppppppp" "p" "iiiiiip",
     "spg_maxpool2_fwd": "ippp" "iiiiiip",
     "spg_maxpool2_bwd": "ippp" "iiiiiip",
-    "spg_patch_im2col": "ipp" "iiip",
+    "spg_patch_im2col": "ipp" "iiiip",
     "spg_preprocess_image": "pp" "iiii" "ppp",
     "spg_preprocess_batch": "pppp" "p" "iii" "ppp",
     "spg_colsum": "ipp" "iiii" "plp" "p",

@@ -190,22 +190,22 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
   }
 }
 
-// patch-embed im2col: img f32 NCHW [B,3,S,S] -> cols T [B*(S/4)^2][Kpad], k = c*49 + ky*7 + kx (conv 7x7 s4 p3)
+// patch-embed im2col: img f32 NCHW [B,3,H,W] -> cols T [B*(H/4)*(W/4)][Kpad], k = c*49 + ky*7 + kx (conv 7x7 s4 p3)
 template <typename T>
-__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int S, int Kpad) {
-  const int So = S / 4;
-  const long total = (long)B * So * So * Kpad;
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H, int W, int Kpad) {
+  const int Ho = H / 4, Wo = W / 4;
+  const long total = (long)B * Ho * Wo * Kpad;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int k = (int)(i % Kpad);
     long p = i / Kpad;
-    const int ox = (int)(p % So); p /= So;
-    const int oy = (int)(p % So);
-    const int b = (int)(p / So);
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
     float v = 0.f;
     if (k < 147) {
       const int c = k / 49, r = k - c * 49, ky = r / 7, kx = r - ky * 7;
       const int iy = oy * 4 + ky - 3, ix = ox * 4 + kx - 3;
-      if ((unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S) v = img[(((long)b * 3 + c) * S + iy) * S + ix];
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = img[(((long)b * 3 + c) * H + iy) * W + ix];
     }
     ST<T>::st(cols + i, v);
   }
@@ -644,11 +644,11 @@ extern "C" int spg_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, v
   else hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, idx, (float*)dx, B, H, W, C, ldc, c0);
   return check_launch("maxpool2_bwd");
 }
-extern "C" int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int S, int Kpad, spg_stream_t stream) {
-  SPG_REQUIRE(S % 4 == 0 && Kpad >= 147, "patch_im2col: S=%d Kpad=%d", S, Kpad);
-  const int grid = ew_grid((long)B * (S / 4) * (S / 4) * Kpad);
-  if (dtype == SPG_BF16) hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, S, Kpad);
-  else hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, S, Kpad);
+extern "C" int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int H, int W, int Kpad, spg_stream_t stream) {
+  SPG_REQUIRE(H % 4 == 0 && W % 4 == 0 && Kpad >= 147, "patch_im2col: H=%d W=%d Kpad=%d", H, W, Kpad);
+  const int grid = ew_grid((long)B * (H / 4) * (W / 4) * Kpad);
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, H, W, Kpad);
+  else hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, H, W, Kpad);
   return check_launch("patch_im2col");
 }
 // ---------------------------------------------------------------------------------------------------

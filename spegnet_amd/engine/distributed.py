@@ -56,8 +56,12 @@ def make_buckets(unit_ends: List[int], bucket_elems: int) -> List[Tuple[int, int
 
 
 class GradSync:
+    """Gradient all-reduce over the flat arena.  Payload bf16 by default (431 MB instead of 862 MB per step over xGMI; the
+    sum of <= 8 ranks is formed in bf16 by RCCL, the fp32 gradient is rounded once going in and widened coming out); compress_bf16=False
+    keeps fp32 on the wire."""
+
     def __init__(self, grad_flat: torch.Tensor, unit_ends: List[int], bucket_mb: float = 48.0, group=None,
-                 compress_bf16: bool = False):
+                 compress_bf16: bool = True):
         self.g = grad_flat
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
@@ -82,22 +86,28 @@ class GradSync:
             self._next += 1
             self._launch(s, e)
 
-    def _launch(self, s: int, e: int):
+    def reduce_range(self, s: int, e: int):
+        """all-reduce (sum) of g[s:e] on the CURRENT stream; bf16 payload through a persistent staging buffer (HIP cast kernels)"""
         view = self.g[s:e]
+        if self.compress and self.cuda and (e - s) % 8 == 0:
+            from .. import _lib
+            tmp = self._tmp.get((s, e))
+            if tmp is None:
+                tmp = self._tmp[(s, e)] = torch.empty(e - s, dtype=torch.bfloat16, device=view.device)
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.call("spg_cast_bf16", view.data_ptr(), tmp.data_ptr(), e - s, 0, st)
+            dist.all_reduce(tmp, group=self.group)
+            _lib.call("spg_cast_bf16", view.data_ptr(), tmp.data_ptr(), e - s, 1, st)
+        else:
+            dist.all_reduce(view, group=self.group)
+
+    def _launch(self, s: int, e: int):
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                if self.compress:
-                    tmp = self._tmp.get((s, e))
-                    if tmp is None:
-                        tmp = self._tmp[(s, e)] = torch.empty(e - s, dtype=torch.bfloat16, device=view.device)
-                    tmp.copy_(view)
-                    dist.all_reduce(tmp, group=self.group)
-                    view.copy_(tmp)
-                else:
-                    dist.all_reduce(view, group=self.group)
+                self.reduce_range(s, e)
         else:
-            self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
+            self._works.append(dist.all_reduce(self.g[s:e], group=self.group, async_op=True))
 
     def finish(self):
         """All buckets launched and complete w.r.t. the current stream; returns the grad scale 1/world."""

@@ -100,11 +100,70 @@ class Predictor:
         original = np.array(Image.open(image_path).convert('RGB'))
         return seg_np, edge_np, original
 
+    def _forward_batch(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """One eval-mode forward of [n,3,S,S].  Full batches (n == batch_size) replay a hipGraph captured on first use (BASELINE config #3:
+        no per-kernel launch cost); a shorter last batch runs eagerly."""
+        n = x.shape[0]
+        if n != self.batch_size or self.batch_size < 2:
+            with torch.no_grad():
+                return self.model(x)
+        if getattr(self, "_graph", None) is None or self._static_x.shape != x.shape:
+            with torch.no_grad():
+                self._static_x = x.clone()
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    self.model(self._static_x)                 # warm-up off the capture stream (allocator, lazy init)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._static_out = self.model(self._static_x)
+        self._static_x.copy_(x)
+        self._graph.replay()
+        return self._static_out
+
     def predict_batch(self, image_paths: List[str], output_size: Optional[Tuple[int, int]] = None) -> Dict:
+        """Reference engine/predictor.py:376-430 walks the list in chunks of batch_size and still predicts image by image; here a chunk
+        IS a batch: the decoded uint8 images are uploaded together, resized / normalised by one batched HIP launch
+        (ops.preprocess_batch), and go through ONE forward (a captured hipGraph for full batches).  Per-image results are those of
+        predict_single (eval-mode BatchNorm: no cross-sample coupling)."""
+        from .. import ops
         self.result_manager.log_message(f"Starting batch prediction of {len(image_paths)} images with batch size {self.batch_size}")
-        for p in image_paths:
-            seg, edge, orig = self.predict_single(p, output_size)
-            self.result_manager.save_prediction(Path(p).name, seg, edge, orig)
+        ip = self.image_processor
+        mean, std = ip.norm_mean.flatten().tolist(), ip.norm_std.flatten().tolist()
+        bs = max(int(self.batch_size or 1), 1)
+        for i in range(0, len(image_paths), bs):
+            paths = image_paths[i:i + bs]
+            t0 = time.time()
+            originals = []
+            for p in paths:
+                try:
+                    originals.append(np.array(Image.open(p).convert('RGB')))
+                except Exception as e:
+                    raise RuntimeError(f"Failed to process image {p}: {e}")
+            sizes = [(o.shape[0], o.shape[1]) for o in originals]
+            offs, off = [], 0
+            for h, w in sizes:
+                offs.append(off)
+                off += (h * w * 3 + 255) // 256 * 256
+            host = torch.empty(off, dtype=torch.uint8).pin_memory()
+            for o, k in zip(originals, offs):
+                host[k:k + o.size].copy_(torch.from_numpy(o).reshape(-1))
+            x = ops.preprocess_batch(host.to(self.device, non_blocking=True), offs, sizes, ip.target_size, mean, std)
+            self.result_manager.update_timing('preprocessing', time.time() - t0)
+            t0 = time.time()
+            out = self._forward_batch(x)
+            torch.cuda.synchronize(self.device)
+            self.result_manager.update_timing('inference', time.time() - t0)
+            t0 = time.time()
+            seg, edge = out['predictions'][-1].float(), out['edge'].float()
+            if output_size:
+                seg = F.interpolate(seg, size=output_size, mode='bilinear', align_corners=False)
+                edge = F.interpolate(edge, size=output_size, mode='bilinear', align_corners=False)
+            seg_np, edge_np = seg.sigmoid().squeeze(1).cpu().numpy(), edge.sigmoid().squeeze(1).cpu().numpy()
+            self.result_manager.update_timing('postprocessing', time.time() - t0)
+            for j, p in enumerate(paths):
+                self.result_manager.save_prediction(Path(p).name, seg_np[j], edge_np[j], originals[j])
         return self.result_manager.summarize()
 
     def predict_directory(self, input_dir: str, output_size: Optional[Tuple[int, int]] = None,

@@ -50,7 +50,7 @@ class TrainStep:
         self.graph = self.graph_b = None
         self.segments = None
         self.comm_stream = None
-        self.n_segments = 4
+        self.n_segments = 8     # graph segments of the backward (the all-reduce of each finished range overlaps the next segment)
         self.static = None
         self.losses = None
         self.world = sync.world if sync is not None else 1
@@ -82,8 +82,7 @@ class TrainStep:
         return losses
 
     def _allreduce_flat(self):
-        import torch.distributed as dist
-        dist.all_reduce(self.arena.g)
+        self.sync.reduce_range(0, self.arena.size)
 
     def _step_split(self, images, masks, edges):
         losses = self._fwd_bwd(images, masks, edges)
@@ -186,7 +185,7 @@ class TrainStep:
             self.comm_stream.wait_event(ev)
             if self.world > 1:
                 with torch.cuda.stream(self.comm_stream):
-                    dist.all_reduce(self.arena.g[start:end])
+                    self.sync.reduce_range(start, end)     # bf16 payload by default (GradSync)
             start = end
         main.wait_stream(self.comm_stream)
         self.graph_b.replay()
@@ -277,6 +276,7 @@ class TrainingMonitor:
         self.history.append({"epoch": epoch, "phase": phase, **m})
         self._sums, self._n = {}, 0
         if self.dir_manager is not None and hasattr(self.dir_manager, "run_dir"):
+            os.makedirs(str(self.dir_manager.run_dir), exist_ok=True)
             path = os.path.join(str(self.dir_manager.run_dir), "metrics.json")
             tmp = path + ".tmp"
             with open(tmp, "w") as f:
@@ -373,6 +373,13 @@ class Trainer:
                               for p in out['predictions']])
                 eds.append(F.interpolate(out['edge'][i:i + 1].float(), size=edges[i].shape[-2:], mode='bilinear', align_corners=False))
             metrics = self.criterion(predictions=preds, edge_pred=eds, masks=masks, edges=edges)
+            if not is_train:
+                # validation metrics on the device (reference engine/trainer.py:482-520 reads weighted_f / s_alpha / mae from them)
+                if getattr(self, "_metrics", None) is None:
+                    from ..utils.metrics import MetricsProcessor
+                    self._metrics = MetricsProcessor()
+                cod = self._metrics.compute_metrics([p[-1][0] for p in preds], masks, [e[0] for e in eds], edges)
+                metrics.update({k: torch.tensor(v) for k, v in cod.items()})
             if is_train:
                 self.arena.zero_grad()
                 metrics['loss'].backward()

@@ -313,8 +313,8 @@ class Engine:
     def trunk_fwd(self, img: Tensor, training: bool, save: bool):
         e = "encoder.encoder."
         P, W, T = self.P, self.W, self.dtype
-        B, _, S, S2 = img.shape
-        h = w = S // 4
+        B, _, Hi, Wi = img.shape
+        h, w = Hi // 4, Wi // 4
         D = self.cfg["embed_dim"]
         cols = ops.patch_im2col(img.float().contiguous(), T, PATCH_KPAD)
         basis = self.pos_basis(h, w, B)

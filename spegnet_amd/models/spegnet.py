@@ -71,8 +71,6 @@ def _check_input(x: torch.Tensor):
         raise ValueError(f"Expected 4D input (B,C,H,W), got {x.dim()}D")
     if any(s % 32 != 0 for s in x.shape[-2:]):
         raise ValueError("Input spatial dims must be divisible by 32")
-    if x.shape[-1] != x.shape[-2]:
-        raise ValueError("this build supports square inputs only")
     if not x.is_cuda:
         raise RuntimeError("spegnet_amd.SPEGNet runs only on an MI355X (HIP) device; there is no CPU fallback")
 

@@ -398,9 +398,9 @@ def maxpool2_bwd(dy: Tensor, idx: Tensor, dx: Tensor, B: int, H: int, W: int, C:
 
 
 def patch_im2col(img: Tensor, dtype: torch.dtype, kpad: int) -> Tensor:
-    B, _, S, _ = img.shape
-    cols = torch.empty((B * (S // 4) ** 2, kpad), dtype=dtype, device=img.device)
-    _lib.call("spg_patch_im2col", dcode(cols), _p(f32(img)), _p(cols), B, S, kpad, _stream())
+    B, _, H, W = img.shape
+    cols = torch.empty((B * (H // 4) * (W // 4), kpad), dtype=dtype, device=img.device)
+    _lib.call("spg_patch_im2col", dcode(cols), _p(f32(img)), _p(cols), B, H, W, kpad, _stream())
     return cols
 
 

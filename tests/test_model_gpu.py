@@ -431,7 +431,7 @@ def test_segmented_graph_step_equals_eager_step():
         res.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, gnorms))
         if seg:
             plan = step._plan
-            assert len(step.segments) == len(plan) == 4 and plan[-1][0] == 0 and plan[-1][2] == arena.size
+            assert len(step.segments) == len(plan) >= 4 and plan[-1][0] == 0 and plan[-1][2] == arena.size
             assert [p[2] for p in plan] == sorted(p[2] for p in plan)
     (l0, s0, g0), (l1, s1, g1) = res
     for a, b in zip(l0, l1):
