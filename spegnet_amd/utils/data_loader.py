@@ -141,9 +141,10 @@ class DeviceBatcher:
         self.dev = [torch.empty(max_bytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.copied = [None, None]      # event after the last H2D copy out of each staging buffer
         self.turn = 0
-        self._pending = None
 
-    def submit(self, images_u8: List[torch.Tensor]) -> None:
+    def submit(self, images_u8: List[torch.Tensor]):
+        """Queues upload + preprocess of one batch; returns the handle `result` takes (two batches may be in flight: the one being trained
+        on and the one prefetched behind it)."""
         from .. import ops
         k = self.turn
         self.turn ^= 1
@@ -166,13 +167,12 @@ class DeviceBatcher:
             out = ops.preprocess_batch(self.dev[k], offs, sizes, self.size, self.mean, self.std)
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        self._pending = (out, ev)
+        return out, ev
 
-    def result(self) -> torch.Tensor:
-        out, ev = self._pending
+    def result(self, handle) -> torch.Tensor:
+        out, ev = handle
         torch.cuda.current_stream(self.device).wait_event(ev)
         out.record_stream(torch.cuda.current_stream(self.device))
-        self._pending = None
         return out
 
 
@@ -185,8 +185,7 @@ def prefetch(loader, batcher: Optional[DeviceBatcher], device) -> Iterator[Dict]
         b = dict(b)
         with torch.cuda.stream(copy):
             if 'images_u8' in b:
-                batcher.submit(b.pop('images_u8'))
-                b['_images_pending'] = True
+                b['_images_pending'] = batcher.submit(b.pop('images_u8'))
             else:
                 b['images'] = b['images'].to(device, non_blocking=True)
             for k in ('masks', 'edges'):
@@ -198,8 +197,9 @@ def prefetch(loader, batcher: Optional[DeviceBatcher], device) -> Iterator[Dict]
 
     def finish(b, ev):
         torch.cuda.current_stream(device).wait_event(ev)
-        if b.pop('_images_pending', False):
-            b['images'] = batcher.result()
+        pending = b.pop('_images_pending', None)
+        if pending is not None:
+            b['images'] = batcher.result(pending)
         return b
 
     it = iter(loader)

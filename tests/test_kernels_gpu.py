@@ -642,6 +642,9 @@ def test_easpp_middle_branch_batched(ops, dt):
     brs = []
     for i, d in enumerate(rates):
         z = F.conv2d(xn, wd_t[i].view(C, 1, 3, 3), padding=d, dilation=d, groups=C)
+        # the depth-wise outputs are STORED in dt before BN + ReLU: model that rounding (straight-through), otherwise pixels whose BN(z)
+        # is within bf16 rounding of 0 flip their ReLU mask against the reference and whole gradient terms appear / disappear
+        z = z + (z.to(dt).float() - z).detach()
         brs.append(F.relu(F.batch_norm(z, None, None, gb_t[2 * i], gb_t[2 * i + 1], True, 0.1, 1e-5)))
     g0 = F.conv2d(xn.mean((2, 3), keepdim=True), Wg_t.view(C, C, 1, 1))
     g1 = F.relu(F.batch_norm(g0, None, None, gg_t, bg_t, True, 0.1, 1e-5)).expand(B, C, h, w)
@@ -666,14 +669,7 @@ def test_easpp_middle_branch_batched(ops, dt):
     ops.dwconv4_wgrad(d_dcat, r1, rates, dwd, B, h, w, C)
     d_r1 = ops.dwconv4_dgrad(d_dcat, wd, rates, gadd, B, h, w, C)
     t = tol(dt, 2e-3, 6e-2)
-    if dt == torch.float32:
-        check(d_r1.float().view(B, h, w, C), x_t.grad, t, "d r1")
-    else:
-        # bf16 storage rounds the depth-wise outputs before BN + ReLU: where BN(z) is within rounding of 0 the ReLU mask flips against
-        # the fp32 reference and that pixel's whole gradient appears/disappears in its 9 dgrad neighbours -- isolated points, so the
-        # bulk (99%) must meet the tolerance and the flipped points stay bounded
-        d = (d_r1.float().view(B, h, w, C) - x_t.grad).abs().flatten() / x_t.grad.abs().max()
-        assert float(d.kthvalue(int(0.99 * d.numel())).values) < t and float(d.max()) < 0.5, (float(d.max()),)
+    check(d_r1.float().view(B, h, w, C), x_t.grad, t, "d r1")
     check(dwf.view(C, 5), wf_t.grad, t, "d fusion weight")
     check(dWg, Wg_t.grad, t, "d global 1x1 weight")
     check(dgg, gg_t.grad, t, "d global BN gamma")
