@@ -284,7 +284,7 @@ def main():
             want = "gemm_nt<%s,dense>" % ("bf16" if args.dtype == "bf16" else "f32")
             dom = next(r for r in rows if r["kernel"] == want)
             traffic, src = committed_traffic(want)
-            roof = {"bound": "mfma", "kernel": "gemm_nt_pipe_kernel<%s,dense> (all dense gemm_nt launches: Linear / 1x1 conv fwd + dgrad)" % args.dtype,
+            roof = {"bound": "mfma", "kernel": "gemm_nt<%s,dense>: gemm_nt_pipe_kernel + gemm_nt_v3_kernel (all dense gemm_nt launches: Linear / 1x1 conv fwd + dgrad)" % args.dtype,
                     "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
                     "traffic_source": src, "launches": int(dom["launches_per_step"] * 2), "avg_launch_us": dom["avg_us"],
                     "event_bracket_us": round(bracket_s * 1e6, 2), "flop_per_launch_avg": dom["work_per_launch"],

@@ -55,11 +55,16 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
 def _build_dev(hipcc, verbose):
     objdir = os.path.join(HERE, "build", "dev")
     os.makedirs(objdir, exist_ok=True)
-    lib = os.path.join(HERE, "libspegnet_hip_dev.so")
+    extra = os.environ.get("SPG_DEV_FLAGS", "").split()        # e.g. "-DSPG_V3_KS=1 -DSPG_V3_NS=4" -> its own library name
+    tag = os.environ.get("SPG_DEV_TAG", "")
+    lib = os.path.join(HERE, f"libspegnet_hip_dev{tag}.so")
+    if tag:
+        objdir = os.path.join(objdir, tag.strip("_"))
+        os.makedirs(objdir, exist_ok=True)
     objs = []
     for src in [s_ for s_ in SOURCES if os.path.exists(os.path.join(CSRC, s_))]:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-DSPG_DEV_KERNELS", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + ["-DSPG_DEV_KERNELS"] + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

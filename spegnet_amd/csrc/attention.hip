@@ -729,8 +729,12 @@ template <typename T, int HD>
 static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
   using A = AC<T, HD>;
   const int nwin = p.B * p.nwy * p.nwx;
+#ifdef SPG_DEV_KERNELS   // A/B runs of tools/attn_bench.py only: the product library reads no environment variable
   static int use_res = -1;
   if (use_res < 0) { const char* e = getenv("SPG_ATTN"); use_res = (e && strcmp(e, "tiled") == 0) ? 0 : 1; }
+#else
+  constexpr int use_res = 1;
+#endif
   if constexpr (sizeof(T) == 2 && ResLds<T, HD>::BYTES <= 160 * 1024) {
     if (use_res && maxk > 65 && maxk <= RES_ROWS && maxq <= 256) {   // multi-tile windows only (stage 3, block 44)
       constexpr int LDS = ResLds<T, HD>::BYTES;

@@ -969,6 +969,248 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing no-op pieces
 }
 
+// LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS).  A template (on the pointer type) so that the device-only 16-byte form of the builtin is
+// checked only at instantiation: in a non-dependent statement hipcc's host pass fails the check silently and drops the kernel's stub.
+template <typename T>
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, T* lds, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt_v3: 4 waves (2 x 2), ONE 128 x (32 NB) tile per workgroup, TWO workgroups per CU.
+//
+// Why (measured on the persistent 8-wave kernel above, profiles/round2): its 32 x 16NB wave tile needs 0.75 ds_read_b128 per MFMA and
+// the LDS-DMA fill another 0.25, i.e. the LDS array (256 B/clk/CU, one b128 read per 16-cycle MFMA slot and SIMD) is saturated at
+// ~53 % MFMA occupancy, and the epilogue (~2.3 us per tile, 40 % of a K = 576 tile) runs with every wave of the CU out of the MFMA
+// pipe.  Here
+//   * a wave owns 64 (m) x 16 NB (n): (4 + NB) / (4 NB) = 0.5 reads per MFMA at NB = 4 (+ 0.25 fill);
+//   * a workgroup is 4 waves and NS x 16 KiB of LDS (NS = 4: 64 KiB), so two are resident per CU (2 waves per SIMD from DIFFERENT
+//     tiles): one tile's prologue / epilogue / barrier waits sit under the other tile's MFMAs, and the hardware dispatcher -- not a
+//     static persistent schedule -- balances tiles over CUs (grids that coexist with an RCCL kernel need no CU budget either);
+//   * K advances 32 per step (64-byte LDS rows, one MFMA k-block per stage) so that NS - 1 = 3 DMA groups (48 KiB per workgroup,
+//     96 KiB per CU) stay in flight inside the 80 KiB a workgroup may hold;
+//   * the epilogue needs no LDS transpose: W rows are PERMUTED on their way into LDS (row 16 ni + 4 q + e of a wave's W slice holds
+//     W[n0 + 32 (ni >> 1) + 8 q + 4 (ni & 1) + e]), so the accumulators (ni, ni + 1) of one m block hold 8 CONSECUTIVE output columns
+//     of one row: bias / residual / gelu_h are read and C / C2 written as 16-byte vectors straight from the accumulators, four
+//     lanes covering 64 contiguous bytes of a row.
+// LDS image: 64-byte rows; 16-byte chunk c of row r holds logical chunk c ^ (2 * ((r >> 3) & 1)) -- with the fixed lane groups of
+// ds_read_b128 ({0-3, 12-15, 20-27}, ...) the 16 rows x 4 chunks of a fragment read then fall on 16 distinct 4-bank groups.
+// Pipeline (step t = 32 of K): frags(t) are in registers; barrier; MFMAs(t) | ds_read frags(t+1) from slot (t+1) % NS | DMA group
+// t + NS into slot t % NS (whose fragments everybody has read: lgkmcnt(0) before the barrier).  Group t+1 must have landed at the
+// barrier: younger than it are NS - 2 groups, so the wait is vmcnt((NS - 2) * pieces); once the groups run out, vmcnt(0).
+// ------------------------------------------------------------------------------------------------
+template <int N_> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory"); }
+template <int N_> __device__ __forceinline__ void wait_vm_only() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// KS = MFMA k-blocks (32 of K) per LDS stage: 2 -> 128-byte rows, chunk c of row r holds logical chunk c ^ (r & 7) (the image of the
+// kernels above); 1 -> 64-byte rows, chunk c of row r holds c ^ (2 ((r >> 3) & 1)).  NS = stages.  (KS, NS) = (2, 2): 64 KiB, one DMA
+// group (32 KiB) in flight behind the stage being read; (1, 4): 64 KiB, three 16 KiB groups in flight, a barrier every 32 of K.
+template <bool CONV, int ACT, int NB, int KS, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
+                                                            NtEpi epi, PipeEpi pe, int M, int N, int K, int ldx, int ldc, ConvGeom g,
+                                                            int tiles_n, unsigned xbytes, unsigned wbytes) {
+  using T = bf16_t;
+  static_assert(NB == 4 || NB == 2, "accumulator pairs hold 8 consecutive columns");
+  static_assert(KS == 1 || KS == 2, "");
+  constexpr int RB = 64 * KS;               // LDS row bytes
+  constexpr int PR = 1024 / RB;             // rows per 1 KiB DMA piece
+  constexpr int BN_ = 32 * NB;
+  constexpr int STAGE = (BM + BN_) * RB;
+  constexpr int WROWS = BN_ / 4;            // W rows each wave fills per stage
+  constexpr int XP = 32 / PR, WP = WROWS / PR;
+  constexpr int NP = XP + WP;               // DMA pieces per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int nh = (K + 31) >> 5;             // 32-deep steps
+  const int nst = (nh + KS - 1) / KS;       // stages (DMA groups)
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN_;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, xbytes), wr = make_rsrc(W, wbytes);
+
+  // ---- fill roles: wave w moves X rows [32 w, 32 w + 32) and W rows [WROWS w, WROWS (w + 1)) of the stage image
+  const int lrow = KS == 2 ? lane >> 3 : lane >> 2;                                       // row within a piece
+  const int kch = KS == 2 ? ((lane & 7) ^ lrow) : ((lane & 3) ^ ((lane >> 5) << 1));     // logical 16-byte chunk this lane fetches
+  unsigned xoff[XP], woff[WP];
+  bool xin[XP], win[WP];
+  int py[XP], px[XP];
+#pragma unroll
+  for (int p = 0; p < XP; ++p) {
+    const int m = m0 + wave * 32 + p * PR + lrow;
+    xin[p] = m < M;
+    if constexpr (CONV) {
+      const int hw = g.H * g.W;
+      const int b = m / hw, rem = m - b * hw;
+      py[p] = rem / g.W; px[p] = rem - py[p] * g.W;
+      xoff[p] = (unsigned)m;
+    } else {
+      py[p] = 0; px[p] = 0;
+      xoff[p] = (unsigned)(((long)m * ldx + kch * 8) * 2);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < WP; ++p) {
+    const int i = wave * WROWS + p * PR + lrow;             // row of the W image
+    const int half = i / (16 * NB), l = i - half * (16 * NB), ni = l >> 4, j = l & 15;
+    const int n = n0 + half * (16 * NB) + (ni >> 1) * 32 + (j >> 2) * 8 + (ni & 1) * 4 + (j & 3);
+    win[p] = n < N;
+    woff[p] = (unsigned)(((long)n * K + kch * 8) * 2);
+  }
+  auto dma_piece = [&](int p, int gi, char* st) __attribute__((always_inline)) {   // piece p of DMA group (stage) gi
+    const int k0 = gi * (32 * KS) + kch * 8;
+    const bool kin = k0 < K;
+    if (p < XP) {
+      unsigned off;
+      if constexpr (CONV) off = x_chunk_off<T, true>((int)xoff[p], k0, ldx, g, py[p], px[p]);
+      else off = xoff[p] + (unsigned)gi * (unsigned)RB;
+      lds_dma16(xr, st + (wave * 32 + p * PR) * RB, (kin && xin[p]) ? off : OOB);
+    } else {
+      const int q_ = p - XP;
+      lds_dma16(wr, st + (BM + wave * WROWS + q_ * PR) * RB, (kin && win[q_]) ? woff[q_] + (unsigned)gi * (unsigned)RB : OOB);
+    }
+  };
+
+  f32x4 acc[NB][4];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r15 = lane & 15, q = lane >> 4;
+  // this lane's fragment chunk inside a 16-row block, for k-block 0 (k-block 1 of a 128-byte row: the same ^ 64)
+  const int fro = KS == 2 ? r15 * RB + ((q ^ (r15 & 7)) << 4) : r15 * RB + ((q ^ ((r15 >> 3) << 1)) << 4);
+  const int boff = (wm * 64) * RB + fro, aoff = (BM + wn * (16 * NB)) * RB + fro;
+  bf16x8_t fa0[NB], fb0[4], fa1[NB], fb1[4];
+  auto read_frag = [&](bf16x8_t* fa, bf16x8_t* fb, const char* st, int sub, int r) __attribute__((always_inline)) {
+    const int x = sub * 64;      // (only KS == 2 has sub == 1)
+    if (r < 4) fb[r] = *reinterpret_cast<const bf16x8_t*>(st + ((boff + r * 16 * RB) ^ x));   // order of first use: m blocks, then n blocks
+    else fa[r - 4] = *reinterpret_cast<const bf16x8_t*>(st + ((aoff + (r - 4) * 16 * RB) ^ x));
+  };
+  constexpr int NH = NB * 4, NR = NB + 4;   // MFMAs / fragment reads per step
+
+  // ---- prologue: groups 0 .. NS-1 in flight, group 0 landed, its k-block 0 fragments requested
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    if (i < nst) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dma_piece(p, i, smem + i * STAGE);
+    }
+  }
+  if (nst >= NS) wait_vm_only<(NS - 1) * NP>();
+  else wait_vm_only<0>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int r = 0; r < NR; ++r) read_frag(fa0, fb0, smem, 0, r);
+
+  // ---- epilogue operands (requested in the last step, after the last DMA group has landed)
+  const int ncol = n0 + wn * (16 * NB) + q * 8;              // first of this lane's 8 consecutive columns of vector 0 (vector v: + 32 v)
+  const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, pe.c_bytes), c2r = make_rsrc(epi.C2, pe.c2_bytes);
+  const __amdgpu_buffer_rsrc_t rr = make_rsrc(epi.residual, pe.r_bytes), hr = make_rsrc(epi.gelu_h, pe.h_bytes);
+  const __amdgpu_buffer_rsrc_t br = make_rsrc(epi.bias, pe.bias_bytes);
+  constexpr int NV = NB / 2;                                 // 16-byte vectors per lane and m block
+  unsigned eo[4];
+  u32x4 er[4][NV], eh[4][NV];
+  f32x4 eb[NB];
+  auto epi_request = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const bufvec_t b = __builtin_amdgcn_raw_buffer_load_b128(br, (unsigned)((ncol + 32 * (i >> 1) + 4 * (i & 1)) * 4), 0, 0);
+      eb[i] = f32x4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = m0 + wm * 64 + mi * 16 + r15;
+      eo[mi] = (m < M) ? (unsigned)(((long)m * ldc + ncol) * 2) : OOB;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
+        er[mi][v] = bload16(rr, o);
+        if constexpr (ACT == PIPE_ACT_HH) eh[mi][v] = bload16(hr, o);
+      }
+    }
+  };
+
+  // step t (32 of K): MFMAs from (ca, cb) | fragment reads of step t+1 into (na, nb).  BAR: step t+1 starts a new stage -- stage
+  // gdone = (t + 1) / KS - 1 has been read completely, so after the barrier its slot takes DMA group gdone + NS, and group gdone + 1
+  // must have landed: NS - 2 groups are younger than it (none once the groups have run out: vmcnt(0)).
+  auto step = [&](bf16x8_t* ca, bf16x8_t* cb, bf16x8_t* na, bf16x8_t* nb, int t, auto BAR_) __attribute__((always_inline)) {
+    constexpr bool BAR = decltype(BAR_)::value;
+    const int gdone = (t + 1) / KS - 1;
+    if constexpr (BAR) {
+      if (gdone + NS <= nst) wait_vm_lgkm0<(NS - 2) * NP>();
+      else wait_vm_lgkm0<0>();
+      __builtin_amdgcn_s_barrier();
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int rs = ((t + 1) / KS) % NS;
+    const char* rst = smem + rs * STAGE;
+    char* wst = smem + (BAR ? (gdone % NS) : 0) * STAGE;
+    const bool fill = BAR && gdone + NS < nst;
+    const int sub = KS == 2 ? ((t + 1) & 1) : 0;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      acc[i >> 2][i & 3] = Mma<T>::mma(ca[i >> 2], cb[i & 3], acc[i >> 2][i & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i < NR) read_frag(na, nb, rst, sub, i);
+      if constexpr (BAR) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          constexpr int first = NP * 2 <= NH ? NH - 2 * NP + 1 : (NH > NP ? NH - NP : 0);   // every other slot of the tail, or every slot
+          constexpr int stride = NP * 2 <= NH ? 2 : 1;
+          if (first + stride * p == i && fill) dma_piece(p, gdone + NS, wst);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto last_step = [&](bf16x8_t* ca, bf16x8_t* cb) __attribute__((always_inline)) {
+    epi_request();
+#pragma unroll
+    for (int i = 0; i < NH; ++i) acc[i >> 2][i & 3] = Mma<T>::mma(ca[i >> 2], cb[i & 3], acc[i >> 2][i & 3]);
+  };
+  for (int t = 0;;) {   // (t is even at the top: with KS == 2 only the second step of a pair crosses into a new stage)
+    if (t + 1 >= nh) { last_step(fa0, fb0); break; }
+    step(fa0, fb0, fa1, fb1, t, std::integral_constant<bool, KS == 1>{}); ++t;
+    if (t + 1 >= nh) { last_step(fa1, fb1); break; }
+    step(fa1, fb1, fa0, fb0, t, std::true_type{}); ++t;
+  }
+
+  // ---- epilogue: straight from the accumulators
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float ev[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ev[e] = acc[2 * v][mi][e] + eb[2 * v][e];
+        ev[4 + e] = acc[2 * v + 1][mi][e] + eb[2 * v + 1][e];
+      }
+      const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
+      if constexpr (ACT == PIPE_ACT_GELU) {
+        bstore16(c2r, o, pack16<T>(ev));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ev[e] = gelu_f(ev[e]);
+      }
+      if constexpr (ACT == PIPE_ACT_HH) {
+        float h[8];
+        unpack16<T>(eh[mi][v], h);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ev[e] *= gelu_grad_f(h[e]);
+      }
+      float rres[8];
+      unpack16<T>(er[mi][v], rres);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ev[e] += rres[e];
+      bstore16(cr, o, pack16<T>(ev));
+    }
+  }
+}
+
 // TN: dW[n][k] += sum_m dY[m][n] * X[m][k].  LDS rows are output features (n for the dY operand, k for the
 // X operand), 128 bytes of consecutive m per row; register transpose of 4(m) x 16-byte patches.
 // swizzle for these images: sw(f) = (f ^ (f >> 4)) & 7 -> fragment reads conflict free, patch writes 2-way.
@@ -2164,6 +2406,16 @@ __global__ void unpack_conv3x3_grad_kernel(const float* __restrict__ packed, flo
 // round for the displaced workgroups (2x for every GEMM that overlaps the collective).  Every GEMM entry point therefore takes a
 // cu_budget argument (0 = all CUs): per call, no process-global state (the multi-GPU trainer passes it for the graph segments that
 // run beside a collective, engine/trainer.py).
+// 1 = product rule (v3 where it measured faster), dev builds: SPG_NT_V3=0 never, 2 always (A/B runs)
+static inline int nt_v3_mode() {
+#ifdef SPG_DEV_KERNELS
+  static const int v = dev_env("SPG_NT_V3", 1);
+  return v;
+#else
+  return 1;
+#endif
+}
+static inline bool nt_v3_enabled() { return nt_v3_mode() != 0; }
 static int hw_cus() {
   static int hw = 0;
   if (hw == 0) {
@@ -2194,6 +2446,64 @@ static inline int pick_nb(int N, int tiles_m, int cus) {
   return nb;
 }
 
+// bf16 problems the 4-wave two-per-CU kernel has an instance for: 8-element-aligned rows, operands addressable by 32-bit offsets, no ReLU
+// (NT_V3_NA = not applicable, the caller falls through to the older kernels)
+constexpr int NT_V3_NA = -1000;
+#ifndef SPG_V3_KS   // (tools/ builds may override the stage geometry: -DSPG_V3_KS=1 -DSPG_V3_NS=4)
+#define SPG_V3_KS 2
+#define SPG_V3_NS 2
+#endif
+constexpr int V3_KS = SPG_V3_KS, V3_NS = SPG_V3_NS;      // 2 stages of 32 KiB (NB = 4): 64 KiB per workgroup, two workgroups per CU
+static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M, int N, int K, int ldx, int ldc, int conv, ConvGeom g,
+                        hipStream_t s) {
+  const int tiles_m = cdiv(M, BM);
+  const long xb = (conv ? (long)M * g.Ci : (long)M * ldx) * 2L, wb = (long)N * K * 2L;
+  const long cb = ((long)(M - 1) * ldc + N) * 2;
+  const int pact = epi.gelu_h ? PIPE_ACT_HH : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : PIPE_ACT_NONE);
+  const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE) && (epi.C2 == nullptr || pact == PIPE_ACT_GELU) &&
+                      !(conv && pact != PIPE_ACT_NONE);
+  if (nt_v3_enabled() && N % 8 == 0 && ldc % 8 == 0 && K % 8 == 0 && (conv ? g.Ci % 8 == 0 : ldx % 8 == 0) && cb < 0xFFFFFFF0L &&
+      xb < 0xFFFFFFF0L && wb < 0xFFFFFFF0L && epi_ok) {
+      PipeEpi pe;
+      pe.c_bytes = (unsigned)cb;
+      pe.c2_bytes = epi.C2 ? (unsigned)cb : 0u;
+      pe.r_bytes = epi.residual ? (unsigned)cb : 0u;
+      pe.h_bytes = epi.gelu_h ? (unsigned)cb : 0u;
+      pe.bias_bytes = epi.bias ? (unsigned)N * 4u : 0u;
+      // tile width: columns of work (incl. the zero columns of the last tile) x per-column-tile fixed cost (X fill, prologue, epilogue)
+      const int nb3 = cdiv(N, 128) * 5 <= cdiv(N, 64) * 3 ? 4 : 2;
+      const int tn3 = cdiv(N, 32 * nb3);
+      const int grid3 = tn3 * tiles_m;
+      // Measured (tools/nt_check.py, hipGraph timing): with two workgroups on most CUs and a short K loop this kernel beats the
+      // persistent one by 5-25 % (qkv 17.8 -> 16.2 us, fc1+GELU 35.4 -> 30.4, the stage-1/2 projections 25-30 %); on grids that leave
+      // one 4-wave workgroup per CU, or with long K loops where the persistent kernel's three DMA groups in flight pay (fc2, dqkv,
+      // the CFI fusion GEMM), it loses 10-60 %.  Dispatch on exactly that.
+      const int cus3 = hw_cus();
+      if (nt_v3_mode() == 1 && (grid3 < cus3 + cus3 / 4 || K > 1536)) return NT_V3_NA;
+#define SPG_LAUNCH3(C_, A_, NB_)                                                                                                           \
+  do {                                                                                                                                     \
+    constexpr int lds_ = V3_NS * (BM + 32 * NB_) * 64 * V3_KS;                                                                                       \
+    static bool attr_ = false;                                                                                                             \
+    if (!attr_) {                                                                                                                          \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v3_kernel<C_, A_, NB_, V3_KS, V3_NS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+      attr_ = true;                                                                                                                        \
+    }                                                                                                                                      \
+    hipLaunchKernelGGL((gemm_nt_v3_kernel<C_, A_, NB_, V3_KS, V3_NS>), dim3(grid3), dim3(256), lds_, s, (const bf16_t*)X, (const bf16_t*)W, (bf16_t*)C, \
+                       epi, pe, M, N, K, ldx, ldc, g, tn3, (unsigned)xb, (unsigned)wb);                                                    \
+  } while (0)
+#define SPG_LAUNCH3_NB(C_, A_) \
+  do { if (nb3 == 4) SPG_LAUNCH3(C_, A_, 4); else SPG_LAUNCH3(C_, A_, 2); } while (0)
+      if (conv) SPG_LAUNCH3_NB(true, PIPE_ACT_NONE);
+      else if (pact == PIPE_ACT_GELU) SPG_LAUNCH3_NB(false, PIPE_ACT_GELU);
+      else if (pact == PIPE_ACT_HH) SPG_LAUNCH3_NB(false, PIPE_ACT_HH);
+      else SPG_LAUNCH3_NB(false, PIPE_ACT_NONE);
+#undef SPG_LAUNCH3_NB
+#undef SPG_LAUNCH3
+      return check_launch("gemm_nt(v3)");
+  }
+  return NT_V3_NA;
+}
+
 #ifdef SPG_DEV_KERNELS
 template <typename T>
 static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, int N, int K, int ldx, int ldc, int conv,
@@ -2204,6 +2514,10 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
   if (xb >= 0xFFFFFFF0L || wb >= 0xFFFFFFF0L) {
     set_error("gemm_nt: operand larger than 4 GiB (X %ld B, W %ld B) is not addressable by one buffer descriptor", xb, wb);
     return SPG_ERR_UNSUPPORTED;
+  }
+  if constexpr (sizeof(T) == 2) {
+    const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s);
+    if (rc3 != NT_V3_NA) return rc3;
   }
   if (dev_env("SPG_GEMM_STAGED", 0) == 0) {
     static bool attr_set = false;
@@ -2380,6 +2694,10 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     const int pact = epi.gelu_h ? PIPE_ACT_HH : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : PIPE_ACT_NONE);
     const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE) && (epi.C2 == nullptr || pact == PIPE_ACT_GELU) &&
                         !(conv && pact != PIPE_ACT_NONE);
+    {
+      const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s);
+      if (rc3 != NT_V3_NA) return rc3;
+    }
     if (K > ROWB / (int)sizeof(T) && N % 8 == 0 && ldc % 8 == 0 && cb < 0xFFFFFFF0L && epi_ok) {
       PipeEpi pe;
       pe.c_bytes = (unsigned)cb;
