@@ -528,7 +528,14 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
   const T* qp = reinterpret_cast<const T*>(p.qp);
   const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
   const int ntiles = (nkeys + 63) >> 6, nrows = ntiles * 64;
-  for (int i = tid * 16; i < 2 * ResLds<T, HD>::IMG; i += RES_THREADS * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+  // the window's 16-row query blocks are dealt to gridDim.z workgroups in runs of 8 (one block per wave): a full 16 x 16 window
+  // (16 blocks) no longer takes two passes on one CU while the CUs holding the partial windows of the same image sit idle
+  const int rb0 = (int)blockIdx.z * (RES_THREADS / 64);
+  if (rb0 * 16 >= w.nq) return;
+  for (int i = tid * 16; i < nrows * A::RS; i += RES_THREADS * 16) {   // (the rows the tiles in use cover; staging leaves pad columns)
+    *reinterpret_cast<u32x4*>(kimg + i) = u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(vimg + i) = u32x4{0u, 0u, 0u, 0u};
+  }
   for (int c = tid; c < nrows; c += RES_THREADS) {
     const T* kp = nullptr;
     float b = NEG_BIG;
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
   stage_rows<T, HD>(kptr, nrows, 0, kimg, p.C, vimg);
   __syncthreads();
 
-  for (int rb = wave; rb * 16 < w.nq; rb += RES_THREADS / 64) {
+  for (int rb = rb0 + wave; rb * 16 < w.nq; rb += (RES_THREADS / 64) * (int)gridDim.z) {
     const int qi = rb * 16 + r15;
     const bool qvalid = qi < w.nq;
     const long qrow = q_row(p, w, qvalid ? qi : 0);
@@ -644,7 +651,12 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p) {
   const T* qp = reinterpret_cast<const T*>(p.qp);
   const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
   const int ntq = (w.nq + 63) >> 6, nrows = ntq * 64;
-  for (int i = tid * 16; i < 2 * ResLds<T, HD>::IMG; i += RES_THREADS * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+  const int kb0 = (int)blockIdx.z * (RES_THREADS / 64);      // key blocks dealt to gridDim.z workgroups, as the query blocks above
+  if (kb0 * 16 >= nkeys) return;
+  for (int i = tid * 16; i < nrows * A::RS; i += RES_THREADS * 16) {
+    *reinterpret_cast<u32x4*>(qimg + i) = u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(doimg + i) = u32x4{0u, 0u, 0u, 0u};
+  }
   for (int i = tid; i < nrows; i += RES_THREADS) {
     const T* a = nullptr;
     float ls = 1.0e30f, dl = 0.f;
@@ -669,7 +681,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p) {
   stage_rows<T, HD>(qptrs, nrows, 0, doimg);
   __syncthreads();
 
-  for (int kbk = wave; kbk * 16 < nkeys; kbk += RES_THREADS / 64) {
+  for (int kbk = kb0 + wave; kbk * 16 < nkeys; kbk += (RES_THREADS / 64) * (int)gridDim.z) {
     const int c = kbk * 16 + r15;
     const T* kp = nullptr;
     float kbias = NEG_BIG;
@@ -745,7 +757,10 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
       }
-      const dim3 grid(p.heads, nwin);
+      // (z > 1 deals a window's 16-row blocks to several workgroups in runs of 8.  Measured on the stage-3 windows: SLOWER, 58 -> 66 us
+      // per backward pair -- these kernels are bound by the staging latency of a workgroup (pointer table, K/V loads, LDS stores:
+      // ~2/3 of its time), which every extra workgroup pays again, and at 133 KiB of LDS only one workgroup fits a CU.)
+      const dim3 grid(p.heads, nwin, 1), gridk(p.heads, nwin, 1);
       if (which == 0) {
         hipLaunchKernelGGL((attn_res_q_kernel<T, HD, false>), grid, dim3(RES_THREADS), LDS, s, p);
         return check_launch("attn_fwd(res)");
@@ -753,7 +768,7 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
       hipLaunchKernelGGL((attn_res_q_kernel<T, HD, true>), grid, dim3(RES_THREADS), LDS, s, p);
       int rc = check_launch("attn_bwd_dq(res)");
       if (rc) return rc;
-      hipLaunchKernelGGL((attn_res_dkv_kernel<T, HD>), grid, dim3(RES_THREADS), LDS, s, p);
+      hipLaunchKernelGGL((attn_res_dkv_kernel<T, HD>), gridk, dim3(RES_THREADS), LDS, s, p);
       return check_launch("attn_bwd_dkv(res)");
     }
   }

@@ -877,6 +877,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
         if (i == 3) dma_addr(1);
         if (i == 4) dma_go(1, 0);
         if (i == 5) dma_go(1, 1);
+        if (i == 6) issue_advance();   // (inside the block: scalar work in the issue slots the MFMAs leave free)
       } else if (dma_mode == 2) {   // late: behind the fragment reads
         if (i == NM - 6) dma_addr(0);
         if (i == NM - 5) dma_go(0, 0);
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
     }
     kt = last ? 0 : kt + 1;
     tile = last ? tile + G : tile;
-    issue_advance();
+    if constexpr (DBG == 8 || DBG == 9) issue_advance();   // (the ablation modes issue their DMA elsewhere in the block)
     rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
   };
   for (int gc = 0; gc < total; gc += 2) {
@@ -1632,6 +1633,7 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
       if (i == 3) dma_addr(1);
       if (i == 4) dma_go(1, 0);
       if (i == 5) dma_go(1, 1);
+      if (i == 6) issue_advance();   // (inside the block: scalar work in the issue slots the MFMAs leave free)
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (BIAS) {
@@ -1684,7 +1686,6 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
     }
     st_i = last ? 0 : st_i + 1;
     unit = last ? unit + G : unit;
-    issue_advance();
     rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
   };
   for (int gc = 0; gc < total; gc += 2) {
@@ -1782,6 +1783,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
   };
   auto dma_go = [&](int i, int which) __attribute__((always_inline)) {
     const unsigned st = smem_base + is_slot * STAGE_B + (i * 8 + wave) * 1024;
+    if constexpr (DBG == 4) { asm volatile("" :: "v"(dyo[i]), "v"(dxo[i]), "s"(st)); return; }   // ablation: no fill
     if (which == 0) dma16_asm(yr, st, dyo[i]);
     else dma16_asm(xr, st + 16384, dxo[i]);
   };
@@ -1828,11 +1830,27 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < 12; ++i) read_frag(fa, smem, i);
+  if constexpr (DBG == 3) fb = fa;
 
   // ---- compute cursor
   int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;   // seg0: m step at which this workgroup entered the current tile
   int cj, ctile;
-  tn_locate_tile(g, cgt, cj, ctile);
+  // per-tile quantities live in registers and change only when the cursor moves to another tile: looking them up in the argument
+  // struct every step (scalar loads share lgkmcnt with the LDS reads, then an integer division) stalled each step's first MFMA
+  int c_tk, c_tn;
+  bool c_bias;
+  auto locate = [&](int gt, int& j, int& tile, int& tn, int& tk, bool& bias) __attribute__((always_inline)) {
+    tn_locate_tile(g, gt, j, tile);
+    const TnJob& jb = g.job[j];
+    tn = tile / jb.tiles_k; tk = tile - tn * jb.tiles_k;
+    bias = jb.dbias != nullptr && tk == 0;
+  };
+  locate(cgt, cj, ctile, c_tn, c_tk, c_bias);
+  // the step's scalar bookkeeping (cursor advance, DMA stream advance) is placed INSIDE the MFMA block, in the issue slots the
+  // MFMAs leave free: after the block it ran with the matrix pipe idle on every wave at once (the barrier keeps them in phase)
+  bool s_tile_end = false, s_range_end = false, s_moved = false;
+  int n_cgt = 0, n_cm = 0, n_seg0 = 0, n_cj = 0, n_ctile = 0, n_tn = 0, n_tk = 0;
+  bool n_bias = false;
   int rd_slot = 1, st1 = 0, st2 = 0;
   const int r15 = lane & 15, q = lane >> 4;
   auto mma_block = [&](Frags& cur, Frags& nxt, auto BIAS_) __attribute__((always_inline)) {
@@ -1843,13 +1861,26 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
       const int ms = i >> 3, r = i & 7, ni = r >> 1, ki = r & 1;
       if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);
       else asm volatile("" :: "v"(cur.b[ms][ki]), "v"(cur.a[ms][ni]));
-      if (i < 12) read_frag(nxt, rst, i);
+      if (i < 12 && DBG != 3) read_frag(nxt, rst, i);   // (DBG 3: ablation without the fragment reads)
       if (i == 0) dma_addr(0);
       if (i == 1) dma_go(0, 0);
       if (i == 2) dma_go(0, 1);
       if (i == 3) dma_addr(1);
       if (i == 4) dma_go(1, 0);
       if (i == 5) dma_go(1, 1);
+      if (i == 6) issue_advance();
+      if (i == 8) {
+        const int nls = cls + 1;
+        const bool jump = nls == WS && nls < total;          // whole tiles done: on to the remainder share
+        s_moved = (jump || s_tile_end) && !s_range_end;
+        n_cgt = jump ? gt_rem : (s_tile_end ? cgt + 1 : cgt);
+        n_cm = jump ? m_rem : (s_tile_end ? 0 : cm + 1);
+        n_seg0 = jump ? m_rem : (s_tile_end ? 0 : seg0);
+      }
+      if (i == 10) {
+        n_cj = cj; n_ctile = ctile; n_tn = c_tn; n_tk = c_tk; n_bias = c_bias;
+        if (s_moved) locate(n_cgt, n_cj, n_ctile, n_tn, n_tk, n_bias);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (BIAS) {
@@ -1870,14 +1901,15 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     st2 = st1; st1 = 0;
-    const TnJob& jb = g.job[cj];
-    const int tk = ctile % jb.tiles_k, tn = ctile / jb.tiles_k;
-    const bool bias_tile = jb.dbias != nullptr && tk == 0;
-    if (bias_tile) mma_block(cur, nxt, std::true_type{}); else mma_block(cur, nxt, std::false_type{});
-    __builtin_amdgcn_sched_barrier(0);
+    const bool bias_tile = c_bias;
     const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
     const bool range_end = cls + 1 == total;
+    s_tile_end = tile_end; s_range_end = range_end;
+    if (bias_tile) mma_block(cur, nxt, std::true_type{}); else mma_block(cur, nxt, std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
     if (tile_end || range_end) {
+      const TnJob& jb = g.job[cj];
+      const int tk = c_tk, tn = c_tn;
       const int n0 = tn * 128 + wn * 64, k0 = tk * 128 + wk * 32;
       if (seg0 == 0 && tile_end) {
         // the whole tile was multiplied here: accumulate into the gradient (single owner)
@@ -1924,16 +1956,9 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
       }
       bsum = 0.f;
     }
-    // advance the compute cursor (value selects: see gemm_nt_pipe_kernel on symmetric updates)
-    const int nls = cls + 1;
-    const bool jump = nls == WS && nls < total;          // whole tiles done: on to the remainder share
-    const bool moved = (jump || tile_end) && !range_end;
-    cgt = jump ? gt_rem : (tile_end ? cgt + 1 : cgt);
-    cm = jump ? m_rem : (tile_end ? 0 : cm + 1);
-    seg0 = jump ? m_rem : (tile_end ? 0 : seg0);
-    cls = nls;
-    if (moved) tn_locate_tile(g, cgt, cj, ctile);
-    issue_advance();
+    // commit the cursor values computed inside the block
+    cgt = n_cgt; cm = n_cm; seg0 = n_seg0; cls = cls + 1;
+    cj = n_cj; ctile = n_ctile; c_tn = n_tn; c_tk = n_tk; c_bias = n_bias;
     rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
   };
   for (int gc = 0; gc < total; gc += 2) {
@@ -2978,9 +3003,16 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
     attr = true;
   }
 #ifdef SPG_DEV_KERNELS
-  if (dev_env("SPG_TN_GROUP_DEBUG", 0) == 2) {   // no-MFMA ablation (wrong results by construction): dev builds only
+  const int dbgg = dev_env("SPG_TN_GROUP_DEBUG", 0);   // ablations (wrong results by construction): 2 no MFMAs, 3 no fragment reads, 4 no fill
+  if (dbgg == 2) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else if (dbgg == 3) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 3>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else if (dbgg == 4) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 4>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   } else
 #endif
   hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);

@@ -43,7 +43,10 @@ class Engine:
         # quantisation, ramp-up and tail of each launch).  With wgrad_async they are forked onto a second HIP stream -- inside a
         # captured step that is a parallel branch of the graph -- so their workgroups could pack into CUs the dgrad chain leaves idle.
         # Operands are held until join_wgrad(), which every backward piece calls before it returns.  Off by default: on one MI355X
-        # the two chip-sized branches contend (226.0 vs 232.2 img/s, see engine/trainer.py).
+        # the two chip-sized branches contend (226.0 vs 232.2 img/s, see engine/trainer.py).  A SPATIAL split was measured too
+        # (round 2: the grouped wgrad launches on a side stream with a 64 / 96-CU grid, the dgrad chain sized for the other CUs):
+        # 34.3 / 31.9 ms per step against 29.2 in line -- the wgrad branch becomes the critical path before the chain's idle CU time
+        # pays for the partition.
         self.wgrad_async = False
         self.group_wgrads = True    # trunk blocks: one grouped wgrad launch per block (False: per-layer launches, for A/B runs)
         self._wg_jobs = None
@@ -430,8 +433,8 @@ class Engine:
             st["unit"] += 1
             if self.unit_cb is not None:
                 self.unit_cb(st["unit"])
+        self.join_wgrad()          # (before the deferred slab reduces: they read what forked launches wrote)
         self.flush_ln_params()
-        self.join_wgrad()
 
     def trunk_bwd_end(self):
         e = "encoder.encoder."
