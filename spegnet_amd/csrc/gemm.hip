@@ -1451,6 +1451,15 @@ template <> struct TnFrag<bf16_t> {
     o0 = row0 * 256 + ((((c >> 1) ^ tnd_swz(row0)) << 1 | (c & 1)) << 4) + within;
     o1 = row1 * 256 + ((((c >> 1) ^ tnd_swz(row1)) << 1 | (c & 1)) << 4) + within;
   }
+  // one transpose read (half a fragment: 4 of its 8 rows) and the join of two halves
+  __device__ static __forceinline__ s16x4_t load_half(const char* tile, int o) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + o));
+  }
+  __device__ static __forceinline__ Frag join(s16x4_t v0, s16x4_t v1) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
   __device__ static __forceinline__ Frag load_at(const char* tile, int o0, int o1) {
     const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + o0));
     const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + o1));
@@ -1727,6 +1736,17 @@ __device__ __forceinline__ void tn_locate_tile(const TnGroup& g, int gt, int& j,
   tile = gt - g.job[j].tile0;
 }
 
+#ifdef SPG_DEV_KERNELS
+// In-kernel stamps (DBG 5, tools/tn_stamps.py): per wave, cycles summed over the steps in [top waits | barrier | MFMA block + read drain | tail]
+__device__ unsigned long long tn_stamp_sums[256 * 8 * 4];
+#endif
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
 template <typename T, int DBG = 0>   // DBG 2: no MFMAs (times the fill + read pipeline alone; wrong results by construction)
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
   static_assert(sizeof(T) == 2, "bf16 only");
@@ -1862,13 +1882,21 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
       if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);
       else asm volatile("" :: "v"(cur.b[ms][ki]), "v"(cur.a[ms][ni]));
       if (i < 12 && DBG != 3) read_frag(nxt, rst, i);   // (DBG 3: ablation without the fragment reads)
-      if (i == 0) dma_addr(0);
-      if (i == 1) dma_go(0, 0);
-      if (i == 2) dma_go(0, 1);
-      if (i == 3) dma_addr(1);
-      if (i == 4) dma_go(1, 0);
-      if (i == 5) dma_go(1, 1);
-      if (i == 6) issue_advance();
+      if constexpr (DBG == 6) {   // A/B: the DMA pieces behind the fragment reads
+        if (i == 11) { dma_addr(0); dma_addr(1); }
+        if (i == 12) dma_go(0, 0);
+        if (i == 13) dma_go(0, 1);
+        if (i == 14) dma_go(1, 0);
+        if (i == 15) { dma_go(1, 1); issue_advance(); }
+      } else {
+        if (i == 0) dma_addr(0);
+        if (i == 1) dma_go(0, 0);
+        if (i == 2) dma_go(0, 1);
+        if (i == 3) dma_addr(1);
+        if (i == 4) dma_go(1, 0);
+        if (i == 5) dma_go(1, 1);
+        if (i == 6) issue_advance();
+      }
       if (i == 8) {
         const int nls = cls + 1;
         const bool jump = nls == WS && nls < total;          // whole tiles done: on to the remainder share
@@ -1895,11 +1923,15 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
       }
     }
   };
+  unsigned long long sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0, tlast = 0;
+  if constexpr (DBG == 5) tlast = stamp_now();
   auto step = [&](Frags& cur, Frags& nxt) __attribute__((always_inline)) {
     if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else { wait_vm(8 + st1 + st2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg0 += t - tlast; tlast = t; }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg1 += t - tlast; tlast = t; }
     st2 = st1; st1 = 0;
     const bool bias_tile = c_bias;
     const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
@@ -1907,6 +1939,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
     s_tile_end = tile_end; s_range_end = range_end;
     if (bias_tile) mma_block(cur, nxt, std::true_type{}); else mma_block(cur, nxt, std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg2 += t - tlast; tlast = t; }
     if (tile_end || range_end) {
       const TnJob& jb = g.job[cj];
       const int tk = c_tk, tn = c_tn;
@@ -1960,12 +1993,285 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
     cgt = n_cgt; cm = n_cm; seg0 = n_seg0; cls = cls + 1;
     cj = n_cj; ctile = n_ctile; c_tn = n_tn; c_tk = n_tk; c_bias = n_bias;
     rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
+    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg3 += t - tlast; tlast = t; }
   };
   for (int gc = 0; gc < total; gc += 2) {
     step(fa, fb);
     if (gc + 1 < total) step(fb, fa);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SPG_DEV_KERNELS
+  if constexpr (DBG == 5) {
+    if (lane == 0 && blockIdx.x < 256) {
+      unsigned long long* o = tn_stamp_sums + ((int)blockIdx.x * 8 + wave) * 4;
+      o[0] = sg0; o[1] = sg1; o[2] = sg2; o[3] = sg3;
+    }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn_group4_kernel: the same grouped schedule (whole tiles, then an equal share of the remainder tiles' steps; slab slots and
+// tn_group_reduce as above) with SPECIALISED waves: waves 0-3 multiply (a 64 x 64 quarter of the tile each, one per SIMD), waves 4-7
+// only issue the LDS-DMA fill (8 pieces of 1 KiB each per 64-row step).
+//
+// Why: in-kernel stamps of the 8-wave kernel above (tools/tn_stamps.py, profiles/round2_tn_stamps.md) put a 64-row step at ~2300
+// cycles of which the MFMA pipe needs 512: every wave issues, in order, 16 MFMAs + 24 transpose reads + 4 DMA pieces (~80 cycles of
+// issue each among reads and MFMAs) + the cursor bookkeeping, and the ablations (no MFMA / no reads / no fill) remove their share
+// ADDITIVELY -- the step is bound by each wave's own instruction issue, not by the matrix pipe, LDS or the fill.  With the roles split
+// a multiplying wave issues 32 MFMAs + 32 transpose reads and nothing else, and the fill's issue cost sits in a wave of its own
+// on the same SIMD (different instruction types issue in the same cycle from different waves).
+// Hand-off: one workgroup barrier per step, B_k.  Before it a loader has waited for ITS pieces of group k+1 (vmcnt(16): the two
+// younger groups stay in flight), a multiplier for its fragment reads of stage k (lgkmcnt(0)); after it group k+4 may overwrite
+// stage k's slot and the fragments of step k+1 may be read.  Both roles pass exactly 1 + total barriers.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  using F = TnFrag<T>;
+  constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = (int)gridDim.x;
+  const int c = xcd_remap(blockIdx.x, G);
+  const int S = g.S;
+  const int WS = g.W * S;                                                   // steps of this workgroup's whole tiles
+  const int rb = (int)((long)c * g.RS / G), re = (int)((long)(c + 1) * g.RS / G);   // its share of the remainder steps
+  const int total = WS + (re - rb);
+  if (total <= 0) return;
+  const int gt_first = WS > 0 ? c * g.W : g.W * G + rb / S;                 // first tile / step of the sequence
+  const int m_first = WS > 0 ? 0 : rb % S;
+  const int gt_rem = g.W * G + rb / S, m_rem = rb % S;                      // where the remainder share starts
+
+  if (wave >= 4) {
+    // ================================================================ loader waves
+    const int lw = wave - 4;
+    const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    const int lrow = lane >> 4, lpc = lane & 15;
+    const int prow0 = lw * 4 + lrow;                                        // row (mod 16) of this lane's pieces
+    const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;
+    int is_job = -1, is_gt = gt_first, is_tile, is_mstep = m_first, is_ls = 0, is_slot = 0;
+    bool is_live = true, is_yin = false, is_xin = false;
+    unsigned yoff = 0, xoff = 0, ystride = 0, xstride = 0, y16 = 0, x16 = 0;
+    rsrc_words_t yr, xr;
+    auto enter_tile = [&]() __attribute__((always_inline)) {   // (also switches descriptors when the tile belongs to another problem)
+      int j;
+      tn_locate_tile(g, is_gt, j, is_tile);
+      const TnJob& jb = g.job[j];
+      if (j != is_job) {
+        is_job = j;
+        yr = make_rsrc_words(jb.dY, (unsigned)((long)g.M * jb.ldy * 2));
+        xr = make_rsrc_words(jb.X, (unsigned)((long)g.M * jb.ldx * 2));
+        ystride = (unsigned)(MSTEP * jb.ldy * 2); xstride = (unsigned)(MSTEP * jb.ldx * 2);
+        y16 = (unsigned)(16 * jb.ldy * 2); x16 = (unsigned)(16 * jb.ldx * 2);
+      }
+      const int tk = is_tile % jb.tiles_k, tn = is_tile / jb.tiles_k;
+      const int n0 = tn * 128, k0 = tk * 128;
+      const long m0 = (long)is_mstep * MSTEP + prow0;
+      yoff = (unsigned)((m0 * jb.ldy + n0 + fcol) * 2);
+      xoff = (unsigned)((m0 * jb.ldx + k0 + fcol) * 2);
+      is_yin = n0 + fcol < jb.N; is_xin = k0 + fcol < jb.K;
+    };
+    enter_tile();
+    auto issue_group = [&]() __attribute__((always_inline)) {   // rows past M fall outside the descriptors: hardware zero fill
+      const unsigned st = smem_base + is_slot * STAGE_B + lw * 1024;
+      const bool yl = is_live && is_yin, xl = is_live && is_xin;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dma16_asm(yr, st + j * 4096, yl ? yoff + j * y16 : OOB);
+        dma16_asm(xr, st + 16384 + j * 4096, xl ? xoff + j * x16 : OOB);
+      }
+      is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+      yoff += ystride; xoff += xstride;
+      ++is_ls;
+      const bool tile_end = is_mstep + 1 == S;
+      if (is_ls >= total) is_live = false;
+      else if (is_ls == WS) { is_gt = gt_rem; is_mstep = m_rem; enter_tile(); }        // whole tiles done: jump to the remainder share
+      else if (tile_end) { is_gt = is_gt + 1; is_mstep = 0; enter_tile(); }
+      else is_mstep = is_mstep + 1;
+    };
+    for (int i = 0; i < STAGES; ++i) issue_group();
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");       // group 0
+    __builtin_amdgcn_s_barrier();
+    unsigned long long sg0 = 0, sg1 = 0, sg2 = 0, tlast = 0;
+    if constexpr (DBG == 5) tlast = stamp_now();
+    for (int k = 0; k < total; ++k) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // group k+1 (groups k+2, k+3 stay in flight)
+      if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg0 += t - tlast; tlast = t; }
+      __builtin_amdgcn_s_barrier();                         // B_k
+      if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg1 += t - tlast; tlast = t; }
+      issue_group();                                        // group k+4 -> the slot of stage k
+      if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg2 += t - tlast; tlast = t; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing no-op pieces
+#ifdef SPG_DEV_KERNELS
+    if constexpr (DBG == 5) {
+      if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = tn_stamp_sums + ((int)blockIdx.x * 8 + wave) * 4;
+        o[0] = sg0; o[1] = sg1; o[2] = sg2; o[3] = 0;
+      }
+    }
+#endif
+    return;
+  }
+
+  // ================================================================== multiplying waves
+  const int wn = wave & 1, wk = wave >> 1;
+  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
+  int oa[2][4][2], ob[2][4][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      F::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
+      F::offsets(s2, wk * 64 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
+    }
+  // fragments are kept as their two transpose-read halves: ONE read per MFMA slot fits the ~8 issue cycles an MFMA leaves free
+  // (two per slot added their issue time to the MFMA's: stamps, tools/tn_stamps.py)
+  struct Frags { s16x4_t a[2][4][2], b[2][4][2]; };
+  Frags fa, fb;
+  auto read_half = [&](Frags& f, const char* st, int t) __attribute__((always_inline)) {   // t-th of the 32 reads of a step
+    const int idx = t >> 1, h = t & 1, sx = idx >> 3, r = idx & 7;
+    if (r < 4) f.b[sx][r][h] = F::load_half(st + 16384, ob[sx][r][h]);
+    else f.a[sx][r - 4][h] = F::load_half(st, oa[sx][r - 4][h]);
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum0 = 0.f, bsum1 = 0.f;
+  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+
+  __builtin_amdgcn_s_barrier();                             // group 0 has landed
+#pragma unroll
+  for (int i = 0; i < 32; ++i) read_half(fa, smem, i);
+
+  int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;   // seg0: m step at which this workgroup entered the current tile
+  int cj, ctile, c_tk, c_tn;
+  bool c_bias;
+  auto locate = [&](int gt, int& j, int& tile, int& tn, int& tk, bool& bias) __attribute__((always_inline)) {
+    tn_locate_tile(g, gt, j, tile);
+    const TnJob& jb = g.job[j];
+    tn = tile / jb.tiles_k; tk = tile - tn * jb.tiles_k;
+    bias = jb.dbias != nullptr && tk == 0;
+  };
+  locate(cgt, cj, ctile, c_tn, c_tk, c_bias);
+  int rd_slot = 1;
+  const int r15 = lane & 15, q = lane >> 4;
+  unsigned long long sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0, tlast = 0;
+  if constexpr (DBG == 5) tlast = stamp_now();
+  auto step = [&](Frags& cur, Frags& nxt) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this step's fragments (and with them: stage k has been read)
+    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg0 += t - tlast; tlast = t; }
+    __builtin_amdgcn_s_barrier();                           // B_k
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg1 += t - tlast; tlast = t; }
+    const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
+    const bool range_end = cls + 1 == total;
+    const bool bias_tile = c_bias;
+    const char* rst = smem + rd_slot * STAGE_B;
+    // cursor values of the next step, computed in the MFMA shadows below
+    int n_cgt = cgt, n_cm = cm, n_seg0 = seg0, n_cj = cj, n_ctile = ctile, n_tn = c_tn, n_tk = c_tk;
+    bool n_bias = c_bias;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int ms = i >> 4, r = i & 15, ni = r >> 2, ki = r & 3;
+      const typename F::Frag fb_ = F::join(cur.b[ms][ki][0], cur.b[ms][ki][1]), fa_ = F::join(cur.a[ms][ni][0], cur.a[ms][ni][1]);
+      if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(fb_, fa_, acc[ni][ki]);
+      else asm volatile("" :: "v"(fb_), "v"(fa_));
+      __builtin_amdgcn_sched_barrier(0);
+      read_half(nxt, rst, i);   // (unconditional: past the last step this reads a stale stage into registers nobody uses)
+      if (i == 18) {
+        const int nls = cls + 1;
+        const bool jump = nls == WS && nls < total;          // whole tiles done: on to the remainder share
+        const bool moved = (jump || tile_end) && !range_end;
+        n_cgt = jump ? gt_rem : (tile_end ? cgt + 1 : cgt);
+        n_cm = jump ? m_rem : (tile_end ? 0 : cm + 1);
+        n_seg0 = jump ? m_rem : (tile_end ? 0 : seg0);
+        if (moved) locate(n_cgt, n_cj, n_ctile, n_tn, n_tk, n_bias);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg2 += t - tlast; tlast = t; }
+    if (bias_tile) {   // column sums of dY over this step's 64 rows: this wave's two 16-column blocks of its n half
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        const typename F::Frag v0 = wk == 0 ? F::join(cur.a[ms][0][0], cur.a[ms][0][1]) : F::join(cur.a[ms][2][0], cur.a[ms][2][1]);
+        const typename F::Frag v1 = wk == 0 ? F::join(cur.a[ms][1][0], cur.a[ms][1][1]) : F::join(cur.a[ms][3][0], cur.a[ms][3][1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2_t p0 = {v0[2 * e], v0[2 * e + 1]}, p1 = {v1[2 * e], v1[2 * e + 1]};
+          bsum0 = __builtin_amdgcn_fdot2_f32_bf16(p0, ones2, bsum0, false);
+          bsum1 = __builtin_amdgcn_fdot2_f32_bf16(p1, ones2, bsum1, false);
+        }
+      }
+    }
+    if (tile_end || range_end) {
+      const TnJob& jb = g.job[cj];
+      const int n0 = c_tn * 128 + wn * 64, k0 = c_tk * 128 + wk * 64;
+      if (seg0 == 0 && tile_end) {
+        // the whole tile was multiplied here: accumulate into the gradient (single owner)
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(jb.dW, (unsigned)((long)jb.N * jb.ldw * 4));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          u32x4 old[4];
+          unsigned o[4];
+#pragma unroll
+          for (int ki = 0; ki < 4; ++ki) {
+            const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
+            o[ki] = (n < jb.N && k < jb.K) ? (unsigned)(((long)n * jb.ldw + k) * 4) : OOB;   // K % 4 == 0
+            old[ki] = bload16(wr, o[ki]);
+          }
+#pragma unroll
+          for (int ki = 0; ki < 4; ++ki) {
+            const f32x4 v = acc[ni][ki] + f32x4{__uint_as_float(old[ki].x), __uint_as_float(old[ki].y), __uint_as_float(old[ki].z),
+                                                __uint_as_float(old[ki].w)};
+            bstore16(wr, o[ki], u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
+            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      } else {
+        const int slot = seg0 != 0 ? 0 : 1;
+        const unsigned base = (unsigned)(((long)c * 2 + slot) * TN_SLOT_FLOATS * 4);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int ki = 0; ki < 4; ++ki) {
+            const int nl = wn * 64 + ni * 16 + r15, kl = wk * 64 + ki * 16 + q * 4;
+            bstore16(sr, base + (unsigned)((nl * 128 + kl) * 4), u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
+                                                                      __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
+            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+      if (bias_tile) {   // partial column sums of this segment: float atomics straight into the bias gradient
+        float b0 = bsum0, b1 = bsum1;
+        b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
+        b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
+        const int n = n0 + wk * 32 + r15;
+        if (q == 0 && n < jb.N) atomicAdd(jb.dbias + n, b0);
+        if (q == 0 && n + 16 < jb.N) atomicAdd(jb.dbias + n + 16, b1);
+      }
+      bsum0 = 0.f; bsum1 = 0.f;
+    }
+    cgt = n_cgt; cm = n_cm; seg0 = n_seg0; cls = cls + 1;
+    cj = n_cj; ctile = n_ctile; c_tn = n_tn; c_tk = n_tk; c_bias = n_bias;
+    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
+    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg3 += t - tlast; tlast = t; }
+  };
+  for (int gc = 0; gc < total; gc += 2) {
+    step(fa, fb);
+    if (gc + 1 < total) step(fb, fa);
+  }
+#ifdef SPG_DEV_KERNELS
+  if constexpr (DBG == 5) {
+    if (lane == 0 && blockIdx.x < 256) {
+      unsigned long long* o = tn_stamp_sums + ((int)blockIdx.x * 8 + wave) * 4;
+      o[0] = sg0; o[1] = sg1; o[2] = sg2; o[3] = sg3;
+    }
+  }
+#endif
 }
 
 // Folds the partial sums of the remainder tiles cut by share boundaries into dW.  Block b looks at boundary c = b + 1 (between the
@@ -2441,6 +2747,14 @@ static inline int nt_v3_mode() {
 #endif
 }
 static inline bool nt_v3_enabled() { return nt_v3_mode() != 0; }
+static inline bool tn_group_v4() {   // dev builds: SPG_TN_GROUP_V4=0 selects the 8-wave kernel (A/B runs)
+#ifdef SPG_DEV_KERNELS
+  static const int v = dev_env("SPG_TN_GROUP_V4", 1);
+  return v != 0;
+#else
+  return true;
+#endif
+}
 static int hw_cus() {
   static int hw = 0;
   if (hw == 0) {
@@ -3003,18 +3317,41 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
     attr = true;
   }
 #ifdef SPG_DEV_KERNELS
-  const int dbgg = dev_env("SPG_TN_GROUP_DEBUG", 0);   // ablations (wrong results by construction): 2 no MFMAs, 3 no fragment reads, 4 no fill
+  const int dbgg = tn_group_v4() ? 0 : dev_env("SPG_TN_GROUP_DEBUG", 0);   // 8-wave kernel's ablations (wrong results by construction): 2 no MFMAs, 3 no fragment reads, 4 no fill, 5 stamps, 6 late DMA
   if (dbgg == 2) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   } else if (dbgg == 3) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 3>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else if (dbgg == 5) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 5>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else if (dbgg == 6) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 6>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   } else if (dbgg == 4) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t, 4>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   } else
 #endif
+#ifdef SPG_DEV_KERNELS
+  if (tn_group_v4() && dev_env("SPG_TN_GROUP_DEBUG", 0) == 5) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group4_kernel<bf16_t, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipLaunchKernelGGL((gemm_tn_group4_kernel<bf16_t, 5>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else if (tn_group_v4() && dev_env("SPG_TN_GROUP_DEBUG", 0) == 2) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group4_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipLaunchKernelGGL((gemm_tn_group4_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else
+#endif
+  if (tn_group_v4()) {
+    static bool attr4 = false;
+    if (!attr4) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group4_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+      attr4 = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_group4_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else
   hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
   int rc = check_launch("gemm_tn_group");
   if (reduce_desc_out) {     // deferred: the caller collects descriptors and folds the slabs later (spg_gemm_tn_group_reduce_batch)
@@ -3028,6 +3365,11 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   return check_launch("gemm_tn_group(reduce)");
 }
 
+#ifdef SPG_DEV_KERNELS
+extern "C" int spg_dev_tn_stamps(unsigned long long* out) {   // 256 workgroups x 8 waves x 4 segment sums (SPG_TN_GROUP_DEBUG=5)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(spg::tn_stamp_sums), sizeof(unsigned long long) * 256 * 8 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" long spg_gemm_tn_group_desc_bytes(void) { return (long)sizeof(TnReduceDesc); }
 
 extern "C" int spg_gemm_tn_group_reduce_batch(int n, const void* const* descs, const void* const* workspaces, spg_stream_t stream) {
