@@ -1212,6 +1212,244 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
   }
 }
 
+#ifdef SPG_DEV_KERNELS
+// ------------------------------------------------------------------------------------------------
+// gemm_nt_v5: persistent 128 x (32 NB) tiles with SPECIALISED waves -- waves 0-3 multiply (64 x 16 NB each, one per SIMD) and run the
+// accumulator-direct epilogue of gemm_nt_v3, waves 4-7 only issue the LDS-DMA fill (4 stages of 64 K, three groups in flight, running
+// ahead across tile boundaries so a tile's epilogue sits under the next tile's fill).
+// Why: stamps and ablations of the grouped wgrad kernel (tools/tn_stamps.py) showed the 8-wave pipelined kernels bound by each wave's
+// own instruction issue -- MFMAs, fragment reads, ~80-100 cycles per DMA piece and the cursor bookkeeping add up in one in-order
+// stream -- not by the matrix pipe.  Split by role, a multiplying wave issues 32 MFMAs + 16 ds_read_b128 per 64 of K and the fill's
+// issue cost runs beside it on the same SIMD.
+// Hand-off: one workgroup barrier per K step, B_k, between the step's two 32-deep halves.  Before it a multiplier has waited for its
+// reads of stage k (lgkmcnt(0)), a loader for ITS pieces of group k+1 (vmcnt(2 NP)); after it the multipliers read half 0 of stage
+// k+1 and the loaders overwrite stage k's slot with group k+4.  Both roles pass 1 + (tiles x K steps) barriers.
+// Result (round 2): NOT faster in the training step -- NT steps already run at the fill path's rate (~800 cycles per 32 KiB stage
+// with four issuing waves, tools/tn_stamps.py), so taking the fill out of the multiplying waves buys nothing here; back-to-back
+// replays of one problem (tools/nt_check.py) showed 8 % on the long-K projections, the step with cold operands lost 0.3 ms
+// (28.17 vs 27.87 ms, two A/B pairs on one box).  Dev builds only (SPG_NT_V5=1).
+// ------------------------------------------------------------------------------------------------
+template <bool CONV, int ACT, int NB>
+__global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
+                                                         NtEpi epi, PipeEpi pe, int M, int N, int K, int ldx, int ldc, ConvGeom g,
+                                                         int tiles_n, int ntiles, unsigned xbytes, unsigned wbytes) {
+  using T = bf16_t;
+  static_assert(NB == 4 || NB == 2, "accumulator pairs hold 8 consecutive columns");
+  constexpr int RB = 128, NS = 4;
+  constexpr int BN_ = 32 * NB;
+  constexpr int STAGE = (BM + BN_) * RB;
+  constexpr int WROWS = BN_ / 4;            // W rows each loader fills per stage
+  constexpr int XP = 4, WP = WROWS / 8;     // 1 KiB pieces (8 rows) per loader and stage
+  constexpr int NP = XP + WP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkt = (K + 63) >> 6;
+  const int G = (int)gridDim.x;
+  const int first = xcd_remap(blockIdx.x, G);
+  if (first >= ntiles) return;
+  const int my_tiles = (ntiles - first + G - 1) / G;
+  const int total = my_tiles * nkt;
+
+  if (wave >= 4) {
+    // ================================================================ loader waves
+    const int lw = wave - 4;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, xbytes), wr = make_rsrc(W, wbytes);
+    const int lrow = lane >> 3;
+    const int kch = (lane & 7) ^ lrow;        // logical 16-byte chunk this lane fetches
+    unsigned xoff[XP], woff[WP];
+    bool xin[XP], win[WP];
+    int py[XP], px[XP];
+    int is_tile = first, is_kt = 0, is_slot = 0;
+    bool is_live = true;
+    auto enter_tile = [&]() __attribute__((always_inline)) {
+      const int tn = is_tile % tiles_n, tm = is_tile / tiles_n;
+      const int m0 = tm * BM, n0 = tn * BN_;
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        const int m = m0 + lw * 32 + p * 8 + lrow;
+        xin[p] = m < M;
+        if constexpr (CONV) {
+          const int hw = g.H * g.W;
+          const int b = m / hw, rem = m - b * hw;
+          py[p] = rem / g.W; px[p] = rem - py[p] * g.W;
+          xoff[p] = (unsigned)m;
+        } else {
+          py[p] = 0; px[p] = 0;
+          xoff[p] = (unsigned)(((long)m * ldx + kch * 8) * 2);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < WP; ++p) {
+        const int i = lw * WROWS + p * 8 + lrow;              // row of the W image (permuted: see gemm_nt_v3)
+        const int half = i / (16 * NB), l = i - half * (16 * NB), ni = l >> 4, j = l & 15;
+        const int n = n0 + half * (16 * NB) + (ni >> 1) * 32 + (j >> 2) * 8 + (ni & 1) * 4 + (j & 3);
+        win[p] = n < N;
+        woff[p] = (unsigned)(((long)n * K + kch * 8) * 2);
+      }
+    };
+    enter_tile();
+    auto issue_group = [&]() __attribute__((always_inline)) {
+      char* st = smem + is_slot * STAGE;
+      const int k0 = is_kt * 64 + kch * 8;
+      const bool kin = is_live && k0 < K;
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        unsigned off;
+        if constexpr (CONV) off = x_chunk_off<T, true>((int)xoff[p], k0, ldx, g, py[p], px[p]);
+        else off = xoff[p] + (unsigned)is_kt * 128u;
+        lds_dma16(xr, st + (lw * 32 + p * 8) * RB, (kin && xin[p]) ? off : OOB);
+      }
+#pragma unroll
+      for (int p = 0; p < WP; ++p)
+        lds_dma16(wr, st + (BM + lw * WROWS + p * 8) * RB, (kin && win[p]) ? woff[p] + (unsigned)is_kt * 128u : OOB);
+      is_slot = is_slot + 1 == NS ? 0 : is_slot + 1;
+      if (++is_kt == nkt) {
+        is_kt = 0; is_tile += G;
+        if (is_tile < ntiles) enter_tile(); else is_live = false;
+      }
+    };
+#pragma unroll 1
+    for (int i = 0; i < NS; ++i) issue_group();
+    wait_vm_only<(NS - 1) * NP>();          // group 0
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int k = 0; k < total; ++k) {
+      wait_vm_only<(NS - 2) * NP>();        // group k+1 (two younger groups stay in flight)
+      __builtin_amdgcn_s_barrier();         // B_k
+      issue_group();                        // group k+4 -> the slot of stage k
+    }
+    wait_vm_only<0>();                      // the trailing no-op pieces
+    return;
+  }
+
+  // ================================================================== multiplying waves
+  const int wn = wave & 1, wm = wave >> 1;
+  f32x4 acc[NB][4];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r15 = lane & 15, q = lane >> 4;
+  const int fro = r15 * RB + ((q ^ (r15 & 7)) << 4);        // this lane's fragment chunk inside a 16-row block (k half 1: ^ 64)
+  const int boff = (wm * 64) * RB + fro, aoff = (BM + wn * (16 * NB)) * RB + fro;
+  bf16x8_t fa0[NB], fb0[4], fa1[NB], fb1[4];
+  auto read_frag = [&](bf16x8_t* fa, bf16x8_t* fb, const char* st, int sub, int r) __attribute__((always_inline)) {
+    const int x = sub * 64;
+    if (r < 4) fb[r] = *reinterpret_cast<const bf16x8_t*>(st + ((boff + r * 16 * RB) ^ x));
+    else fa[r - 4] = *reinterpret_cast<const bf16x8_t*>(st + ((aoff + (r - 4) * 16 * RB) ^ x));
+  };
+  constexpr int NH = NB * 4, NR = NB + 4;   // MFMAs / fragment reads per half step
+  const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, pe.c_bytes), c2r = make_rsrc(epi.C2, pe.c2_bytes);
+  const __amdgpu_buffer_rsrc_t rr = make_rsrc(epi.residual, pe.r_bytes), hr = make_rsrc(epi.gelu_h, pe.h_bytes);
+  const __amdgpu_buffer_rsrc_t br = make_rsrc(epi.bias, pe.bias_bytes);
+  constexpr int NV = NB / 2;                                 // 16-byte vectors per lane and m block
+  int tile = first, kt = 0, slot = 0;
+  int ncol = 0, mrow = 0;
+  unsigned eo[4];
+  u32x4 er[4][NV], eh[4][NV];
+  f32x4 eb[NB];
+  auto epi_request = [&]() __attribute__((always_inline)) {
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    ncol = tn * BN_ + wn * (16 * NB) + q * 8;              // first of this lane's 8 consecutive columns of vector 0 (vector v: + 32 v)
+    mrow = tm * BM + wm * 64 + r15;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const bufvec_t b = __builtin_amdgcn_raw_buffer_load_b128(br, (unsigned)((ncol + 32 * (i >> 1) + 4 * (i & 1)) * 4), 0, 0);
+      eb[i] = f32x4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = mrow + mi * 16;
+      eo[mi] = (m < M) ? (unsigned)(((long)m * ldc + ncol) * 2) : OOB;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
+        er[mi][v] = bload16(rr, o);
+        if constexpr (ACT == PIPE_ACT_HH) eh[mi][v] = bload16(hr, o);
+      }
+    }
+  };
+  auto epi_run = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float ev[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ev[e] = acc[2 * v][mi][e] + eb[2 * v][e];
+          ev[4 + e] = acc[2 * v + 1][mi][e] + eb[2 * v + 1][e];
+        }
+        acc[2 * v][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[2 * v + 1][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
+        if constexpr (ACT == PIPE_ACT_GELU) {
+          bstore16(c2r, o, pack16<T>(ev));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ev[e] = gelu_f(ev[e]);
+        }
+        if constexpr (ACT == PIPE_ACT_HH) {
+          float h[8];
+          unpack16<T>(eh[mi][v], h);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ev[e] *= gelu_grad_f(h[e]);
+        }
+        float rres[8];
+        unpack16<T>(er[mi][v], rres);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ev[e] += rres[e];
+        bstore16(cr, o, pack16<T>(ev));
+      }
+    }
+  };
+
+  __builtin_amdgcn_s_barrier();             // group 0 has landed
+#pragma unroll
+  for (int r = 0; r < NR; ++r) read_frag(fa0, fb0, smem, 0, r);
+#pragma unroll 1
+  for (int gs = 0; gs < total; ++gs) {
+    const char* st = smem + slot * STAGE;
+    const int nslot = slot + 1 == NS ? 0 : slot + 1;
+    const char* nst = smem + nslot * STAGE;
+    const bool last = kt + 1 == nkt;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // half 0's fragments (read during the previous step's second half)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      acc[i >> 2][i & 3] = Mma<T>::mma(fa0[i >> 2], fb0[i & 3], acc[i >> 2][i & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        if (r * NH / NR == i) read_frag(fa1, fb1, st, 1, r);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // stage k has been read completely
+    __builtin_amdgcn_s_barrier();                          // B_k
+    __builtin_amdgcn_sched_barrier(0);
+    if (last) epi_request();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      acc[i >> 2][i & 3] = Mma<T>::mma(fa1[i >> 2], fb1[i & 3], acc[i >> 2][i & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        if (r * NH / NR == i) read_frag(fa0, fb0, nst, 0, r);   // (after the last step: a stale stage, unused)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (last) {
+      epi_run();
+      kt = 0; tile += G;
+    } else {
+      ++kt;
+    }
+    slot = nslot;
+  }
+}
+
+#endif  // SPG_DEV_KERNELS (gemm_nt_v5)
+
 // TN: dW[n][k] += sum_m dY[m][n] * X[m][k].  LDS rows are output features (n for the dY operand, k for the
 // X operand), 128 bytes of consecutive m per row; register transpose of 4(m) x 16-byte patches.
 // swizzle for these images: sw(f) = (f ^ (f >> 4)) & 7 -> fragment reads conflict free, patch writes 2-way.
@@ -1702,6 +1940,207 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
     if (gc + 1 < total) step(fb, fa);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn_pipe4_kernel: gemm_tn_pipe_kernel's schedule (units = tile x M split, partial sums to the split's slab) with SPECIALISED
+// waves -- waves 0-3 multiply a 64 x 64 quarter of the tile each, waves 4-7 only issue the LDS-DMA fill (and, for the 3x3
+// convolution, the gather arithmetic); see gemm_tn_group4_kernel for the measurements behind the split and for the hand-off.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool CONV>
+__global__ __launch_bounds__(512) void gemm_tn_pipe4_kernel(const T* __restrict__ dY, const T* __restrict__ X, int M, int N, int K, int ldy,
+                                                            int ldx, ConvGeom g, int tiles_k, int tiles, int splits, int m_per_split,
+                                                            unsigned ybytes, unsigned xbytes, float* __restrict__ dbias,
+                                                            float* __restrict__ slabs, unsigned slab_bytes) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  using F = TnFrag<T>;
+  constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = (int)gridDim.x;
+  const int first = xcd_remap(blockIdx.x, G);
+  const int units = tiles * splits;
+  if (first >= units) return;
+  const int my_units = (units - first + G - 1) / G;
+  const int nsteps = m_per_split / MSTEP;
+  const int total = my_units * nsteps;
+
+  if (wave >= 4) {
+    // ================================================================ loader waves: pieces {lw, lw + 4, lw + 8, lw + 12} of both operands
+    const int lw = wave - 4;
+    const rsrc_words_t yr = make_rsrc_words(dY, ybytes), xr = make_rsrc_words(X, xbytes);
+    const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    const int lrow = lane >> 4, lpc = lane & 15;
+    const int prow0 = lw * 4 + lrow;                              // row (mod 16) of this lane's pieces
+    const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;   // logical feature column stored at physical chunk lpc
+    int is_step = 0, is_unit = first, is_slot = 0;
+    bool is_live = true, is_yin = false, is_xin = false;
+    unsigned yoff = 0, xoff = 0;
+    const unsigned ystride = (unsigned)(MSTEP * ldy * 2), xstride = (unsigned)(MSTEP * ldx * 2);
+    const unsigned y16 = (unsigned)(16 * ldy * 2), x16 = (unsigned)(16 * ldx * 2);
+    int cv_dy = 0, cv_dx = 0, cv_m = 0;
+    long cv_delta = 0;
+    const int cv_hw = g.H * g.W;
+    const float cv_rhw = 1.f / (float)(CONV ? cv_hw : 1), cv_rw = 1.f / (float)(CONV ? g.W : 1);
+    auto enter_unit = [&]() __attribute__((always_inline)) {
+      const int tile = is_unit % tiles, split = is_unit / tiles;
+      const int tk = tile % tiles_k, tn = tile / tiles_k;
+      const int n0 = tn * 128, k0 = tk * 128;
+      const long m0 = (long)split * m_per_split + prow0;
+      yoff = (unsigned)((m0 * ldy + n0 + fcol) * 2);
+      is_yin = n0 + fcol < N; is_xin = k0 + fcol < K;
+      if constexpr (!CONV) {
+        xoff = (unsigned)((m0 * ldx + k0 + fcol) * 2);
+      } else {
+        const int kk = k0 + fcol;
+        const int tap = kk / g.Ci, ci = kk - tap * g.Ci;
+        cv_dy = tap / 3 - 1; cv_dx = tap - (tap / 3) * 3 - 1;
+        cv_delta = ((long)(cv_dy * g.W + cv_dx) * g.Ci + ci) * 2;
+        cv_m = (int)m0;
+      }
+    };
+    enter_unit();
+    auto issue_group = [&]() __attribute__((always_inline)) {   // rows past M fall outside the descriptors: hardware zero fill
+      const unsigned st = smem_base + is_slot * STAGE_B + lw * 1024;
+      const bool yl = is_live && is_yin, xl = is_live && is_xin;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dma16_asm(yr, st + j * 4096, yl ? yoff + j * y16 : OOB);
+        unsigned xo;
+        if constexpr (!CONV) {
+          xo = xl ? xoff + j * x16 : OOB;
+        } else {
+          const int m = cv_m + 16 * j;
+          const int bimg = div_small(m, cv_hw, cv_rhw);
+          const int pix = m - bimg * cv_hw;
+          const int y = div_small(pix, g.W, cv_rw), x = pix - y * g.W;
+          const bool ok = xl && m < M && (unsigned)(y + cv_dy) < (unsigned)g.H && (unsigned)(x + cv_dx) < (unsigned)g.W;
+          xo = ok ? (unsigned)((long)m * g.Ci * 2 + cv_delta) : OOB;
+        }
+        dma16_asm(xr, st + 16384 + j * 4096, xo);
+      }
+      is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+      const bool wrap = is_step + 1 == nsteps;
+      yoff += ystride; xoff += xstride; cv_m += MSTEP;
+      is_step = wrap ? 0 : is_step + 1;
+      is_unit = wrap ? is_unit + G : is_unit;
+      if (wrap) { if (is_unit < units) enter_unit(); else is_live = false; }
+    };
+#pragma unroll 1
+    for (int i = 0; i < STAGES; ++i) issue_group();
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");       // group 0
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int k = 0; k < total; ++k) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // group k+1 (groups k+2, k+3 stay in flight)
+      __builtin_amdgcn_s_barrier();                         // B_k
+      issue_group();                                        // group k+4 -> the slot of stage k
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing no-op pieces
+    return;
+  }
+
+  // ================================================================== multiplying waves
+  const int wn = wave & 1, wk = wave >> 1;
+  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
+  int oa[2][4][2], ob[2][4][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      F::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
+      F::offsets(s2, wk * 64 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
+    }
+  struct Frags { s16x4_t a[2][4][2], b[2][4][2]; };   // fragments as their two transpose-read halves: one read per MFMA slot
+  Frags fa, fb;
+  auto read_half = [&](Frags& f, const char* st, int t) __attribute__((always_inline)) {   // t-th of the 32 reads of a step
+    const int idx = t >> 1, h = t & 1, sx = idx >> 3, r = idx & 7;
+    if (r < 4) f.b[sx][r][h] = F::load_half(st + 16384, ob[sx][r][h]);
+    else f.a[sx][r - 4][h] = F::load_half(st, oa[sx][r - 4][h]);
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum0 = 0.f, bsum1 = 0.f;
+  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+
+  __builtin_amdgcn_s_barrier();                             // group 0 has landed
+#pragma unroll
+  for (int i = 0; i < 32; ++i) read_half(fa, smem, i);
+
+  int st_i = 0, unit = first, rd_slot = 1;
+  int c_tk, c_tn, c_split;
+  auto locate = [&](int u, int& tn, int& tk, int& split) __attribute__((always_inline)) {
+    const int tile = u % tiles;
+    split = u / tiles; tn = tile / tiles_k; tk = tile - tn * tiles_k;
+  };
+  locate(unit, c_tn, c_tk, c_split);
+  const int r15 = lane & 15, q = lane >> 4;
+  auto step = [&](Frags& cur, Frags& nxt) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this step's fragments (and with them: stage k has been read)
+    __builtin_amdgcn_s_barrier();                           // B_k
+    __builtin_amdgcn_sched_barrier(0);
+    const bool last = __builtin_amdgcn_readfirstlane(st_i + 1) == nsteps;
+    const bool bias_unit = dbias != nullptr && c_tk == 0;
+    const char* rst = smem + rd_slot * STAGE_B;
+    int n_tn = c_tn, n_tk = c_tk, n_split = c_split;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int ms = i >> 4, r = i & 15, ni = r >> 2, ki = r & 3;
+      const typename F::Frag fb_ = F::join(cur.b[ms][ki][0], cur.b[ms][ki][1]), fa_ = F::join(cur.a[ms][ni][0], cur.a[ms][ni][1]);
+      acc[ni][ki] = Mma<T>::mma(fb_, fa_, acc[ni][ki]);       // D[k][n]: 4 consecutive k per lane
+      __builtin_amdgcn_sched_barrier(0);
+      read_half(nxt, rst, i);   // (unconditional: past the last step this reads a stale stage into registers nobody uses)
+      if (i == 18 && last) locate(unit + G, n_tn, n_tk, n_split);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (bias_unit) {   // column sums of dY over this step's 64 rows: this wave's two 16-column blocks of its n half
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        const typename F::Frag v0 = wk == 0 ? F::join(cur.a[ms][0][0], cur.a[ms][0][1]) : F::join(cur.a[ms][2][0], cur.a[ms][2][1]);
+        const typename F::Frag v1 = wk == 0 ? F::join(cur.a[ms][1][0], cur.a[ms][1][1]) : F::join(cur.a[ms][3][0], cur.a[ms][3][1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2_t p0 = {v0[2 * e], v0[2 * e + 1]}, p1 = {v1[2 * e], v1[2 * e + 1]};
+          bsum0 = __builtin_amdgcn_fdot2_f32_bf16(p0, ones2, bsum0, false);
+          bsum1 = __builtin_amdgcn_fdot2_f32_bf16(p1, ones2, bsum1, false);
+        }
+      }
+    }
+    if (last) {
+      const int n0 = c_tn * 128 + wn * 64, k0 = c_tk * 128 + wk * 64;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+          const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
+          const unsigned o = (n < N && k < K) ? (unsigned)((((long)c_split * N + n) * K + k) * 4) : OOB;   // K % 4 == 0
+          bstore16(sr, o, u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]), __float_as_uint(acc[ni][ki][2]),
+                                __float_as_uint(acc[ni][ki][3])});
+          acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      if (bias_unit) {   // fold the 4 m groups of a column (lanes l, l+16, l+32, l+48), then one atomic per column
+        float b0 = bsum0, b1 = bsum1;
+        b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
+        b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
+        const int n = n0 + wk * 32 + r15;
+        if (q == 0 && n < N) atomicAdd(dbias + n, b0);
+        if (q == 0 && n + 16 < N) atomicAdd(dbias + n + 16, b1);
+      }
+      bsum0 = 0.f; bsum1 = 0.f;
+    }
+    st_i = last ? 0 : st_i + 1;
+    unit = last ? unit + G : unit;
+    c_tn = n_tn; c_tk = n_tk; c_split = n_split;
+    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
+  };
+  for (int gc = 0; gc < total; gc += 2) {
+    step(fa, fb);
+    if (gc + 1 < total) step(fb, fa);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2747,6 +3186,12 @@ static inline int nt_v3_mode() {
 #endif
 }
 static inline bool nt_v3_enabled() { return nt_v3_mode() != 0; }
+#ifdef SPG_DEV_KERNELS
+static inline int nt_v5_mode() {   // SPG_NT_V5: 1 routes every applicable NT problem to gemm_nt_v5, 2 only the long-K ones, 0 none
+  static const int v = dev_env("SPG_NT_V5", 0);
+  return v;
+}
+#endif
 static inline bool tn_group_v4() {   // dev builds: SPG_TN_GROUP_V4=0 selects the 8-wave kernel (A/B runs)
 #ifdef SPG_DEV_KERNELS
   static const int v = dev_env("SPG_TN_GROUP_V4", 1);
@@ -2794,7 +3239,7 @@ constexpr int NT_V3_NA = -1000;
 #endif
 constexpr int V3_KS = SPG_V3_KS, V3_NS = SPG_V3_NS;      // 2 stages of 32 KiB (NB = 4): 64 KiB per workgroup, two workgroups per CU
 static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M, int N, int K, int ldx, int ldc, int conv, ConvGeom g,
-                        hipStream_t s) {
+                        hipStream_t s, int cu_budget) {
   const int tiles_m = cdiv(M, BM);
   const long xb = (conv ? (long)M * g.Ci : (long)M * ldx) * 2L, wb = (long)N * K * 2L;
   const long cb = ((long)(M - 1) * ldc + N) * 2;
@@ -2818,6 +3263,32 @@ static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M,
       // one 4-wave workgroup per CU, or with long K loops where the persistent kernel's three DMA groups in flight pay (fc2, dqkv,
       // the CFI fusion GEMM), it loses 10-60 %.  Dispatch on exactly that.
       const int cus3 = hw_cus();
+#ifdef SPG_DEV_KERNELS
+      if (nt_v5_mode() == 1 || (nt_v5_mode() == 2 && !conv && K > 1536)) {   // A/B runs of the specialised-wave NT kernel
+        const int cus5 = num_cus(cu_budget);
+        const int grid5 = grid3 < cus5 ? grid3 : cus5;
+#define SPG_LAUNCH5(C_, A_, NB_)                                                                                                           \
+  do {                                                                                                                                     \
+    constexpr int lds_ = 4 * (BM + 32 * NB_) * 128;                                                                                        \
+    static bool attr_ = false;                                                                                                             \
+    if (!attr_) {                                                                                                                          \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v5_kernel<C_, A_, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+      attr_ = true;                                                                                                                        \
+    }                                                                                                                                      \
+    hipLaunchKernelGGL((gemm_nt_v5_kernel<C_, A_, NB_>), dim3(grid5), dim3(512), lds_, s, (const bf16_t*)X, (const bf16_t*)W, (bf16_t*)C, \
+                       epi, pe, M, N, K, ldx, ldc, g, tn3, grid3, (unsigned)xb, (unsigned)wb);                                             \
+  } while (0)
+#define SPG_LAUNCH5_NB(C_, A_) \
+  do { if (nb3 == 4) SPG_LAUNCH5(C_, A_, 4); else SPG_LAUNCH5(C_, A_, 2); } while (0)
+        if (conv) SPG_LAUNCH5_NB(true, PIPE_ACT_NONE);
+        else if (pact == PIPE_ACT_GELU) SPG_LAUNCH5_NB(false, PIPE_ACT_GELU);
+        else if (pact == PIPE_ACT_HH) SPG_LAUNCH5_NB(false, PIPE_ACT_HH);
+        else SPG_LAUNCH5_NB(false, PIPE_ACT_NONE);
+#undef SPG_LAUNCH5_NB
+#undef SPG_LAUNCH5
+        return check_launch("gemm_nt(v5)");
+      }
+#endif
       if (nt_v3_mode() == 1 && (grid3 < cus3 + cus3 / 4 || K > 1536)) return NT_V3_NA;
 #define SPG_LAUNCH3(C_, A_, NB_)                                                                                                           \
   do {                                                                                                                                     \
@@ -2855,7 +3326,7 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     return SPG_ERR_UNSUPPORTED;
   }
   if constexpr (sizeof(T) == 2) {
-    const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s);
+    const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s, cu_budget);
     if (rc3 != NT_V3_NA) return rc3;
   }
   if (dev_env("SPG_GEMM_STAGED", 0) == 0) {
@@ -3034,7 +3505,7 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE) && (epi.C2 == nullptr || pact == PIPE_ACT_GELU) &&
                         !(conv && pact != PIPE_ACT_NONE);
     {
-      const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s);
+      const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s, cu_budget);
       if (rc3 != NT_V3_NA) return rc3;
     }
     if (K > ROWB / (int)sizeof(T) && N % 8 == 0 && ldc % 8 == 0 && cb < 0xFFFFFFF0L && epi_ok) {
@@ -3153,7 +3624,20 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe_kernel<T, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
           attrp = true;
         }
-        if (conv)
+        if (tn_group_v4()) {   // specialised waves (dev builds: SPG_TN_GROUP_V4=0 selects the 8-wave kernels)
+          static bool attr4 = false;
+          if (!attr4) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe4_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe4_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+            attr4 = true;
+          }
+          if (conv)
+            hipLaunchKernelGGL((gemm_tn_pipe4_kernel<T, true>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, g,
+                               tiles_k, tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
+          else
+            hipLaunchKernelGGL((gemm_tn_pipe4_kernel<T, false>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, g,
+                               tiles_k, tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
+        } else if (conv)
           hipLaunchKernelGGL((gemm_tn_pipe_kernel<T, true, 0>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, g,
                              tiles_k, tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
         else
