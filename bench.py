@@ -273,7 +273,22 @@ def main():
                 a.record(); b.record(); pairs.append((a, b))
             torch.cuda.synchronize()
             gaps = sorted(a.elapsed_time(b) * 1e-3 for a, b in pairs)
-            bracket_s = gaps[len(gaps) // 2]
+            empty_s = gaps[len(gaps) // 2]
+            # ... but around a KERNEL part of that cost overlaps the kernel's own execution (the empty pair over-corrected the
+            # round-1/2 lines by ~2 us against rocprofv3).  Two-point calibration instead: intervals around spin kernels of n and 2n
+            # cycles are E1 = b + T and E2 = b + 2T, so b = 2 E1 - E2 without knowing T.
+            n_spin = int(0.02 * spin_cycles_per_ms)        # ~20 us
+            torch.cuda._sleep(int(20 * spin_cycles_per_ms))
+            p1, p2 = [], []
+            for _ in range(48):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); torch.cuda._sleep(n_spin); b.record(); p1.append((a, b))
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); torch.cuda._sleep(2 * n_spin); b.record(); p2.append((a, b))
+            torch.cuda.synchronize()
+            e1 = sorted(a.elapsed_time(b) * 1e-3 for a, b in p1)[len(p1) // 2]
+            e2 = sorted(a.elapsed_time(b) * 1e-3 for a, b in p2)[len(p2) // 2]
+            bracket_s = min(max(2 * e1 - e2, 0.0), empty_s)
             ops.PROFILE = []
             for _ in range(2):
                 torch.cuda._sleep(int(150 * spin_cycles_per_ms))
@@ -287,7 +302,7 @@ def main():
             roof = {"bound": "mfma", "kernel": "gemm_nt<%s,dense>: gemm_nt_pipe_kernel + gemm_nt_v3_kernel (all dense gemm_nt launches: Linear / 1x1 conv fwd + dgrad)" % args.dtype,
                     "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
                     "traffic_source": src, "launches": int(dom["launches_per_step"] * 2), "avg_launch_us": dom["avg_us"],
-                    "event_bracket_us": round(bracket_s * 1e6, 2), "flop_per_launch_avg": dom["work_per_launch"],
+                    "event_bracket_us": round(bracket_s * 1e6, 2), "event_empty_pair_us": round(empty_s * 1e6, 2), "flop_per_launch_avg": dom["work_per_launch"],
                     # every instrumented op of the step (2 eager steps, HIP events on the launch stream): recompute frac = achieved / peak,
                     # achieved = work_per_launch / avg_us
                     "kernels": rows}
