@@ -195,14 +195,23 @@ int spg_upsample_bilinear(int dtype, const void* x, void* y, int B, int h, int w
                           int c0, spg_stream_t stream);
 int spg_upsample_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int h, int w, int C, int H, int W, int ldy,
                               int c0, int accumulate, spg_stream_t stream);
-int spg_se_fc(const float* gap, const float* w1, const float* w2, float* hidden, float* scale, int B, int C, int R,
+/* in_scale multiplies gap on load: pass the per-image column SUMS of spg_gap_sum and 1 / HW (the squeeze is a mean,
+ * feature_integration.py SE block); dgap of se_fc_bwd is the gradient w.r.t. the scaled input.                                    */
+int spg_se_fc(const float* gap, const float* w1, const float* w2, float* hidden, float* scale, int B, int C, int R, float in_scale,
               spg_stream_t stream);
 /* reductions across workgroups below are deterministic (partials + fixed-order finish by the last workgroup): red_ws is scratch of the
  * stated size, red_counter ONE 32-bit word that is zero before its first use (see "Deterministic reductions").
  * se_fc_bwd: B*(C+R) floats.  dwconv3x3_wgrad: 64*9*C floats.  easpp_fuse_bwd: 32*B*6*C floats (dglob is overwritten).            */
 int spg_se_fc_bwd(const float* gap, const float* w1, const float* w2, const float* hidden, const float* scale,
-                  const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, float* red_ws, long red_ws_floats,
-                  unsigned* red_counter, spg_stream_t stream);
+                  const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, float in_scale, float* red_ws,
+                  long red_ws_floats, unsigned* red_counter, spg_stream_t stream);
+/* dst[R][Kp] (dtype) = [a[R][na] | b[R][nb] | 0]: the position-embedding GEMM's weight operand [pos_embed | pos_embed_window]
+ * (reference: sam2 Hiera._get_pos_embed via feature_encoding.py:236) packed in ONE launch per step.                               */
+int spg_pack_cols2(int dtype, const float* a, int na, const float* b, int nb, void* dst, int R, int Kp, spg_stream_t stream);
+/* up to 4 jobs of dst[r][c] += src[r][c], c < C (row strides ldd / lds): column slices of padded weight-gradient results into the
+ * gradients of patch_embed.proj.weight / pos_embed / pos_embed_window.                                                            */
+int spg_add_cols_batch(int njobs, float* const* dst, const float* const* src, const int* R, const int* C, const int* ldd,
+                       const int* lds, spg_stream_t stream);
 int spg_chan_scale(int dtype, const void* x, const float* scale, void* y, int B, long HW, int C, spg_stream_t stream);
 int spg_chan_scale_bwd(int dtype, const void* dy, const float* scale, const float* dgap, void* dx, int B, long HW,
                        int C, spg_stream_t stream);

@@ -53,8 +53,10 @@ SIGNATURES = {
     "spg_bn_bwd_apply": "ippppppppp" "liip",
     "spg_upsample_bilinear": "ipp" "iiiiiiiip",
     "spg_upsample_bilinear_bwd": "ipp" "iiiiiiiiip",
-    "spg_se_fc": "ppppp" "iiip",
-    "spg_se_fc_bwd": "ppppppppp" "iii" "plp" "p",
+    "spg_se_fc": "ppppp" "iiifp",
+    "spg_se_fc_bwd": "ppppppppp" "iiif" "plp" "p",
+    "spg_pack_cols2": "ipipi" "piip",
+    "spg_add_cols_batch": "ipppppp" "p",
     "spg_chan_scale": "ippp" "ilip",
     "spg_chan_scale_bwd": "ipppp" "ilip",
     "spg_dwconv3x3": "ippp" "iiiiiip",

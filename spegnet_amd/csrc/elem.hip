@@ -214,11 +214,11 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
 // ---- SE excitation (per image): hidden = relu(W1 gap), scale = sigmoid(W2 hidden) ---------------------------
 __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
                                                     const float* __restrict__ w2, float* __restrict__ hidden,
-                                                    float* __restrict__ scale, int C, int R) {
+                                                    float* __restrict__ scale, int C, int R, float in_scale) {
   extern __shared__ float sm[];  // gap[C] + hidden[R]
   const int b = blockIdx.x;
   float* g = sm; float* h = sm + C;
-  for (int c = threadIdx.x; c < C; c += 256) g[c] = gap[(long)b * C + c];
+  for (int c = threadIdx.x; c < C; c += 256) g[c] = gap[(long)b * C + c] * in_scale;   // (in_scale = 1 / HW: gap holds column SUMS)
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = wave; r < R; r += 4) {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ scale, const float* __restrict__ dscale,
                                                         float* __restrict__ dgap, float* __restrict__ dw1,
                                                         float* __restrict__ dw2, int C, int R, float* __restrict__ ws,
-                                                        unsigned* __restrict__ counter) {
+                                                        unsigned* __restrict__ counter, float in_scale) {
   extern __shared__ float sm[];  // dz[C] + dh[R]
   __shared__ unsigned s_last;
   const int b = blockIdx.x, B = gridDim.x;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
     float s2 = 0.f, s1 = 0.f;
     for (int bb = 0; bb < B; ++bb) {
       s2 += gdz[(long)bb * C + c] * hidden[(long)bb * R + r];
-      s1 += gdh[(long)bb * R + r] * gap[(long)bb * C + c];
+      s1 += gdh[(long)bb * R + r] * (gap[(long)bb * C + c] * in_scale);
     }
     dw2[(long)c * R + r] += s2;
     dw1[(long)r * C + c] += s1;
@@ -575,6 +575,30 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const T* __restrict__ 
   finish_partials<256>(part + C, gridDim.x, C + 1, 1, db, 1, red);
 }
 
+
+// dst[r][0..Kp) = cast(a[r][0..na) | b[r][0..nb) | zeros): the position-embedding GEMM's weight operand [pos_embed | pos_embed_window]
+template <typename T>
+__global__ __launch_bounds__(256) void pack_cols2_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
+                                                         T* __restrict__ dst, int R, int Kp) {
+  const long total = (long)R * Kp;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / Kp), k = (int)(i - (long)r * Kp);
+    const float v = k < na ? a[(long)r * na + k] : (k < na + nb ? b[(long)r * nb + (k - na)] : 0.f);
+    ST<T>::st(dst + i, v);
+  }
+}
+// up to 4 jobs of dst[r][c] += src[r][c] (c < C; row strides ldd / lds) in one launch: column slices of padded wgrad results into
+// their parameters' gradients
+struct AddColsJob { float* dst; const float* src; int R, C, ldd, lds; };
+struct AddColsBatch { AddColsJob job[4]; int njobs; };
+__global__ __launch_bounds__(256) void add_cols_batch_kernel(AddColsBatch bt) {
+  const AddColsJob& j = bt.job[blockIdx.y];
+  const long total = (long)j.R * j.C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / j.C), c = (int)(i - (long)r * j.C);
+    j.dst[(long)r * j.ldd + c] += j.src[(long)r * j.lds + c];
+  }
+}
 }  // namespace spg
 
 using namespace spg;
@@ -764,17 +788,39 @@ extern "C" int spg_preprocess_image(const uint8_t* img_hwc, float* out_chw, int 
   return check_launch("preprocess_image");
 }
 
+extern "C" int spg_pack_cols2(int dtype, const float* a, int na, const float* b, int nb, void* dst, int R, int Kp, spg_stream_t stream) {
+  SPG_REQUIRE(R > 0 && na >= 0 && nb >= 0 && na + nb <= Kp, "pack_cols2: %d + %d columns do not fit %d", na, nb, Kp);
+  const long total = (long)R * Kp;
+  if (dtype == SPG_BF16) hipLaunchKernelGGL(pack_cols2_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, (bf16_t*)dst, R, Kp);
+  else hipLaunchKernelGGL(pack_cols2_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, (float*)dst, R, Kp);
+  return check_launch("pack_cols2");
+}
+extern "C" int spg_add_cols_batch(int njobs, float* const* dst, const float* const* src, const int* R, const int* C, const int* ldd,
+                                  const int* lds, spg_stream_t stream) {
+  SPG_REQUIRE(njobs >= 1 && njobs <= 4, "add_cols_batch: 1..4 jobs, got %d", njobs);
+  AddColsBatch bt;
+  long mx = 0;
+  for (int i = 0; i < njobs; ++i) {
+    SPG_REQUIRE(R[i] > 0 && C[i] > 0 && ldd[i] >= C[i] && lds[i] >= C[i], "add_cols_batch: job %d: bad extents", i);
+    bt.job[i] = AddColsJob{dst[i], src[i], R[i], C[i], ldd[i], lds[i]};
+    mx = (long)R[i] * C[i] > mx ? (long)R[i] * C[i] : mx;
+  }
+  for (int i = njobs; i < 4; ++i) bt.job[i] = bt.job[0];
+  bt.njobs = njobs;
+  hipLaunchKernelGGL(add_cols_batch_kernel, dim3(ew_grid(mx), njobs), dim3(256), 0, (hipStream_t)stream, bt);
+  return check_launch("add_cols_batch");
+}
 extern "C" int spg_se_fc(const float* gap, const float* w1, const float* w2, float* hidden, float* scale, int B, int C, int R,
-                         spg_stream_t stream) {
-  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, C, R);
+                         float in_scale, spg_stream_t stream) {
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, C, R, in_scale);
   return check_launch("se_fc");
 }
 extern "C" int spg_se_fc_bwd(const float* gap, const float* w1, const float* w2, const float* hidden, const float* scale,
-                             const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, float* red_ws,
+                             const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, float in_scale, float* red_ws,
                              long red_ws_floats, unsigned* red_counter, spg_stream_t stream) {
   SPG_REQUIRE(red_ws && red_counter && red_ws_floats >= (long)B * (C + R), "se_fc_bwd: needs B*(C+R) floats of scratch and one zeroed counter");
   hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, dscale, dgap, dw1, dw2, C, R,
-                     red_ws, red_counter);
+                     red_ws, red_counter, in_scale);
   return check_launch("se_fc_bwd");
 }
 extern "C" int spg_chan_scale(int dtype, const void* x, const float* scale, void* y, int B, long HW, int C, spg_stream_t stream) {

@@ -308,10 +308,7 @@ class Engine:
         e = "encoder.encoder."
         n_b, n_w, Kp = self._basis_dims
         C = self.cfg["embed_dim"]
-        m = torch.zeros((C, Kp), dtype=torch.float32, device=self.P[e + "pos_embed"].device)
-        m[:, :n_b] = self.P[e + "pos_embed"].detach().view(C, n_b)
-        m[:, n_b:n_b + n_w] = self.P[e + "pos_embed_window"].detach().view(C, n_w)
-        return m.to(self.dtype)
+        return ops.pack_cols2(self.P[e + "pos_embed"].detach().view(C, n_b), self.P[e + "pos_embed_window"].detach().view(C, n_w), Kp, self.dtype)
 
     def trunk_fwd(self, img: Tensor, training: bool, save: bool):
         e = "encoder.encoder."
@@ -444,12 +441,11 @@ class Engine:
         d2 = dx.reshape(-1, D)
         pw = ops.zeros_f32((D, PATCH_KPAD), dx.device)
         ops.gemm_tn(d2, ctx["cols"], pw, dbias=self.grad(e + "patch_embed.proj.bias"))
-        self.grad(e + "patch_embed.proj.weight").view(D, 147).add_(pw[:, :147])
         n_b, n_w, Kp = self._basis_dims
         gpos = ops.zeros_f32((D, Kp), dx.device)
         ops.gemm_tn(d2, ctx["basis"], gpos)
-        self.grad(e + "pos_embed").view(D, n_b).add_(gpos[:, :n_b])
-        self.grad(e + "pos_embed_window").view(D, n_w).add_(gpos[:, n_b:n_b + n_w])
+        ops.add_cols_batch([(self.grad(e + "patch_embed.proj.weight").view(D, 147), pw), (self.grad(e + "pos_embed").view(D, n_b), gpos),
+                            (self.grad(e + "pos_embed_window").view(D, n_w), gpos[:, n_b:])])
         self._bw = None
         self.join_wgrad()
 
@@ -488,8 +484,8 @@ class Engine:
         y4 = ops.gemm_nt(s4.reshape(-1, C4), W[FUSION_W + ":s4"])
         f0 = ops.cfi_combine(y2, y3, y4, B, h, w, h3, w3, h4, w4, 512)
         f1, c["bn_f"] = self.bn_fwd("fusion.bn.", f0, 512, True, training, save)
-        gap = ops.gap_sum(f1, B, HW, 512) / HW
-        hidden, scale = ops.se_fc(gap, P["fusion.se_block.fc.0.weight"], P["fusion.se_block.fc.2.weight"])
+        gap = ops.gap_sum(f1, B, HW, 512)            # column SUMS: the SE kernels take the 1 / HW of the mean as in_scale
+        hidden, scale = ops.se_fc(gap, P["fusion.se_block.fc.0.weight"], P["fusion.se_block.fc.2.weight"], 1.0 / HW)
         fused = ops.chan_scale(f1, scale, B, HW, 512)
         # --- e-ASPP
         r0 = ops.gemm_nt(fused, W["context.reduce.0.weight"])
@@ -625,7 +621,7 @@ class Engine:
         # --- SE + fusion
         dscale = ops.chan_prod_sum(d_fused, c["f1"], B, HW, 512)
         dgap = ops.se_fc_bwd(c["gap"], P["fusion.se_block.fc.0.weight"], P["fusion.se_block.fc.2.weight"], c["hidden"], c["scale"],
-                             dscale, G("fusion.se_block.fc.0.weight"), G("fusion.se_block.fc.2.weight"))
+                             dscale, G("fusion.se_block.fc.0.weight"), G("fusion.se_block.fc.2.weight"), 1.0 / HW)
         d_f1 = ops.chan_scale_bwd(d_fused, c["scale"], dgap, B, HW, 512)
         d_f0 = self.bn_bwd(c["bn_f"], d_f1)
         # fusion conv backward per source: d_y2 = d_f0, d_y3 / d_y4 = the bilinear adjoints of d_f0 (512 channels at the coarse

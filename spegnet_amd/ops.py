@@ -532,24 +532,44 @@ def upsample_bwd(dy: Tensor, dx: Tensor, B: int, h: int, w: int, C: int, H: int,
     _lib.call("spg_upsample_bilinear_bwd", dcode(dy), _p(_c(dy)), _p(dx), B, h, w, C, H, W, ldy, c0, 1 if accumulate else 0, _stream())
 
 
-def se_fc(gap: Tensor, w1: Tensor, w2: Tensor):
+def se_fc(gap: Tensor, w1: Tensor, w2: Tensor, in_scale: float = 1.0):
+    """SE block FCs on in_scale * gap (pass gap = per-image column sums and in_scale = 1 / HW: no separate mean kernel)."""
     B, C = gap.shape
     R = w1.shape[0]
     hidden = torch.empty((B, R), dtype=torch.float32, device=gap.device)
     scale = torch.empty((B, C), dtype=torch.float32, device=gap.device)
-    _lib.call("spg_se_fc", _p(f32(gap)), _p(f32(w1)), _p(f32(w2)), _p(hidden), _p(scale), B, C, R, _stream())
+    _lib.call("spg_se_fc", _p(f32(gap)), _p(f32(w1)), _p(f32(w2)), _p(hidden), _p(scale), B, C, R, float(in_scale), _stream())
     return hidden, scale
 
 
-def se_fc_bwd(gap, w1, w2, hidden, scale, dscale, dw1, dw2) -> Tensor:
+def se_fc_bwd(gap, w1, w2, hidden, scale, dscale, dw1, dw2, in_scale: float = 1.0) -> Tensor:
     B, C = gap.shape
     R = w1.shape[0]
     dgap = torch.empty_like(gap)
     n = B * (C + R)
     ws = red_scratch(gap.device, n)
     _lib.call("spg_se_fc_bwd", _p(gap), _p(f32(w1)), _p(f32(w2)), _p(hidden), _p(scale), _p(f32(dscale)), _p(dgap), _p(f32(dw1)),
-              _p(f32(dw2)), B, C, R, _p(ws), n, red_counters(gap.device, 1), _stream())
+              _p(f32(dw2)), B, C, R, float(in_scale), _p(ws), n, red_counters(gap.device, 1), _stream())
     return dgap
+
+
+def pack_cols2(a: Tensor, b: Tensor, Kp: int, dtype: torch.dtype) -> Tensor:
+    """[R, Kp] (dtype) = [a | b | 0] from two fp32 [R, na] / [R, nb] matrices, one launch."""
+    R, na, nb = a.shape[0], a.shape[1], b.shape[1]
+    out = torch.empty((R, Kp), dtype=dtype, device=a.device)
+    _lib.call("spg_pack_cols2", dcode(out), _p(f32(a)), na, _p(f32(b)), nb, _p(out), R, Kp, _stream())
+    return out
+
+
+def add_cols_batch(jobs) -> None:
+    """jobs: up to 4 (dst [R, C] fp32 contiguous view, src [R, >= C] fp32 with row stride src.stride(0)): dst += src[:, :C], one launch."""
+    import ctypes
+    n = len(jobs)
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    for d, s_ in jobs:
+        assert d.dtype == torch.float32 and s_.dtype == torch.float32 and d.is_contiguous() and s_.stride(1) == 1 and d.shape[0] == s_.shape[0]
+    _lib.call("spg_add_cols_batch", n, P(*[_p(d) for d, _ in jobs]), P(*[_p(s_) for _, s_ in jobs]), I(*[d.shape[0] for d, _ in jobs]),
+              I(*[d.shape[1] for d, _ in jobs]), I(*[d.shape[1] for d, _ in jobs]), I(*[s_.stride(0) for _, s_ in jobs]), _stream())
 
 
 def chan_scale(x: Tensor, scale: Tensor, B: int, HW: int, C: int) -> Tensor:

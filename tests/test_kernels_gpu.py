@@ -404,15 +404,15 @@ def test_se_block(ops, dt):
     gap_ref = xf.mean(1)
     s_ref = torch.sigmoid(F.linear(F.relu(F.linear(gap_ref, w1f)), w2f))
     ref = xf * s_ref[:, None]
-    gap = ops.gap_sum(x, B, HW, C) / HW
-    hidden, scale = ops.se_fc(gap, w1, w2)
+    gap = ops.gap_sum(x, B, HW, C)                       # column sums; the mean's 1 / HW is the SE kernels' in_scale
+    hidden, scale = ops.se_fc(gap, w1, w2, 1.0 / HW)
     y = ops.chan_scale(x, scale, B, HW, C)
     check(y.float(), ref.detach(), tol(dt, 1e-5, 1e-2), "se fwd")
     dy = rnd(B, HW, C, seed=4).to(dt)
     ref.backward(dy.float())
     dscale = ops.chan_prod_sum(dy, x, B, HW, C)
     dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
-    dgap = ops.se_fc_bwd(gap, w1, w2, hidden, scale, dscale, dw1, dw2)
+    dgap = ops.se_fc_bwd(gap, w1, w2, hidden, scale, dscale, dw1, dw2, 1.0 / HW)
     dx = ops.chan_scale_bwd(dy, scale, dgap, B, HW, C)
     check(dx.float(), xf.grad, tol(dt, 1e-4, 2e-2), "se dx")
     check(dw1, w1f.grad, tol(dt, 1e-4, 3e-2), "se dw1")
@@ -678,6 +678,62 @@ def test_easpp_middle_branch_batched(ops, dt):
         check(dwd[i], wd_t[i].grad, t, f"d depth-wise weight {i}")
         check(dgam[i], gb_t[2 * i].grad, t, f"d branch BN gamma {i}")
         check(dbet[i], gb_t[2 * i + 1].grad, t, f"d branch BN beta {i}")
+
+
+def test_pack_cols2_and_add_cols_batch(ops):
+    """the position-embedding operand [pos_embed | pos_embed_window | 0] and the column-slice gradient adds (models/engine.py trunk)"""
+    a, b = rnd(144, 49, seed=1), rnd(144, 64, seed=2)
+    for dt in DT:
+        out = ops.pack_cols2(a, b, 120, dt)
+        ref = torch.zeros(144, 120, device="cuda")
+        ref[:, :49], ref[:, 49:113] = a, b
+        assert torch.equal(out, ref.to(dt))
+    d0, d1, d2 = rnd(144, 147, seed=3), rnd(144, 49, seed=4), rnd(144, 64, seed=5)
+    s0, s1 = rnd(144, 152, seed=6), rnd(144, 120, seed=7)
+    r0, r1, r2 = d0 + s0[:, :147], d1 + s1[:, :49], d2 + s1[:, 49:113]
+    ops.add_cols_batch([(d0, s0), (d1, s1), (d2, s1[:, 49:])])
+    assert torch.equal(d0, r0) and torch.equal(d1, r1) and torch.equal(d2, r2)
+
+
+# ------------------------------------------------------------------------------------------- CU budget
+@pytest.mark.parametrize("budget", [240, 96, 8])
+def test_gemms_under_a_cu_budget(ops, budget):
+    """The multi-GPU step sizes the persistent GEMM grids for fewer CUs while a collective is resident (ops.cu_budget, a per-call ABI
+    argument): tile widths, split plans, the grouped wgrad's whole-tile / remainder shares and its workspace all change with it -- same
+    results required (reference: the same calls at the full chip)."""
+    dt = torch.bfloat16
+    x, w = rnd(4608, 576, seed=1).to(dt), (rnd(1728, 576, seed=2) * 0.05).to(dt)
+    b, res = rnd(1728, seed=3), rnd(4608, 1728, seed=4).to(dt)
+    full = ops.gemm_nt(x, w, bias=b, residual=res)
+    xl, wl = rnd(4608, 2304, seed=5).to(dt), (rnd(576, 2304, seed=6) * 0.03).to(dt)
+    full_l = ops.gemm_nt(xl, wl)                                   # long-K, few tiles: the persistent kernel
+    xc, wc = rnd(2, 24, 24, 64, seed=7).to(dt), (rnd(128, 9 * 64, seed=8) * 0.05).to(dt)
+    full_c = ops.gemm_nt(xc, wc, conv=(2, 24, 24, 64))
+    shapes = [(4608, 576, 2304), (4608, 2304, 576), (4608, 576, 576), (4608, 1728, 576)]
+    mk = lambda: [(rnd(M, N, seed=10 + i).to(dt), rnd(M, K, seed=20 + i).to(dt), torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda"))
+                  for i, (M, N, K) in enumerate(shapes)]
+    ref_jobs = mk()
+    ops.gemm_tn_group(ref_jobs)
+    dyc = rnd(2 * 24 * 24, 128, seed=9).to(dt)
+    dwc_ref = torch.zeros(128, 9 * 64, device="cuda")
+    ops.gemm_tn(dyc, xc, dwc_ref, conv=(2, 24, 24, 64))
+    with ops.cu_budget(budget):
+        assert ops.cu_budget_now() == budget
+        check(ops.gemm_nt(x, w, bias=b, residual=res).float(), full.float(), 1e-6, "gemm_nt under budget")   # same arithmetic per element
+        check(ops.gemm_nt(xl, wl).float(), full_l.float(), 1e-6, "long-K gemm_nt under budget")
+        check(ops.gemm_nt(xc, wc, conv=(2, 24, 24, 64)).float(), full_c.float(), 1e-6, "conv gemm_nt under budget")
+        jobs = mk()
+        pending = []
+        ops.gemm_tn_group(jobs, pending)
+        ops.gemm_tn_group_reduce(pending)
+        dwc = torch.zeros(128, 9 * 64, device="cuda")
+        ops.gemm_tn(dyc, xc, dwc, conv=(2, 24, 24, 64))
+    assert ops.cu_budget_now() == 0
+    for (dy, xx, dw, db), (_, _, rw, rb) in zip(jobs, ref_jobs):
+        check(dw, dy.float().t() @ xx.float(), 1e-2, "grouped wgrad under budget vs torch")
+        check(dw, rw, 2e-5, "grouped wgrad under budget vs full chip")     # (summation order over M differs with the shares)
+        check(db, rb, 2e-5, "grouped dbias under budget")
+    check(dwc, dwc_ref, 2e-5, "conv wgrad under budget")
 
 
 # ------------------------------------------------------------------------------------------- fused CODLoss
