@@ -302,28 +302,44 @@ __global__ __launch_bounds__(256) void easpp_fuse_bn_bwd_apply_kernel(const T* _
 
 // ---- global branch, forward (one workgroup): gm = gsum/HW; gl0 = gm . Wg^T; BN over the B values of each channel (train: batch
 // statistics + running update; eval: running); glob = relu(.)
-__global__ __launch_bounds__(256) void easpp_global_fwd_kernel(const float* __restrict__ gsum, const float* __restrict__ Wg,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
-                                                               float* __restrict__ rvar, long long* __restrict__ nbt, float* __restrict__ gm,
-                                                               float* __restrict__ gl0, float* __restrict__ glob, float* __restrict__ ss,
-                                                               float* __restrict__ mi, int B, int C, float inv_hw, float eps, float momentum,
-                                                               int training) {
-  extern __shared__ float sm[];   // gm [B][C]
-  for (int i = threadIdx.x; i < B * C; i += 256) { sm[i] = gsum[i] * inv_hw; gm[i] = sm[i]; }
+__global__ __launch_bounds__(1024) void easpp_global_fwd_kernel(const float* __restrict__ gsum, const float* __restrict__ Wg,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar, long long* __restrict__ nbt, float* __restrict__ gm,
+                                                                float* __restrict__ gl0, float* __restrict__ glob, float* __restrict__ ss,
+                                                                float* __restrict__ mi, int B, int C, float inv_hw, float eps, float momentum,
+                                                                int training) {
+  extern __shared__ float sm[];   // gm [B][C], then gl0 [B][C]
+  float* sl = sm + B * C;
+  const int nt = (int)blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+  for (int i = threadIdx.x; i < B * C; i += nt) { sm[i] = gsum[i] * inv_hw; gm[i] = sm[i]; }
   __syncthreads();
-  for (int o = threadIdx.x; o < C; o += 256) {
-    float mu = 0.f;
-    for (int b = 0; b < B; ++b) {
-      float s = 0.f;
-      for (int k = 0; k < C; ++k) s += Wg[(long)o * C + k] * sm[b * C + k];
-      gl0[b * C + o] = s;
-      mu += s;
+  // 1x1 conv: a wave per output channel, lanes stride the input channels (coalesced weight rows), 8 images per pass
+  for (int o = wave; o < C; o += nw) {
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      float s[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] = 0.f;
+      for (int k = lane; k < C; k += 64) {
+        const float w = Wg[(long)o * C + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (b0 + j < B) s[j] += w * sm[(b0 + j) * C + k];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = wave_sum(s[j]);
+        if (lane == 0 && b0 + j < B) { sl[(b0 + j) * C + o] = t; gl0[(b0 + j) * C + o] = t; }
+      }
     }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += nt) {
+    float mu = 0.f;
+    for (int b = 0; b < B; ++b) mu += sl[b * C + o];
     float var;
     if (training) {
       mu /= (float)B;
       float q = 0.f;
-      for (int b = 0; b < B; ++b) { const float dlt = gl0[b * C + o] - mu; q += dlt * dlt; }
+      for (int b = 0; b < B; ++b) { const float dlt = sl[b * C + o] - mu; q += dlt * dlt; }
       var = q / (float)B;
       if (rmean) {
         rmean[o] = (1.f - momentum) * rmean[o] + momentum * mu;
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(256) void easpp_global_fwd_kernel(const float* __re
     }
     const float is = rsqrtf(var + eps), sc = gamma[o] * is, sh = beta[o] - mu * sc;
     ss[o] = sc; ss[C + o] = sh; mi[o] = mu; mi[C + o] = is;
-    for (int b = 0; b < B; ++b) glob[b * C + o] = fmaxf(gl0[b * C + o] * sc + sh, 0.f);
+    for (int b = 0; b < B; ++b) glob[b * C + o] = fmaxf(sl[b * C + o] * sc + sh, 0.f);
   }
   if (training && threadIdx.x == 0 && nbt) nbt[0] += 1;
 }
@@ -342,14 +358,14 @@ __global__ __launch_bounds__(256) void easpp_global_fwd_kernel(const float* __re
 // ---- global branch, backward (one workgroup).  S[b][g] = sum_p dfu[b,p,g] (per-image column sums of the fusion conv's output gradient).
 // concat channel cc = 4C + ch (ch < C) belongs to group g = cc/5, tap j = cc%5:  dglob[b][ch] = w[cc]*S[b][g],  dw_fuse[cc] += sum_b glob[b][ch]*S[b][g];
 // then BN (over B) + ReLU backward, the 1x1 conv's weight gradient and the GAP adjoint  gadd[b][k] = (sum_o d_gl0[b][o]*Wg[o][k]) / HW.
-__global__ __launch_bounds__(256) void easpp_global_bwd_kernel(const float* __restrict__ S, const float* __restrict__ glob, const float* __restrict__ gl0,
+__global__ __launch_bounds__(1024) void easpp_global_bwd_kernel(const float* __restrict__ S, const float* __restrict__ glob, const float* __restrict__ gl0,
                                                                const float* __restrict__ gm, const float* __restrict__ wf, const float* __restrict__ Wg,
                                                                const float* __restrict__ gamma, const float* __restrict__ mi, float* __restrict__ dwf,
                                                                float* __restrict__ dWg, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ gadd, int B, int C, float inv_hw, int training) {
   extern __shared__ float sm[];   // dgl0 [B][C]
-  const int C4 = 4 * C;
-  for (int ch = threadIdx.x; ch < C; ch += 256) {
+  const int C4 = 4 * C, nt = (int)blockDim.x;
+  for (int ch = threadIdx.x; ch < C; ch += nt) {
     const int cc = C4 + ch, g = cc / 5;
     const float wv = wf[cc];
     float dwsum = 0.f, s0 = 0.f, s1 = 0.f;
@@ -373,13 +389,13 @@ __global__ __launch_bounds__(256) void easpp_global_bwd_kernel(const float* __re
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * C; i += 256) {
+  for (int i = threadIdx.x; i < C * C; i += nt) {
     const int o = i / C, k = i - o * C;
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += sm[b * C + o] * gm[b * C + k];
     dWg[i] += s;
   }
-  for (int i = threadIdx.x; i < B * C; i += 256) {
+  for (int i = threadIdx.x; i < B * C; i += nt) {
     const int b = i / C, k = i - b * C;
     float s = 0.f;
     for (int o = 0; o < C; ++o) s += sm[b * C + o] * Wg[(long)o * C + k];
@@ -513,7 +529,8 @@ extern "C" int spg_easpp_global_fwd(const float* gsum, const float* Wg, const fl
   SPG_REQUIRE(B >= 1 && B <= 64 && C >= 1 && C <= 512, "easpp_global_fwd: B=%d (1..64), C=%d (1..512)", B, C);
   SPG_REQUIRE(training || (running_mean && running_var), "easpp_global_fwd: eval mode needs running statistics");
   SPG_REQUIRE(!training || B >= 2, "easpp_global_fwd: train-mode BatchNorm over B values needs B >= 2 (Expected more than 1 value per channel)");
-  hipLaunchKernelGGL(easpp_global_fwd_kernel, dim3(1), dim3(256), (size_t)B * C * sizeof(float), (hipStream_t)stream, gsum, Wg, gamma, beta, running_mean,
+  SPG_REQUIRE((long)B * C <= 8192, "easpp_global_fwd: B * C = %ld exceeds the 64 KiB of LDS the kernel stages (8192 values)", (long)B * C);
+  hipLaunchKernelGGL(easpp_global_fwd_kernel, dim3(1), dim3(1024), (size_t)2 * B * C * sizeof(float), (hipStream_t)stream, gsum, Wg, gamma, beta, running_mean,
                      running_var, num_batches_tracked, gm, gl0, glob, scale_shift, mean_invstd, B, C, 1.f / (float)HW, eps, momentum, training);
   return check_launch("easpp_global_fwd");
 }
@@ -522,7 +539,7 @@ extern "C" int spg_easpp_global_bwd(const float* S, const float* glob, const flo
                                     const float* gamma, const float* mean_invstd, float* dwf, float* dWg, float* dgamma, float* dbeta, float* gadd,
                                     int B, int C, long HW, int training, spg_stream_t stream) {
   SPG_REQUIRE(B >= 1 && B <= 64 && C >= 1 && C <= 512, "easpp_global_bwd: B=%d (1..64), C=%d (1..512)", B, C);
-  hipLaunchKernelGGL(easpp_global_bwd_kernel, dim3(1), dim3(256), (size_t)B * C * sizeof(float), (hipStream_t)stream, S, glob, gl0, gm, wf, Wg, gamma,
+  hipLaunchKernelGGL(easpp_global_bwd_kernel, dim3(1), dim3(1024), (size_t)B * C * sizeof(float), (hipStream_t)stream, S, glob, gl0, gm, wf, Wg, gamma,
                      mean_invstd, dwf, dWg, dgamma, dbeta, gadd, B, C, 1.f / (float)HW, training);
   return check_launch("easpp_global_bwd");
 }

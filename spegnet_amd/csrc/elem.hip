@@ -190,6 +190,66 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
   }
 }
 
+// 16-byte versions (C, ldc, c0 multiples of the vector width): a thread owns VEC channels of one pooled pixel
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                               int B, int H, int W, int C, int ldc, int c0) {
+  constexpr int VEC = ST<T>::VEC;
+  const int Ho = H / 2, Wo = W / 2, nch = C / VEC;
+  const long total = (long)B * Ho * Wo * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    long p = i / nch;
+    const int X = (int)(p % Wo); p /= Wo;
+    const int Y = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const T* base = x + (((long)b * H + 2 * Y) * W + 2 * X) * ldc + c0 + ch * VEC;
+    float v0[VEC], v1[VEC], v2[VEC], v3[VEC], best[VEC];
+    unpack16<T>(ld16(base), v0); unpack16<T>(ld16(base + ldc), v1);
+    unpack16<T>(ld16(base + (long)W * ldc), v2); unpack16<T>(ld16(base + (long)(W + 1) * ldc), v3);
+    uint8_t bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      best[e] = v0[e]; bi[e] = 0;
+      if (v1[e] > best[e]) { best[e] = v1[e]; bi[e] = 1; }
+      if (v2[e] > best[e]) { best[e] = v2[e]; bi[e] = 2; }
+      if (v3[e] > best[e]) { best[e] = v3[e]; bi[e] = 3; }
+    }
+    const long o = (((long)b * Ho + Y) * Wo + X) * C + ch * VEC;
+    st16(y + o, pack16<T>(best));
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) idx[o + e] = bi[e];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_vec_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                               T* __restrict__ dx, int B, int H, int W, int C, int ldc, int c0) {
+  constexpr int VEC = ST<T>::VEC;
+  const int Ho = H / 2, Wo = W / 2, nch = C / VEC;
+  const long total = (long)B * Ho * Wo * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    long p = i / nch;
+    const int X = (int)(p % Wo); p /= Wo;
+    const int Y = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const long o = (((long)b * Ho + Y) * Wo + X) * C + ch * VEC;
+    float g[VEC];
+    unpack16<T>(ld16(dy + o), g);
+    uint8_t bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) bi[e] = idx[o + e];
+    T* base = dx + (((long)b * H + 2 * Y) * W + 2 * X) * ldc + c0 + ch * VEC;
+#pragma unroll
+    for (int me = 0; me < 4; ++me) {
+      float v[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = bi[e] == me ? g[e] : 0.f;
+      st16(base + ((long)(me >> 1) * W + (me & 1)) * ldc, pack16<T>(v));
+    }
+  }
+}
+
 // patch-embed im2col: img f32 NCHW [B,3,H,W] -> cols T [B*(H/4)*(W/4)][Kpad], k = c*49 + ky*7 + kx (conv 7x7 s4 p3)
 template <typename T>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H, int W, int Kpad) {
@@ -236,25 +296,25 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ ga
 }
 // given dscale -> dgap, dw1 +=, dw2 += (one block per image; the weight gradients sum over images in image order, by the block
 // that arrives last: ws holds dz[B][C] then dh[B][R])
-__global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
-                                                        const float* __restrict__ w2, const float* __restrict__ hidden,
-                                                        const float* __restrict__ scale, const float* __restrict__ dscale,
-                                                        float* __restrict__ dgap, float* __restrict__ dw1,
-                                                        float* __restrict__ dw2, int C, int R, float* __restrict__ ws,
-                                                        unsigned* __restrict__ counter, float in_scale) {
-  extern __shared__ float sm[];  // dz[C] + dh[R]
+__global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, const float* __restrict__ hidden,
+                                                         const float* __restrict__ scale, const float* __restrict__ dscale,
+                                                         float* __restrict__ dgap, float* __restrict__ dw1,
+                                                         float* __restrict__ dw2, int C, int R, float* __restrict__ ws,
+                                                         unsigned* __restrict__ counter, float in_scale) {
+  extern __shared__ float sm[];  // dz[C] + dh[R]; the last block re-uses it as gdz[B][C] | gap[B][C] | gdh[B][R] | hidden[B][R]
   __shared__ unsigned s_last;
-  const int b = blockIdx.x, B = gridDim.x;
+  const int b = blockIdx.x, B = gridDim.x, nt = (int)blockDim.x;
   float* dz = sm; float* dh = sm + C;
   float* gdz = ws; float* gdh = ws + (long)B * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += nt) {
     const float s = scale[(long)b * C + c];
     dz[c] = dscale[(long)b * C + c] * s * (1.f - s);
     st_part(gdz + (long)b * C + c, dz[c]);
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < R; r += 4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+  for (int r = wave; r < R; r += nw) {
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += w2[(long)c * R + r] * dz[c];
     s = wave_sum(s);
@@ -262,21 +322,28 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
     if (lane == 0) { dh[r] = hr > 0.f ? s : 0.f; st_part(gdh + (long)b * R + r, dh[r]); }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += nt) {
     float s = 0.f;
     for (int r = 0; r < R; ++r) s += w1[(long)r * C + c] * dh[r];
     dgap[(long)b * C + c] = s;
   }
   if (!arrive_last(counter, (unsigned)B, &s_last)) return;
-  for (int i = threadIdx.x; i < C * R; i += 256) {
+  // the last block: weight gradients summed over the images in image order, operands staged in LDS (coalesced) first
+  float* l_dz = sm; float* l_gap = l_dz + B * C; float* l_dh = l_gap + B * C; float* l_hid = l_dh + B * R;
+  for (int i = threadIdx.x; i < B * C; i += nt) { l_dz[i] = gdz[i]; l_gap[i] = gap[i] * in_scale; }
+  for (int i = threadIdx.x; i < B * R; i += nt) { l_dh[i] = gdh[i]; l_hid[i] = hidden[i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * R; i += nt) {          // dw2 [C][R]: consecutive threads, consecutive r
     const int c = i / R, r = i - c * R;
-    float s2 = 0.f, s1 = 0.f;
-    for (int bb = 0; bb < B; ++bb) {
-      s2 += gdz[(long)bb * C + c] * hidden[(long)bb * R + r];
-      s1 += gdh[(long)bb * R + r] * (gap[(long)bb * C + c] * in_scale);
-    }
-    dw2[(long)c * R + r] += s2;
-    dw1[(long)r * C + c] += s1;
+    float s2 = 0.f;
+    for (int bb = 0; bb < B; ++bb) s2 += l_dz[bb * C + c] * l_hid[bb * R + r];
+    dw2[i] += s2;
+  }
+  for (int i = threadIdx.x; i < C * R; i += nt) {          // dw1 [R][C]: consecutive threads, consecutive c
+    const int r = i / C, c = i - r * C;
+    float s1 = 0.f;
+    for (int bb = 0; bb < B; ++bb) s1 += l_dh[bb * R + r] * l_gap[bb * C + c];
+    dw1[i] += s1;
   }
 }
 
@@ -655,6 +722,13 @@ extern "C" int spg_cast_bf16(const float* f32, void* bf16, long n, int to_f32, s
 extern "C" int spg_maxpool2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int ldc, int c0,
                                 spg_stream_t stream) {
   SPG_REQUIRE((H % 2 == 0) && (W % 2 == 0), "maxpool2: H=%d W=%d must be even", H, W);
+  const int vw = vec_of(dtype);
+  if (C % vw == 0 && ldc % vw == 0 && c0 % vw == 0) {
+    const int gridv = ew_grid((long)B * (H / 2) * (W / 2) * (C / vw));
+    if (dtype == SPG_BF16) hipLaunchKernelGGL(maxpool2_fwd_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, idx, B, H, W, C, ldc, c0);
+    else hipLaunchKernelGGL(maxpool2_fwd_vec_kernel<float>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, idx, B, H, W, C, ldc, c0);
+    return check_launch("maxpool2_fwd(vec)");
+  }
   const int grid = ew_grid((long)B * (H / 2) * (W / 2) * C);
   if (dtype == SPG_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, idx, B, H, W, C, ldc, c0);
   else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, idx, B, H, W, C, ldc, c0);
@@ -663,6 +737,13 @@ extern "C" int spg_maxpool2_fwd(int dtype, const void* x, void* y, uint8_t* idx,
 extern "C" int spg_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C, int ldc,
                                 int c0, spg_stream_t stream) {
   SPG_REQUIRE((H % 2 == 0) && (W % 2 == 0), "maxpool2_bwd: H=%d W=%d must be even", H, W);
+  const int vw = vec_of(dtype);
+  if (C % vw == 0 && ldc % vw == 0 && c0 % vw == 0) {
+    const int gridv = ew_grid((long)B * (H / 2) * (W / 2) * (C / vw));
+    if (dtype == SPG_BF16) hipLaunchKernelGGL(maxpool2_bwd_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, idx, (bf16_t*)dx, B, H, W, C, ldc, c0);
+    else hipLaunchKernelGGL(maxpool2_bwd_vec_kernel<float>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const float*)dy, idx, (float*)dx, B, H, W, C, ldc, c0);
+    return check_launch("maxpool2_bwd(vec)");
+  }
   const int grid = ew_grid((long)B * H * W * C);
   if (dtype == SPG_BF16) hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, idx, (bf16_t*)dx, B, H, W, C, ldc, c0);
   else hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, idx, (float*)dx, B, H, W, C, ldc, c0);
@@ -819,7 +900,9 @@ extern "C" int spg_se_fc_bwd(const float* gap, const float* w1, const float* w2,
                              const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, float in_scale, float* red_ws,
                              long red_ws_floats, unsigned* red_counter, spg_stream_t stream) {
   SPG_REQUIRE(red_ws && red_counter && red_ws_floats >= (long)B * (C + R), "se_fc_bwd: needs B*(C+R) floats of scratch and one zeroed counter");
-  hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gap, w1, w2, hidden, scale, dscale, dgap, dw1, dw2, C, R,
+  const size_t lds = (size_t)2 * B * (C + R) * sizeof(float);     // (>= the C + R floats of the per-image phase)
+  SPG_REQUIRE(lds <= 64 * 1024, "se_fc_bwd: B * (C + R) = %ld exceeds the 64 KiB of LDS the last block stages", (long)B * (C + R));
+  hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, gap, w1, w2, hidden, scale, dscale, dgap, dw1, dw2, C, R,
                      red_ws, red_counter, in_scale);
   return check_launch("se_fc_bwd");
 }
