@@ -508,6 +508,41 @@ __device__ __forceinline__ void stage_rows(const T* const* ptrs, int nrows, int 
     }
   }
 }
+// One-pass staging: every 16-byte chunk of rows [0, nrows) of up to two row images is written exactly once -- data chunks from the
+// row pointers the callables return (null = zero row), the pad chunks of a row (d >= HD) as zeros.  No pointer table in LDS, no
+// separate zero fill, no barrier before the loads (these kernels are bound by exactly that dependent chain: table -> barrier -> loads
+// -> LDS stores -> barrier).  srcA / srcB: token -> const T* (row start) or nullptr; rimgB == nullptr: one image.
+template <typename T, int HD, typename FA, typename FB>
+__device__ __forceinline__ void stage_rows2(int nrows, FA srcA, char* rimgA, FB srcB, char* rimgB) {
+  constexpr int VEC = AC<T, HD>::VEC, NCH = AC<T, HD>::NCH, RS = AC<T, HD>::RS;
+  constexpr int RCH = RS / 16;        // 16-byte chunks per image row incl. padding
+  constexpr int U = 4;
+  const int total = nrows * RCH;
+  for (int base = threadIdx.x; base < total; base += RES_THREADS * U) {
+    u32x4 v[U], v2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = base + u * RES_THREADS;
+      v[u] = u32x4{0u, 0u, 0u, 0u}; v2[u] = u32x4{0u, 0u, 0u, 0u};
+      if (p < total) {
+        const int t = p / RCH, ch = p - t * RCH;
+        if (ch < NCH) {
+          const T* a = srcA(t);
+          if (a) v[u] = ld16(a + ch * VEC);
+          if (rimgB) { const T* b = srcB(t); if (b) v2[u] = ld16(b + ch * VEC); }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = base + u * RES_THREADS;
+      if (p < total) {
+        *reinterpret_cast<u32x4*>(rimgA + p * 16) = v[u];
+        if (rimgB) *reinterpret_cast<u32x4*>(rimgB + p * 16) = v2[u];
+      }
+    }
+  }
+}
 template <typename T, int HD> struct ResLds {
   static constexpr int IMG = RES_ROWS * AC<T, HD>::RS;
   static constexpr int BYTES = 2 * IMG + RES_ROWS * 8 + 3 * RES_ROWS * 4;
@@ -519,8 +554,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
   char* vimg = kimg + ResLds<T, HD>::IMG;
-  const T** kptr = reinterpret_cast<const T**>(vimg + ResLds<T, HD>::IMG);
-  float* kb = reinterpret_cast<float*>(kptr + RES_ROWS);
+  float* kb = reinterpret_cast<float*>(vimg + ResLds<T, HD>::IMG + RES_ROWS * 8);   // (LDS map of ResLds: two images, 8 B x rows spare, 3 float arrays)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
   const int head = blockIdx.x;
   const Win w = get_win(p, blockIdx.y);
@@ -532,19 +566,18 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
   // (16 blocks) no longer takes two passes on one CU while the CUs holding the partial windows of the same image sit idle
   const int rb0 = (int)blockIdx.z * (RES_THREADS / 64);
   if (rb0 * 16 >= w.nq) return;
-  for (int i = tid * 16; i < nrows * A::RS; i += RES_THREADS * 16) {   // (the rows the tiles in use cover; staging leaves pad columns)
-    *reinterpret_cast<u32x4*>(kimg + i) = u32x4{0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(vimg + i) = u32x4{0u, 0u, 0u, 0u};
+  // per-key score bias (0 / log(n_pad) for the virtual pad key / -inf for the unused slots of the last tile), then K and V in one pass
+  for (int c = tid; c < nrows; c += RES_THREADS)
+    kb[c] = c < w.nvalid ? 0.f : ((c == w.nvalid && w.npad > 0) ? __logf((float)w.npad) : NEG_BIG);
+  {
+    auto ksrc = [&](int c) -> const T* {
+      if (c < w.nvalid) return qkv + key_row(p, w, c) * 3 * p.C + p.C + head * HD;
+      if (c == w.nvalid && w.npad > 0) return reinterpret_cast<const T*>(p.bias) + p.C + head * HD;
+      return nullptr;
+    };
+    auto vsrc = [&](int c) -> const T* { const T* k = ksrc(c); return k ? k + p.C : nullptr; };
+    stage_rows2<T, HD>(nrows, ksrc, kimg, vsrc, vimg);
   }
-  for (int c = tid; c < nrows; c += RES_THREADS) {
-    const T* kp = nullptr;
-    float b = NEG_BIG;
-    if (c < w.nvalid) { kp = qkv + key_row(p, w, c) * 3 * p.C + p.C + head * HD; b = 0.f; }
-    else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; b = __logf((float)w.npad); }
-    kptr[c] = kp; kb[c] = b;
-  }
-  __syncthreads();
-  stage_rows<T, HD>(kptr, nrows, 0, kimg, p.C, vimg);
   __syncthreads();
 
   for (int rb = rb0 + wave; rb * 16 < w.nq; rb += (RES_THREADS / 64) * (int)gridDim.z) {
@@ -640,8 +673,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
   char* doimg = qimg + ResLds<T, HD>::IMG;
-  const T** qptrs = reinterpret_cast<const T**>(doimg + ResLds<T, HD>::IMG);
-  float* lse_s = reinterpret_cast<float*>(qptrs + RES_ROWS);
+  float* lse_s = reinterpret_cast<float*>(doimg + ResLds<T, HD>::IMG + RES_ROWS * 8);
   float* delta_s = lse_s + RES_ROWS;
   long* qrows = nullptr; (void)qrows;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
@@ -653,32 +685,27 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p) {
   const int ntq = (w.nq + 63) >> 6, nrows = ntq * 64;
   const int kb0 = (int)blockIdx.z * (RES_THREADS / 64);      // key blocks dealt to gridDim.z workgroups, as the query blocks above
   if (kb0 * 16 >= nkeys) return;
-  for (int i = tid * 16; i < nrows * A::RS; i += RES_THREADS * 16) {
-    *reinterpret_cast<u32x4*>(qimg + i) = u32x4{0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(doimg + i) = u32x4{0u, 0u, 0u, 0u};
-  }
   for (int i = tid; i < nrows; i += RES_THREADS) {
-    const T* a = nullptr;
     float ls = 1.0e30f, dl = 0.f;
     if (i < w.nq) {
       const long row = q_row(p, w, i);
-      a = qp ? qp + row * p.C + head * HD : qkv + row * 3 * p.C + head * HD;
       ls = p.lse[row * p.heads + head];
       dl = p.delta[row * p.heads + head];
     }
-    qptrs[i] = a; lse_s[i] = ls; delta_s[i] = dl;
+    lse_s[i] = ls; delta_s[i] = dl;
   }
-  __syncthreads();
-  stage_rows<T, HD>(qptrs, nrows, 0, qimg);
-  __syncthreads();
-  // dO rows: same token rows in the dout tensor -> rebuild the pointer table in place
-  for (int i = tid; i < nrows; i += RES_THREADS) {
-    const T* b = nullptr;
-    if (i < w.nq) b = reinterpret_cast<const T*>(p.dout) + q_row(p, w, i) * p.C + head * HD;
-    qptrs[i] = b;
+  {
+    auto qsrc = [&](int i) -> const T* {
+      if (i >= w.nq) return nullptr;
+      const long row = q_row(p, w, i);
+      return qp ? qp + row * p.C + head * HD : qkv + row * 3 * p.C + head * HD;
+    };
+    auto dosrc = [&](int i) -> const T* {
+      if (i >= w.nq) return nullptr;
+      return reinterpret_cast<const T*>(p.dout) + q_row(p, w, i) * p.C + head * HD;
+    };
+    stage_rows2<T, HD>(nrows, qsrc, qimg, dosrc, doimg);
   }
-  __syncthreads();
-  stage_rows<T, HD>(qptrs, nrows, 0, doimg);
   __syncthreads();
 
   for (int kbk = kb0 + wave; kbk * 16 < nkeys; kbk += (RES_THREADS / 64) * (int)gridDim.z) {

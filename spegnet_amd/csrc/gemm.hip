@@ -2464,8 +2464,8 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
 // younger groups stay in flight), a multiplier for its fragment reads of stage k (lgkmcnt(0)); after it group k+4 may overwrite
 // stage k's slot and the fragments of step k+1 may be read.  Both roles pass exactly 1 + total barriers.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
+template <typename T, int DBG = 0, int CW = 4>   // CW multiplying waves (4: 64 x 64 each; 8: 64 x 32 each, two per SIMD) + 4 loader waves
+__global__ __launch_bounds__((CW + 4) * 64) void gemm_tn_group4_kernel(TnGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
   static_assert(sizeof(T) == 2, "bf16 only");
   using F = TnFrag<T>;
   constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;
@@ -2483,9 +2483,10 @@ __global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* _
   const int m_first = WS > 0 ? 0 : rb % S;
   const int gt_rem = g.W * G + rb / S, m_rem = rb % S;                      // where the remainder share starts
 
-  if (wave >= 4) {
+  constexpr int KB = 16 / CW;                                             // 16-column k blocks per multiplying wave (its tile: 64 n x 16 KB k)
+  if (wave >= CW) {
     // ================================================================ loader waves
-    const int lw = wave - 4;
+    const int lw = wave - CW;
     const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
     const int lrow = lane >> 4, lpc = lane & 15;
     const int prow0 = lw * 4 + lrow;                                        // row (mod 16) of this lane's pieces
@@ -2547,7 +2548,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* _
 #ifdef SPG_DEV_KERNELS
     if constexpr (DBG == 5) {
       if (lane == 0 && blockIdx.x < 256) {
-        unsigned long long* o = tn_stamp_sums + ((int)blockIdx.x * 8 + wave) * 4;
+        unsigned long long* o = tn_stamp_sums + ((int)blockIdx.x * 8 + (wave & 7)) * 4;
         o[0] = sg0; o[1] = sg1; o[2] = sg2; o[3] = 0;
       }
     }
@@ -2558,34 +2559,35 @@ __global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* _
   // ================================================================== multiplying waves
   const int wn = wave & 1, wk = wave >> 1;
   const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
-  int oa[2][4][2], ob[2][4][2];
+  int oa[2][4][2], ob[2][KB][2];
 #pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
+  for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      F::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
-      F::offsets(s2, wk * 64 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
-    }
+    for (int i = 0; i < 4; ++i) F::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) F::offsets(s2, wk * (16 * KB) + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
+  }
   // fragments are kept as their two transpose-read halves: ONE read per MFMA slot fits the ~8 issue cycles an MFMA leaves free
   // (two per slot added their issue time to the MFMA's: stamps, tools/tn_stamps.py)
-  struct Frags { s16x4_t a[2][4][2], b[2][4][2]; };
+  struct Frags { s16x4_t a[2][4][2], b[2][KB][2]; };
   Frags fa, fb;
-  auto read_half = [&](Frags& f, const char* st, int t) __attribute__((always_inline)) {   // t-th of the 32 reads of a step
-    const int idx = t >> 1, h = t & 1, sx = idx >> 3, r = idx & 7;
-    if (r < 4) f.b[sx][r][h] = F::load_half(st + 16384, ob[sx][r][h]);
-    else f.a[sx][r - 4][h] = F::load_half(st, oa[sx][r - 4][h]);
+  constexpr int NF = 4 + KB, NRD = 4 * NF, NM = 8 * KB;   // fragments per 32-row half, transpose reads and MFMAs per step
+  auto read_half = [&](Frags& f, const char* st, int t) __attribute__((always_inline)) {   // t-th of the NRD reads of a step
+    const int idx = t >> 1, h = t & 1, sx = idx / NF, r = idx % NF;
+    if (r < KB) f.b[sx][r][h] = F::load_half(st + 16384, ob[sx][r][h]);
+    else f.a[sx][r - KB][h] = F::load_half(st, oa[sx][r - KB][h]);
   };
-  f32x4 acc[4][4];
+  f32x4 acc[4][KB];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < KB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum0 = 0.f, bsum1 = 0.f;
   const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
 
   __builtin_amdgcn_s_barrier();                             // group 0 has landed
 #pragma unroll
-  for (int i = 0; i < 32; ++i) read_half(fa, smem, i);
+  for (int i = 0; i < NRD; ++i) read_half(fa, smem, i);
 
   int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;   // seg0: m step at which this workgroup entered the current tile
   int cj, ctile, c_tk, c_tn;
@@ -2615,14 +2617,16 @@ __global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* _
     int n_cgt = cgt, n_cm = cm, n_seg0 = seg0, n_cj = cj, n_ctile = ctile, n_tn = c_tn, n_tk = c_tk;
     bool n_bias = c_bias;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int ms = i >> 4, r = i & 15, ni = r >> 2, ki = r & 3;
+    for (int i = 0; i < NM; ++i) {
+      const int ms = i / (4 * KB), r = i % (4 * KB), ni = r / KB, ki = r % KB;
       const typename F::Frag fb_ = F::join(cur.b[ms][ki][0], cur.b[ms][ki][1]), fa_ = F::join(cur.a[ms][ni][0], cur.a[ms][ni][1]);
       if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(fb_, fa_, acc[ni][ki]);
       else asm volatile("" :: "v"(fb_), "v"(fa_));
       __builtin_amdgcn_sched_barrier(0);
-      read_half(nxt, rst, i);   // (unconditional: past the last step this reads a stale stage into registers nobody uses)
-      if (i == 18) {
+#pragma unroll
+      for (int t = 0; t < NRD; ++t)   // (unconditional: past the last step this reads a stale stage into registers nobody uses)
+        if (t * NM / NRD == i) read_half(nxt, rst, t);
+      if (i == NM / 2 + 2) {
         const int nls = cls + 1;
         const bool jump = nls == WS && nls < total;          // whole tiles done: on to the remainder share
         const bool moved = (jump || tile_end) && !range_end;
@@ -2634,37 +2638,44 @@ __global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* _
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg2 += t - tlast; tlast = t; }
-    if (bias_tile) {   // column sums of dY over this step's 64 rows: this wave's two 16-column blocks of its n half
+    if (bias_tile) {   // column sums of dY over this step's 64 rows: the 64 / CW... columns of the n half this wave is responsible for
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms) {
-        const typename F::Frag v0 = wk == 0 ? F::join(cur.a[ms][0][0], cur.a[ms][0][1]) : F::join(cur.a[ms][2][0], cur.a[ms][2][1]);
-        const typename F::Frag v1 = wk == 0 ? F::join(cur.a[ms][1][0], cur.a[ms][1][1]) : F::join(cur.a[ms][3][0], cur.a[ms][3][1]);
+        typename F::Frag v0, v1;
+        if constexpr (CW == 4) {
+          v0 = wk == 0 ? F::join(cur.a[ms][0][0], cur.a[ms][0][1]) : F::join(cur.a[ms][2][0], cur.a[ms][2][1]);
+          v1 = wk == 0 ? F::join(cur.a[ms][1][0], cur.a[ms][1][1]) : F::join(cur.a[ms][3][0], cur.a[ms][3][1]);
+        } else {
+          v0 = wk == 0 ? F::join(cur.a[ms][0][0], cur.a[ms][0][1]) : (wk == 1 ? F::join(cur.a[ms][1][0], cur.a[ms][1][1]) :
+               (wk == 2 ? F::join(cur.a[ms][2][0], cur.a[ms][2][1]) : F::join(cur.a[ms][3][0], cur.a[ms][3][1])));
+          v1 = v0;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bf16x2_t p0 = {v0[2 * e], v0[2 * e + 1]}, p1 = {v1[2 * e], v1[2 * e + 1]};
           bsum0 = __builtin_amdgcn_fdot2_f32_bf16(p0, ones2, bsum0, false);
-          bsum1 = __builtin_amdgcn_fdot2_f32_bf16(p1, ones2, bsum1, false);
+          if constexpr (CW == 4) bsum1 = __builtin_amdgcn_fdot2_f32_bf16(p1, ones2, bsum1, false);
         }
       }
     }
     if (tile_end || range_end) {
       const TnJob& jb = g.job[cj];
-      const int n0 = c_tn * 128 + wn * 64, k0 = c_tk * 128 + wk * 64;
+      const int n0 = c_tn * 128 + wn * 64, k0 = c_tk * 128 + wk * (16 * KB);
       if (seg0 == 0 && tile_end) {
         // the whole tile was multiplied here: accumulate into the gradient (single owner)
         const __amdgpu_buffer_rsrc_t wr = make_rsrc(jb.dW, (unsigned)((long)jb.N * jb.ldw * 4));
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-          u32x4 old[4];
-          unsigned o[4];
+          u32x4 old[KB];
+          unsigned o[KB];
 #pragma unroll
-          for (int ki = 0; ki < 4; ++ki) {
+          for (int ki = 0; ki < KB; ++ki) {
             const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
             o[ki] = (n < jb.N && k < jb.K) ? (unsigned)(((long)n * jb.ldw + k) * 4) : OOB;   // K % 4 == 0
             old[ki] = bload16(wr, o[ki]);
           }
 #pragma unroll
-          for (int ki = 0; ki < 4; ++ki) {
+          for (int ki = 0; ki < KB; ++ki) {
             const f32x4 v = acc[ni][ki] + f32x4{__uint_as_float(old[ki].x), __uint_as_float(old[ki].y), __uint_as_float(old[ki].z),
                                                 __uint_as_float(old[ki].w)};
             bstore16(wr, o[ki], u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
@@ -2677,8 +2688,8 @@ __global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* _
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int ki = 0; ki < 4; ++ki) {
-            const int nl = wn * 64 + ni * 16 + r15, kl = wk * 64 + ki * 16 + q * 4;
+          for (int ki = 0; ki < KB; ++ki) {
+            const int nl = wn * 64 + ni * 16 + r15, kl = wk * (16 * KB) + ki * 16 + q * 4;
             bstore16(sr, base + (unsigned)((nl * 128 + kl) * 4), u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
                                                                       __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
             acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2688,9 +2699,9 @@ __global__ __launch_bounds__(512) void gemm_tn_group4_kernel(TnGroup g, float* _
         float b0 = bsum0, b1 = bsum1;
         b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
         b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
-        const int n = n0 + wk * 32 + r15;
+        const int n = n0 + wk * (CW == 4 ? 32 : 16) + r15;
         if (q == 0 && n < jb.N) atomicAdd(jb.dbias + n, b0);
-        if (q == 0 && n + 16 < jb.N) atomicAdd(jb.dbias + n + 16, b1);
+        if (CW == 4 && q == 0 && n + 16 < jb.N) atomicAdd(jb.dbias + n + 16, b1);
       }
       bsum0 = 0.f; bsum1 = 0.f;
     }
@@ -3826,6 +3837,12 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   } else if (tn_group_v4() && dev_env("SPG_TN_GROUP_DEBUG", 0) == 2) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group4_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     hipLaunchKernelGGL((gemm_tn_group4_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  } else
+#endif
+#ifdef SPG_DEV_KERNELS
+  if (tn_group_v4() && dev_env("SPG_TN_GROUP_CW", 4) == 8) {   // A/B: eight multiplying waves (two per SIMD) + four loaders
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group4_kernel<bf16_t, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipLaunchKernelGGL((gemm_tn_group4_kernel<bf16_t, 0, 8>), dim3(G), dim3(768), LDSG, s, g, (float*)workspace, (unsigned)need);
   } else
 #endif
   if (tn_group_v4()) {

@@ -227,10 +227,27 @@ class TrainStep:
         if not self.capture:
             return self._eager(images, masks, edges)
         if self.graph is None:
-            if self.world > 1 or self.force_segmented:
-                self._capture_segmented(images, masks, edges)
-            else:
-                self._capture(images, masks, edges)
+            err = None
+            try:
+                if self.world > 1 or self.force_segmented:
+                    self._capture_segmented(images, masks, edges)
+                else:
+                    self._capture(images, masks, edges)
+            except Exception as e:      # noqa: BLE001 -- re-raised below unless every rank agrees to run eagerly
+                err = e
+            if self.world > 1:
+                # ranks must take the same path: a rank that fell back to eager launches alone would issue bucketed all-reduces while
+                # its peers issue the segment-range ones (a hang, not an error).  Every rank has run the same warm-up collectives by
+                # now, so one MIN all-reduce of the outcome is in step on all of them.
+                import torch.distributed as dist
+                ok = torch.tensor([0 if err is not None else 1], device=images.device, dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok) == 0:
+                    logger.warning("hipGraph capture failed on at least one rank (%s): every rank runs the eager step", err)
+                    self.capture, self.graph, self.segments = False, None, None
+                    return self._eager(images, masks, edges)
+            elif err is not None:
+                raise err
         # the captured graphs are frozen to the shapes of the first batch: anything else (a short last batch, another ground-truth size)
         # runs eagerly instead of being broadcast into / rejected by the static buffers
         if any(dst.shape != src.shape for dst, src in zip(self.static, (images, masks, edges))):
