@@ -580,6 +580,9 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
   }
   __syncthreads();
 
+  // (Measured and dropped, round 2: a wave taking its two query blocks of a 16 x 16 window TOGETHER -- each K / V fragment read once for
+  // both, two independent chains -- changed nothing (18.5 -> 19.2 us on a 2 % slower box), like the one-pass staging above and the
+  // split over workgroups: neither the staging chain nor the per-wave compute chain is what bounds these launches.  Unresolved.)
   for (int rb = rb0 + wave; rb * 16 < w.nq; rb += (RES_THREADS / 64) * (int)gridDim.z) {
     const int qi = rb * 16 + r15;
     const bool qvalid = qi < w.nq;
