@@ -64,6 +64,50 @@ __device__ __forceinline__ long q_row(const AttnP& p, const Win& w, int i) {
   return ((long)w.b * p.Hq + w.y0q + ly) * p.Wq + w.x0q + lx;
 }
 
+// Work units of the resident-window kernels, largest first (longest-processing-time order: the hardware dispatches workgroups in
+// index order, one per CU): window classes A = full ws x ws windows, B = right-edge, C = bottom-edge, D = corner windows of an image,
+// each window cut into `parts` runs of 8 row blocks (128 queries / keys) so that a full 16 x 16 window is two workgroups and not one
+// that runs twice as long as the CUs holding the partial windows of the same image.  cnt = windows of the class per image.
+struct ResPlan {
+  int cnt[4], parts[4], first[4];   // first[c]: first unit of class c (all images' units of a class are consecutive)
+  int total;
+};
+__device__ __forceinline__ void res_unit(const ResPlan& pl, const AttnP& p, int u, int& widx, int& part, int& nparts) {
+  int c = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (u >= pl.first[i]) c = i;
+  const int v = u - pl.first[c];
+  nparts = pl.parts[c];
+  part = v % nparts;
+  const int wi = v / nparts;                 // window of class c, image-major
+  const int b = wi / pl.cnt[c], k = wi - b * pl.cnt[c];
+  const int nfy = p.H / p.ws, nfx = p.W / p.ws;
+  int wy, wx;
+  if (c == 0) { wy = k / nfx; wx = k - wy * nfx; }
+  else if (c == 1) { wy = k; wx = nfx; }     // right edge: one per full window row
+  else if (c == 2) { wy = nfy; wx = k; }     // bottom edge: one per full window column
+  else { wy = nfy; wx = nfx; }
+  widx = (b * p.nwy + wy) * p.nwx + wx;
+}
+static ResPlan res_plan(const AttnP& p, bool keys) {
+  ResPlan pl;
+  const int nfy = p.H / p.ws, nfx = p.W / p.ws, ry = p.H % p.ws, rx = p.W % p.ws;
+  const int hv[4] = {p.ws, p.ws, ry, ry}, wv[4] = {p.ws, rx, p.ws, rx};
+  const int cnt[4] = {nfy * nfx, rx ? nfy : 0, ry ? nfx : 0, (rx && ry) ? 1 : 0};
+  int u = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int nv = hv[c] * wv[c];
+    const int rows = keys ? nv : (p.qp ? (hv[c] / 2) * (wv[c] / 2) : nv);    // (the virtual pad key rides with the last key block)
+    int parts = (rows + 127) / 128;
+    if (parts < 1) parts = 1;
+    if (parts > 2) parts = 2;
+    pl.cnt[c] = cnt[c]; pl.parts[c] = parts; pl.first[c] = u;
+    u += p.B * cnt[c] * parts;
+  }
+  pl.total = u;
+  return pl;
+}
+
 template <typename T, int HD> struct AC {  // attention constants
   static constexpr int VEC = ST<T>::VEC;
   static constexpr int NCH = HD / VEC;                               // 16-byte chunks per head row
@@ -548,8 +592,21 @@ template <typename T, int HD> struct ResLds {
   static constexpr int BYTES = 2 * IMG + RES_ROWS * 8 + 3 * RES_ROWS * 4;
 };
 
-template <typename T, int HD, bool DQ>
-__global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   // forward (DQ=false) or dQ (DQ=true)
+#ifdef SPG_DEV_KERNELS
+// in-kernel stamps of the resident forward kernel (tools/attn_stamps.py, SPG_ATTN_STAMPS=1): per workgroup and wave, cycles in
+// [setup + bias table | staging (issue .. landed) + barrier | its query blocks | end]; plus the workgroup's window size
+__device__ unsigned long long attn_stamps[2048 * 8 * 4];
+__device__ int attn_stamp_nq[2048];
+#endif
+__device__ __forceinline__ unsigned long long attn_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+template <typename T, int HD, bool DQ, int DBG = 0>
+__global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPlan pl) {   // forward (DQ=false) or dQ (DQ=true)
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
@@ -557,15 +614,18 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
   float* kb = reinterpret_cast<float*>(vimg + ResLds<T, HD>::IMG + RES_ROWS * 8);   // (LDS map of ResLds: two images, 8 B x rows spare, 3 float arrays)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
   const int head = blockIdx.x;
-  const Win w = get_win(p, blockIdx.y);
+  int widx, part, nparts;
+  res_unit(pl, p, blockIdx.y, widx, part, nparts);
+  const Win w = get_win(p, widx);
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
   const T* qp = reinterpret_cast<const T*>(p.qp);
   const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
   const int ntiles = (nkeys + 63) >> 6, nrows = ntiles * 64;
-  // the window's 16-row query blocks are dealt to gridDim.z workgroups in runs of 8 (one block per wave): a full 16 x 16 window
-  // (16 blocks) no longer takes two passes on one CU while the CUs holding the partial windows of the same image sit idle
-  const int rb0 = (int)blockIdx.z * (RES_THREADS / 64);
+  // this unit's run of query blocks: part, part + nparts, ... in steps of 8 blocks (one per wave)
+  const int rb0 = part * (RES_THREADS / 64);
   if (rb0 * 16 >= w.nq) return;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  if constexpr (DBG == 1) t0 = attn_now();
   // per-key score bias (0 / log(n_pad) for the virtual pad key / -inf for the unused slots of the last tile), then K and V in one pass
   for (int c = tid; c < nrows; c += RES_THREADS)
     kb[c] = c < w.nvalid ? 0.f : ((c == w.nvalid && w.npad > 0) ? __logf((float)w.npad) : NEG_BIG);
@@ -576,14 +636,16 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
       return nullptr;
     };
     auto vsrc = [&](int c) -> const T* { const T* k = ksrc(c); return k ? k + p.C : nullptr; };
+    if constexpr (DBG == 1) t1 = attn_now();
     stage_rows2<T, HD>(nrows, ksrc, kimg, vsrc, vimg);
   }
   __syncthreads();
+  if constexpr (DBG == 1) t2 = attn_now();
 
   // (Measured and dropped, round 2: a wave taking its two query blocks of a 16 x 16 window TOGETHER -- each K / V fragment read once for
   // both, two independent chains -- changed nothing (18.5 -> 19.2 us on a 2 % slower box), like the one-pass staging above and the
   // split over workgroups: neither the staging chain nor the per-wave compute chain is what bounds these launches.  Unresolved.)
-  for (int rb = rb0 + wave; rb * 16 < w.nq; rb += (RES_THREADS / 64) * (int)gridDim.z) {
+  for (int rb = rb0 + wave; rb * 16 < w.nq; rb += (RES_THREADS / 64) * nparts) {
     const int qi = rb * 16 + r15;
     const bool qvalid = qi < w.nq;
     const long qrow = q_row(p, w, qvalid ? qi : 0);
@@ -668,10 +730,21 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p) {   //
       }
     }
   }
+#ifdef SPG_DEV_KERNELS
+  if constexpr (DBG == 1) {
+    t3 = attn_now();
+    const int wg = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;   // (unit-major)
+    if (lane == 0 && wg < 2048) {
+      unsigned long long* o = attn_stamps + (wg * 8 + wave) * 4;
+      o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0;
+      if (wave == 0) attn_stamp_nq[wg] = w.nq;
+    }
+  }
+#endif
 }
 
 template <typename T, int HD>
-__global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p) {
+__global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResPlan pl) {
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
@@ -681,12 +754,14 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p) {
   long* qrows = nullptr; (void)qrows;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
   const int head = blockIdx.x;
-  const Win w = get_win(p, blockIdx.y);
+  int widx, part, nparts;
+  res_unit(pl, p, blockIdx.y, widx, part, nparts);
+  const Win w = get_win(p, widx);
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
   const T* qp = reinterpret_cast<const T*>(p.qp);
   const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
   const int ntq = (w.nq + 63) >> 6, nrows = ntq * 64;
-  const int kb0 = (int)blockIdx.z * (RES_THREADS / 64);      // key blocks dealt to gridDim.z workgroups, as the query blocks above
+  const int kb0 = part * (RES_THREADS / 64);                 // this unit's run of key blocks (the pad key's block goes round-robin too)
   if (kb0 * 16 >= nkeys) return;
   for (int i = tid; i < nrows; i += RES_THREADS) {
     float ls = 1.0e30f, dl = 0.f;
@@ -711,7 +786,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p) {
   }
   __syncthreads();
 
-  for (int kbk = kb0 + wave; kbk * 16 < nkeys; kbk += (RES_THREADS / 64) * (int)gridDim.z) {
+  for (int kbk = kb0 + wave; kbk * 16 < nkeys; kbk += (RES_THREADS / 64) * nparts) {
     const int c = kbk * 16 + r15;
     const T* kp = nullptr;
     float kbias = NEG_BIG;
@@ -787,18 +862,27 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
       }
-      // (z > 1 deals a window's 16-row blocks to several workgroups in runs of 8.  Measured on the stage-3 windows: SLOWER, 58 -> 66 us
-      // per backward pair -- these kernels are bound by the staging latency of a workgroup (pointer table, K/V loads, LDS stores:
-      // ~2/3 of its time), which every extra workgroup pays again, and at 133 KiB of LDS only one workgroup fits a CU.)
-      const dim3 grid(p.heads, nwin, 1), gridk(p.heads, nwin, 1);
+      // units in longest-first order (ResPlan): a full 16 x 16 window is two workgroups.  (Round 2, first attempt: the same split as a
+      // grid z dimension was SLOWER, 58 -> 66 us per backward pair -- z-major dispatch put the second halves of the big windows LAST,
+      // behind 192 empty workgroups, on CUs that had already run a small window.)
+      const ResPlan plq = res_plan(p, false), plk = res_plan(p, true);
+      const dim3 grid(p.heads, plq.total, 1), gridk(p.heads, plk.total, 1);
       if (which == 0) {
-        hipLaunchKernelGGL((attn_res_q_kernel<T, HD, false>), grid, dim3(RES_THREADS), LDS, s, p);
+#ifdef SPG_DEV_KERNELS
+        static const char* st_ = getenv("SPG_ATTN_STAMPS");
+        if (st_ && atoi(st_) == 1) {
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_q_kernel<T, HD, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+          hipLaunchKernelGGL((attn_res_q_kernel<T, HD, false, 1>), grid, dim3(RES_THREADS), LDS, s, p, plq);
+          return check_launch("attn_fwd(res, stamps)");
+        }
+#endif
+        hipLaunchKernelGGL((attn_res_q_kernel<T, HD, false>), grid, dim3(RES_THREADS), LDS, s, p, plq);
         return check_launch("attn_fwd(res)");
       }
-      hipLaunchKernelGGL((attn_res_q_kernel<T, HD, true>), grid, dim3(RES_THREADS), LDS, s, p);
+      hipLaunchKernelGGL((attn_res_q_kernel<T, HD, true>), grid, dim3(RES_THREADS), LDS, s, p, plq);
       int rc = check_launch("attn_bwd_dq(res)");
       if (rc) return rc;
-      hipLaunchKernelGGL((attn_res_dkv_kernel<T, HD>), gridk, dim3(RES_THREADS), LDS, s, p);
+      hipLaunchKernelGGL((attn_res_dkv_kernel<T, HD>), gridk, dim3(RES_THREADS), LDS, s, p, plk);
       return check_launch("attn_bwd_dkv(res)");
     }
   }
@@ -854,6 +938,12 @@ static int dispatch_hd(int which, AttnP p, int hd, int maxq, int maxk, hipStream
 
 using namespace spg;
 
+#ifdef SPG_DEV_KERNELS
+extern "C" int spg_dev_attn_stamps(unsigned long long* out, int* nq) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(spg::attn_stamps), sizeof(unsigned long long) * 2048 * 8 * 4) != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(nq, HIP_SYMBOL(spg::attn_stamp_nq), sizeof(int) * 2048) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int spg_attn_fwd(int dtype, const void* qkv, const void* q_pooled, const void* qkv_bias_t, void* out,
                             float* lse, int B, int H, int W, int heads, int hd, int ws, spg_stream_t stream) {
   SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "attn_fwd: bad dtype");
