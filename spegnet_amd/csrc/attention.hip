@@ -28,6 +28,8 @@ struct AttnP {
   void* out; float* lse;
   const void* dout; void* dqkv; void* dqp; float* dbias; float* delta;
   int B, H, W, heads, ws, nwy, nwx, Hq, Wq, wsq, C;
+  int wsx, wsxq;   // window WIDTH in key / query tokens (= ws / wsq except for packed small windows, below)
+  int sub;         // > 0: a 'window' is `wsx / sub` real windows of width `sub` side by side; tokens attend only inside their own
   float scale;
 };
 
@@ -41,12 +43,12 @@ __device__ __forceinline__ Win get_win(const AttnP& p, int widx) {
   w.b = widx / per;
   const int r = widx - w.b * per;
   const int wy = r / p.nwx, wx = r - wy * p.nwx;
-  w.y0 = wy * p.ws; w.x0 = wx * p.ws;
-  w.hv = min(p.ws, p.H - w.y0); w.wv = min(p.ws, p.W - w.x0);
+  w.y0 = wy * p.ws; w.x0 = wx * p.wsx;
+  w.hv = min(p.ws, p.H - w.y0); w.wv = min(p.wsx, p.W - w.x0);
   w.nvalid = w.hv * w.wv;
-  w.npad = p.ws * p.ws - w.nvalid;
+  w.npad = p.ws * p.wsx - w.nvalid;
   if (p.qp) {
-    w.y0q = wy * p.wsq; w.x0q = wx * p.wsq;
+    w.y0q = wy * p.wsq; w.x0q = wx * p.wsxq;
     w.wvq = w.wv >> 1;
     w.nq = (w.hv >> 1) * w.wvq;
   } else {
@@ -62,6 +64,16 @@ __device__ __forceinline__ long key_row(const AttnP& p, const Win& w, int c) {
 __device__ __forceinline__ long q_row(const AttnP& p, const Win& w, int i) {
   const int ly = i / w.wvq, lx = i - ly * w.wvq;
   return ((long)w.b * p.Hq + w.y0q + ly) * p.Wq + w.x0q + lx;
+}
+
+// Packed small windows (sub > 0: 4 x 4 windows of stage 2, four side by side in one 4 x 16 'window' = one 64-token tile, so that a
+// workgroup's four waves and the 64-slot tile are all used instead of a quarter of each): a key / query pair interacts only if both lie in
+// the same real window.  With 16-wide rows the real window of key c is (c % 16) / 4 and of query i is (i % 16) / 4 -- or (i % 8) / 2
+// for 2 x 2-pooled queries -- so in the tile layouts below the test is a lane constant or depends on the register index only.
+__device__ __forceinline__ bool same_sub(const AttnP& p, int qi, int kc) {
+  const int ks = (kc & 15) >> 2;
+  const int qs = p.qp ? ((qi & 7) >> 1) : ((qi & 15) >> 2);
+  return ks == qs;
 }
 
 // Work units of the resident-window kernels, largest first (longest-processing-time order: the hardware dispatches workgroups in
@@ -81,7 +93,7 @@ __device__ __forceinline__ void res_unit(const ResPlan& pl, const AttnP& p, int 
   part = v % nparts;
   const int wi = v / nparts;                 // window of class c, image-major
   const int b = wi / pl.cnt[c], k = wi - b * pl.cnt[c];
-  const int nfy = p.H / p.ws, nfx = p.W / p.ws;
+  const int nfy = p.H / p.ws, nfx = p.W / p.wsx;
   int wy, wx;
   if (c == 0) { wy = k / nfx; wx = k - wy * nfx; }
   else if (c == 1) { wy = k; wx = nfx; }     // right edge: one per full window row
@@ -91,8 +103,8 @@ __device__ __forceinline__ void res_unit(const ResPlan& pl, const AttnP& p, int 
 }
 static ResPlan res_plan(const AttnP& p, bool keys) {
   ResPlan pl;
-  const int nfy = p.H / p.ws, nfx = p.W / p.ws, ry = p.H % p.ws, rx = p.W % p.ws;
-  const int hv[4] = {p.ws, p.ws, ry, ry}, wv[4] = {p.ws, rx, p.ws, rx};
+  const int nfy = p.H / p.ws, nfx = p.W / p.wsx, ry = p.H % p.ws, rx = p.W % p.wsx;
+  const int hv[4] = {p.ws, p.ws, ry, ry}, wv[4] = {p.wsx, rx, p.wsx, rx};
   const int cnt[4] = {nfy * nfx, rx ? nfy : 0, ry ? nfx : 0, (rx && ry) ? 1 : 0};
   int u = 0;
   for (int c = 0; c < 4; ++c) {
@@ -255,7 +267,7 @@ __device__ __forceinline__ void store_rows_T(T* row, const f32x4 (&acc)[AC<T, HD
 // =====================================================================================================
 // forward
 // =====================================================================================================
-template <typename T, int HD>
+template <typename T, int HD, bool SUB = false>   // SUB: packed 4 x 4 windows (block mask same_sub)
 __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -307,7 +319,11 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
     for (int nb = 0; nb < 4; ++nb) {
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + nb * 16 + q * 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { pv[nb][r] = sacc[nb][r] * p.scale + b4[r]; mx = fmaxf(mx, pv[nb][r]); }
+      for (int r = 0; r < 4; ++r) {
+        pv[nb][r] = sacc[nb][r] * p.scale + b4[r];
+        if constexpr (SUB) { if (!same_sub(p, qi, t * 64 + nb * 16 + q * 4 + r)) pv[nb][r] = NEG_BIG; }
+        mx = fmaxf(mx, pv[nb][r]);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
 // =====================================================================================================
 // backward, query side: dQ (+ delta = rowsum(dO*O) written for the dK/dV kernel)
 // =====================================================================================================
-template <typename T, int HD>
+template <typename T, int HD, bool SUB = false>   // SUB: packed 4 x 4 windows (block mask same_sub)
 __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -401,7 +417,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + nb * 16 + q * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pr = __expf(sacc[nb][r] * p.scale + b4[r] - lse);
+        float pr = __expf(sacc[nb][r] * p.scale + b4[r] - lse);
+        if constexpr (SUB) { if (!same_sub(p, qi, t * 64 + nb * 16 + q * 4 + r)) pr = 0.f; }
         ds[nb][r] = pr * (pacc[nb][r] - delta);
       }
     }
@@ -417,7 +434,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
 // =====================================================================================================
 // backward, key side: dK, dV (keys stationary, queries streamed)
 // =====================================================================================================
-template <typename T, int HD>
+template <typename T, int HD, bool SUB = false>   // SUB: packed 4 x 4 windows (block mask same_sub)
 __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -483,6 +500,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pr[nb][r] = __expf(sacc[nb][r] * p.scale + kbias - l4[r]);
+        if constexpr (SUB) { if (!same_sub(p, t * 64 + nb * 16 + q * 4 + r, c)) pr[nb][r] = 0.f; }
         ds[nb][r] = pr[nb][r] * (pacc[nb][r] - d4[r]);
       }
     }
@@ -886,14 +904,17 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
       return check_launch("attn_bwd_dkv(res)");
     }
   }
+  const bool sub = p.sub > 0;
   if (which == 0) {
     const size_t lds = 2 * A::ROW_BYTES + 64 * 8 + 64 * 4;
-    hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
+    if (sub) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, HD, false>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
     return check_launch("attn_fwd");
   }
   {
     const size_t lds = 2 * A::ROW_BYTES + 64 * 8 + 64 * 4;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
+    if (sub) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, true>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, false>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
     int rc = check_launch("attn_bwd_dq");
     if (rc) return rc;
   }
@@ -901,10 +922,14 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
     const size_t lds = 2 * A::ROW_BYTES + 2 * 64 * 8 + 2 * 64 * 4;
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3(cdiv(maxk, 64), p.heads, nwin), dim3(AT), lds, s, p);
+    // (packed windows have no padded slots: exactly maxk - 1 keys, one key tile)
+    const int kx = cdiv(sub ? maxk - 1 : maxk, 64);
+    if (sub) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, true>), dim3(kx, p.heads, nwin), dim3(AT), lds, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, false>), dim3(kx, p.heads, nwin), dim3(AT), lds, s, p);
     return check_launch("attn_bwd_dkv");
   }
 }
@@ -912,13 +937,17 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
 static int fill_geom(AttnP& p, int B, int H, int W, int heads, int hd, int ws, bool pooled, int* maxq, int* maxk) {
   p.B = B; p.H = H; p.W = W; p.heads = heads; p.C = heads * hd;
   if (ws <= 0) ws = H > W ? H : W;
-  p.ws = ws; p.nwy = cdiv(H, ws); p.nwx = cdiv(W, ws);
-  if (pooled) {
-    if ((H | W | ws) & 1) { set_error("attn: pooled queries need even H, W, window (H=%d W=%d ws=%d)", H, W, ws); return SPG_ERR_BAD_ARG; }
-    p.Hq = H / 2; p.Wq = W / 2; p.wsq = ws / 2;
-  } else { p.Hq = H; p.Wq = W; p.wsq = ws; }
+  if (pooled && ((H | W | ws) & 1)) { set_error("attn: pooled queries need even H, W, window (H=%d W=%d ws=%d)", H, W, ws); return SPG_ERR_BAD_ARG; }
+  // 4 x 4 windows that tile the map exactly (stage 2 of Hiera at any multiple-of-64 image size): four windows side by side are
+  // processed as ONE 4 x 16 'window' with a block mask (same_sub) -- a full 64-token tile and four busy waves per workgroup
+  const bool pack = ws == 4 && H % 4 == 0 && W % 16 == 0;
+  const int wsx = pack ? 16 : ws;
+  p.ws = ws; p.wsx = wsx; p.sub = pack ? 4 : 0;
+  p.nwy = cdiv(H, ws); p.nwx = cdiv(W, wsx);
+  if (pooled) { p.Hq = H / 2; p.Wq = W / 2; p.wsq = ws / 2; p.wsxq = wsx / 2; }
+  else { p.Hq = H; p.Wq = W; p.wsq = ws; p.wsxq = wsx; }
   p.scale = 1.0f / sqrtf((float)hd);
-  const int hv = ws < H ? ws : H, wv = ws < W ? ws : W;
+  const int hv = ws < H ? ws : H, wv = wsx < W ? wsx : W;
   *maxk = hv * wv + 1;
   *maxq = pooled ? (hv / 2) * (wv / 2) : hv * wv;
   return SPG_OK;

@@ -270,6 +270,10 @@ ATTN_CASES = [
     (1, 24, 24, 2, 72, 16, True),    # block 44 style transition
     (1, 12, 12, 2, 72, 8, False),    # stage 4 @384
     (1, 6, 6, 2, 32, 4, False),
+    (2, 16, 16, 2, 72, 4, False),    # 4 x 4 windows, W % 16 == 0: four windows packed per 64-token tile (stage 2 of Hiera-L)
+    (1, 8, 32, 4, 72, 4, False),     # ... non-square map
+    (2, 16, 16, 2, 72, 4, True),     # ... with 2 x 2-pooled queries (the stage 2 -> 3 transition block)
+    (1, 12, 16, 2, 16, 4, False),
 ]
 
 
