@@ -43,7 +43,7 @@ class TrainStep:
                     stay outside graph capture, yet overlap with backward."""
 
     def __init__(self, model: SPEGNet, criterion: CODLoss, arena: Arena, grad_clip: float = 1.0, sync: Optional[GradSync] = None,
-                 capture: bool = False, force_segmented: bool = False):
+                 capture: bool = False, force_segmented: bool = False, wgrad_async: bool = False):
         self.model, self.criterion, self.arena, self.clip, self.sync = model, criterion, arena, grad_clip, sync
         self.capture = capture
         self.force_segmented = force_segmented   # tests: exercise the multi-GPU segmented capture on one rank
@@ -54,9 +54,9 @@ class TrainStep:
         self.static = None
         self.losses = None
         self.world = sync.world if sync is not None else 1
-        # forked weight-gradient stream (models/engine.py), opt-in with SPG_WGRAD_ASYNC=1: measured SLOWER on one MI355X (226.0 vs 232.2
-        # img/s on the B=8@384 graph step) -- both branches are chip-sized persistent kernels, so they contend instead of packing
-        model.engine.wgrad_async = ((sync is None) or capture) and os.environ.get("SPG_WGRAD_ASYNC", "0") == "1"
+        # forked weight-gradient stream (models/engine.py; `TrainStep(..., wgrad_async=True)` for A/B runs): measured SLOWER on one MI355X
+        # (226.0 vs 232.2 img/s on the B=8@384 graph step) -- both branches are chip-sized persistent kernels, so they contend
+        model.engine.wgrad_async = ((sync is None) or capture) and bool(wgrad_async)
         if sync is not None and not capture:
             ends = arena.unit_ends
             model.engine.unit_cb = lambda k: sync.ready(ends[k])
