@@ -305,9 +305,12 @@ int spg_loss_reduce(int dtype, const void* pred, const float* target, const floa
                     long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
 int spg_loss_finalize(const float* stats, const float* seg_sums, const float* edge_sums, float* out, int B, int S,
                       float sw0, float sw1, float sw2, float bce_w, float iou_w, float edge_w, spg_stream_t stream);
+/* dz_ws: B*S*S floats of scratch or NULL.  With it (and a prediction coarser than the target) the gradient runs as two passes -- the
+ * loss derivative of every full-res pixel once, then the adjoint of the bilinear up-sampling -- instead of re-evaluating the
+ * derivative for every low-res logit whose window covers a pixel (9x fewer evaluations at the trunk's three scales).              */
 int spg_loss_grad(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
                   const float* sums, const float* grad_out, void* dpred, int B, int S, int h, int w, int edge, float coef,
-                  float bce_w, float iou_w, float alpha, float gamma, spg_stream_t stream);
+                  float bce_w, float iou_w, float alpha, float gamma, float* dz_ws, spg_stream_t stream);
 
 /* ---- optimizer (engine/trainer.py:274-306 param groups, :399-409 clip + AdamW step) over a flat f32 arena ---------
  * sumsq: out[0] = sum x^2 (deterministic: 2048 floats of scratch + one zeroed counter, see "Deterministic reductions").  adamw: step_f[0] += 1, then clip coefficient min(1, clip/(sqrt(gnorm_sq)*grad_scale+1e-6))

@@ -80,7 +80,7 @@ SIGNATURES = {
     "spg_loss_weight_map": "pppp" "iif" "plp" "p",
     "spg_loss_reduce": "ippppp" "iiiiiff" "plp" "p",
     "spg_loss_finalize": "pppp" "iiffffffp",
-    "spg_loss_grad": "ippppppp" "iiiiifffffp",
+    "spg_loss_grad": "ippppppp" "iiiiifffff" "pp",
     "spg_sumsq": "pp" "l" "plp" "p",
     "spg_adamw": "ppppppppp" "fffff" "ilp",
     "spg_adamw_pack": "i" "ppppppppp" "fffff" "i" "pii" "p",

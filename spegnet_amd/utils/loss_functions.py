@@ -60,19 +60,20 @@ class _FusedCODLoss(torch.autograd.Function):
         B, S = masks.shape[0], masks.shape[-1]
         st = torch.cuda.current_stream().cuda_stream
         go = g_loss.float().contiguous() if g_loss is not None else None
+        dz = torch.empty((B, S, S), dtype=torch.float32, device=masks.device)   # scratch of the two-pass gradient (stream-ordered reuse)
         grads = []
         for i in range(3):
             h, w = preds[i].shape[-2:]
             d = torch.empty_like(preds[i])
             _lib.call("spg_loss_grad", dt, preds[i].data_ptr(), masks.data_ptr(), wmap.data_ptr(), stats.data_ptr(),
                       seg_sums[i * 3 * B:].data_ptr(), go.data_ptr() if go is not None else None, d.data_ptr(), B, S, h, w, 0,
-                      float(sw[i]) / B, float(bce_w), float(iou_w), 0.0, 0.0, st)
+                      float(sw[i]) / B, float(bce_w), float(iou_w), 0.0, 0.0, dz.data_ptr(), st)
             grads.append(d)
         h, w = preds[3].shape[-2:]
         d = torch.empty_like(preds[3])
         _lib.call("spg_loss_grad", dt, preds[3].data_ptr(), edges.data_ptr(), None, stats.data_ptr(), edge_sums.data_ptr(),
                   go.data_ptr() if go is not None else None, d.data_ptr(), B, S, h, w, 1, float(edge_w) / B, 0.0, 0.0, float(alpha),
-                  float(gamma), st)
+                  float(gamma), dz.data_ptr(), st)
         grads.append(d)
         return grads[0], grads[1], grads[2], grads[3], None, None, None
 
