@@ -196,6 +196,31 @@ def test_preprocess_image_matches_reference_arithmetic(ops, H, W, S):
     assert err < 5e-6, f"max abs err {err:.2e}"
 
 
+def test_preprocess_batch_and_device_batcher_match_single_image_kernel(ops):
+    """the batched launch (ragged image sizes packed in one uint8 buffer) and the double-buffered DeviceBatcher around
+    it must give exactly what the single-image kernel gives per image (itself pinned to the reference's CODImageProcessor above)."""
+    from spegnet_amd.utils.data_loader import DeviceBatcher
+    g = torch.Generator().manual_seed(11)
+    sizes = [(300, 400), (384, 384), (97, 513), (640, 480), (64, 64)]
+    imgs = [torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8) for h, w in sizes]
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    ref = torch.stack([ops.preprocess_image(im.cuda(), 96, mean, std) for im in imgs])
+    offs, off = [], 0
+    for h, w in sizes:
+        offs.append(off)
+        off += (h * w * 3 + 255) // 256 * 256
+    base = torch.zeros(off, dtype=torch.uint8)
+    for im, o in zip(imgs, offs):
+        base[o:o + im.numel()] = im.reshape(-1)
+    out = ops.preprocess_batch(base.cuda(), offs, sizes, 96, mean, std)
+    assert torch.equal(out, ref)
+    db = DeviceBatcher(96, mean, std, "cuda", max_bytes=4 << 20)
+    h1 = db.submit(imgs[:3])
+    h2 = db.submit(imgs[3:])            # two batches in flight (the trainer's prefetch)
+    h3 = db.submit(imgs[:2])            # ... and a staging buffer being re-used
+    assert torch.equal(db.result(h1), ref[:3]) and torch.equal(db.result(h2), ref[3:]) and torch.equal(db.result(h3), ref[:2])
+
+
 def test_pack_matrix(ops):
     w = rnd(37, 53, seed=1)
     assert torch.equal(ops.pack_matrix(w, torch.float32), w)
