@@ -134,6 +134,41 @@ def test_predict_batch_is_batched_and_equals_predict_single(tmp_path):
         assert float(np.abs(bs - seg).max()) < 2e-3 and float(np.abs(be - edge).max()) < 2e-3, p
 
 
+def test_predict_batch_at_config3_batch_size(tmp_path):
+    """BASELINE config #3's shape of work through the Predictor (reference engine/predictor.py:376-430): batch_size 64 -> one captured
+    forward for the full chunk of 64 images, an eager one for the remaining 6; spot-checked against predict_single."""
+    from PIL import Image
+    from spegnet_amd.engine.predictor import Predictor
+    cfg = _cfg()
+    sd = O.init_state_dict(seed=2, cfg=O.HIERA_TINY_TEST)
+    ck = tmp_path / "model_best.pth"
+    mc = dict(cfg["model"], compute_dtype="bf16")
+    torch.save({"model_state_dict": sd, "config": {"model": mc}}, ck)
+    rng = np.random.RandomState(3)
+    paths = []
+    for i in range(70):
+        p = tmp_path / f"im{i:02d}.png"
+        Image.fromarray(rng.randint(0, 255, (40 + i % 7, 48 + i % 5, 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+
+    class Keep:
+        def __init__(self): self.items, self.t = {}, {}
+        def update_timing(self, k, v): self.t.setdefault(k, []).append(v)
+        def log_message(self, m): pass
+        def save_prediction(self, name, seg, edge, orig): self.items[name] = (seg.copy(), edge.copy(), orig.shape)
+        def summarize(self): return {"total_predictions": len(self.items), "forwards": len(self.t.get("inference", []))}
+
+    keep = Keep()
+    pr = Predictor(str(ck), mc, dir_manager=None, device="cuda", batch_size=64, result_manager=keep)
+    out = pr.predict_batch(paths, output_size=(64, 64))
+    assert out["total_predictions"] == 70 and out["forwards"] == 2, out
+    single = Predictor(str(ck), mc, dir_manager=None, device="cuda", batch_size=1)
+    for i in (0, 37, 63, 69):
+        seg, edge, _ = single.predict_single(paths[i], output_size=(64, 64))
+        name = [k for k in keep.items if k.startswith(f"im{i:02d}")][0]
+        assert float(np.abs(keep.items[name][0] - seg).max()) < 2e-2 and float(np.abs(keep.items[name][1] - edge).max()) < 2e-2
+
+
 def test_trainer_train_loop_with_loader_device_preprocess_and_resume(tmp_path):
     """Trainer.train(dataset_dirs) end to end on a synthetic on-disk dataset: the package's own loader (reference surface), original-size
     (ragged, non-square) ground truth -> the per-sample loss path, device preprocessing + prefetch, checkpoints, and resume()."""
