@@ -303,8 +303,11 @@ __global__ __launch_bounds__(256) void loss_gather_kernel(const float* __restric
     const int xl = (int)(i % w);
     const int yl = (int)((i / w) % h);
     const int b = (int)(i / ((long)w * h));
-    const int Y0 = max(0, (yl - 1) * sy), Y1 = min(S - 1, (yl + 2) * sy);
-    const int X0 = max(0, (xl - 1) * sx), X1 = min(S - 1, (xl + 2) * sx);
+    // full-res pixels whose taps include (yl, xl): source coordinate (Y + 0.5) / sy - 0.5 in [yl - 1, yl + 1), i.e. for an even scale
+    // exactly the 2 sy rows [yl sy - sy/2, yl sy + 3 sy/2 - 1] (clamped: the border clamps of the interpolation fall inside); an odd
+    // scale keeps the conservative (3 sy)-row window -- candidates outside the taps weigh 0 either way
+    const int Y0 = (sy & 1) ? max(0, (yl - 1) * sy) : max(0, yl * sy - sy / 2), Y1 = (sy & 1) ? min(S - 1, (yl + 2) * sy) : min(S - 1, yl * sy + 3 * sy / 2 - 1);
+    const int X0 = (sx & 1) ? max(0, (xl - 1) * sx) : max(0, xl * sx - sx / 2), X1 = (sx & 1) ? min(S - 1, (xl + 2) * sx) : min(S - 1, xl * sx + 3 * sx / 2 - 1);
     const int nx = X1 - X0 + 1, ncand = (Y1 - Y0 + 1) * nx;
     float acc = 0.f;
     for (int c = lane; c < ncand; c += 64) {
