@@ -1741,6 +1741,7 @@ __device__ __forceinline__ int div_small(int m, int d, float rd) {
   return qq;
 }
 
+#ifdef SPG_DEV_KERNELS   // superseded by gemm_tn_pipe4_kernel (specialised waves); kept for A/B runs (SPG_TN_GROUP_V4=0)
 template <typename T, bool CONV, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__ dY, const T* __restrict__ X, int M, int N, int K, int ldy,
                                                            int ldx, ConvGeom g, int tiles_k, int tiles, int splits, int m_per_split,
@@ -1941,6 +1942,8 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+#endif  // SPG_DEV_KERNELS (8-wave single-problem wgrad kernel)
 
 // ------------------------------------------------------------------------------------------------
 // gemm_tn_pipe4_kernel: gemm_tn_pipe_kernel's schedule (units = tile x M split, partial sums to the split's slab) with SPECIALISED
@@ -2186,6 +2189,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
+#ifdef SPG_DEV_KERNELS   // superseded by gemm_tn_group4_kernel (specialised waves); kept for A/B runs and the ablation modes
 template <typename T, int DBG = 0>   // DBG 2: no MFMAs (times the fill + read pipeline alone; wrong results by construction)
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
   static_assert(sizeof(T) == 2, "bf16 only");
@@ -2448,6 +2452,8 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __
   }
 #endif
 }
+
+#endif  // SPG_DEV_KERNELS (8-wave grouped wgrad kernel)
 
 // ------------------------------------------------------------------------------------------------
 // gemm_tn_group4_kernel: the same grouped schedule (whole tiles, then an equal share of the remainder tiles' steps; slab slots and
@@ -3629,12 +3635,14 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
         const int units = tiles * sp;
         const int grid = units < num_cus(cu_budget) ? units : num_cus(cu_budget);
         constexpr int LDSP = 4 * 32768;
+#ifdef SPG_DEV_KERNELS
         static bool attrp = false;
         if (!attrp) {
           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe_kernel<T, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe_kernel<T, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
           attrp = true;
         }
+#endif
         if (tn_group_v4()) {   // specialised waves (dev builds: SPG_TN_GROUP_V4=0 selects the 8-wave kernels)
           static bool attr4 = false;
           if (!attr4) {
@@ -3648,12 +3656,15 @@ static int launch_tn(const void* dY, const void* X, float* dW, int M, int N, int
           else
             hipLaunchKernelGGL((gemm_tn_pipe4_kernel<T, false>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, g,
                                tiles_k, tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
-        } else if (conv)
+        }
+#ifdef SPG_DEV_KERNELS
+        else if (conv)
           hipLaunchKernelGGL((gemm_tn_pipe_kernel<T, true, 0>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, g,
                              tiles_k, tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
         else
           hipLaunchKernelGGL((gemm_tn_pipe_kernel<T, false, 0>), dim3(grid), dim3(512), LDSP, s, (const T*)dY, (const T*)X, M, N, K, ldy, ldx, g,
                              tiles_k, tiles, sp, mps, (unsigned)yb, (unsigned)xb, dbias, ws, (unsigned)need);
+#endif
         int rc = check_launch("gemm_tn(pipe)");
         if (rc) return rc;
         const long nk4 = (long)N * K / 4;
@@ -3806,12 +3817,12 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   SPG_REQUIRE(workspace && workspace_bytes >= need, "gemm_tn_group: workspace of %ld bytes needed (got %ld)", need, workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
   constexpr int LDSG = 4 * 32768;
+#ifdef SPG_DEV_KERNELS
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     attr = true;
   }
-#ifdef SPG_DEV_KERNELS
   const int dbgg = tn_group_v4() ? 0 : dev_env("SPG_TN_GROUP_DEBUG", 0);   // 8-wave kernel's ablations (wrong results by construction): 2 no MFMAs, 3 no fragment reads, 4 no fill, 5 stamps, 6 late DMA
   if (dbgg == 2) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
@@ -3852,8 +3863,10 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
       attr4 = true;
     }
     hipLaunchKernelGGL((gemm_tn_group4_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
-  } else
-  hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+  }
+#ifdef SPG_DEV_KERNELS
+  else hipLaunchKernelGGL((gemm_tn_group_kernel<bf16_t>), dim3(G), dim3(512), LDSG, s, g, (float*)workspace, (unsigned)need);
+#endif
   int rc = check_launch("gemm_tn_group");
   if (reduce_desc_out) {     // deferred: the caller collects descriptors and folds the slabs later (spg_gemm_tn_group_reduce_batch)
     TnReduceDesc d;
