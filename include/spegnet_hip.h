@@ -28,7 +28,10 @@ typedef void* spg_stream_t; /* hipStream_t */
 
 enum { SPG_F32 = 0, SPG_BF16 = 1 };
 enum { SPG_OK = 0, SPG_ERR_BAD_ARG = -1, SPG_ERR_LAUNCH = -2, SPG_ERR_UNSUPPORTED = -3 };
-enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2 };
+enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
+       /* gemm_nt, bf16: C = gelu(pre), C2 = gelu'(pre) -- the derivative is saved instead of the pre-activation (the MLP's backward
+        * needs nothing else from it) -- and its partner for the backward GEMM: C = acc * gelu_h (+ residual), gelu_h = that derivative */
+       SPG_ACT_GELU_SAVE_GRAD = 3, SPG_ACT_MUL_H = 4 };
 
 int spg_version(void);
 const char* spg_last_error(void);

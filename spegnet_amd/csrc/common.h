@@ -113,6 +113,19 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// gelu(x) and gelu'(x) together: the exponential inside erf_fast(x / sqrt 2) IS exp(-x^2 / 2), the density's -- the derivative costs four
+// more operations when it is formed next to the value (forward epilogue), against a second erf + exp when it is re-derived from the saved
+// pre-activation in the backward epilogue.  g is bit-identical to gelu_f(x).
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& d) {
+  const float u = x * 0.70710678118654752440f;
+  const float ax = fabsf(u);
+  const float t = __frcp_rn(1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __expf(-ax * ax);
+  const float erf = copysignf(1.f - poly * e, u);
+  g = 0.5f * x * (1.f + erf);
+  d = 0.5f * (1.f + erf) + x * (0.39894228040143267794f * e);
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // ---- deterministic cross-workgroup reductions ----------------------------------------------------------

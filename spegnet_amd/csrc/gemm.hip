@@ -567,7 +567,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const T* __restri
 constexpr int PIPE_STAGES = 4;
 constexpr int PIPE_SLAB_BYTES = 16 * 64 * 4;
 constexpr int PIPE_LDS_BYTES = PIPE_STAGES * DMA_STAGE_BYTES + 8 * PIPE_SLAB_BYTES;
-enum { PIPE_ACT_NONE = 0, PIPE_ACT_GELU = 1, PIPE_ACT_HH = 2 };   // none | C2 = preact, C = gelu(.) | C = (.) * gelu'(gelu_h)
+enum { PIPE_ACT_NONE = 0, PIPE_ACT_GELU = 1, PIPE_ACT_HH = 2,   // none | C2 = preact, C = gelu(.) | C = (.) * gelu'(gelu_h)
+       PIPE_ACT_GELU_D = 3, PIPE_ACT_MULH = 4 };                   // C2 = gelu'(preact), C = gelu(.) | C = (.) * gelu_h
 
 __device__ __forceinline__ void wait_vm(int n) {  // s_waitcnt vmcnt(<= n), n wave-uniform, n >= 8
   if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
         const int m = pm0 + wm * 32 + qt * 16 + erow + 8 * jj;
         eo[qt][jj] = (nin && m < M) ? (unsigned)(((long)m * ldc + n) * 2) : OOB;
         er[qt][jj] = bload16(rr, eo[qt][jj]);
-        if constexpr (ACT == PIPE_ACT_HH) eh[qt][jj] = bload16(hr, eo[qt][jj]);
+        if constexpr (ACT == PIPE_ACT_HH || ACT == PIPE_ACT_MULH) eh[qt][jj] = bload16(hr, eo[qt][jj]);
       }
   };
   auto epi_run = [&]() __attribute__((always_inline)) {
@@ -756,11 +757,23 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
 #pragma unroll
           for (int e = 0; e < 8; ++e) ev[e] = gelu_f(ev[e]);
         }
+        if constexpr (ACT == PIPE_ACT_GELU_D) {
+          float dv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gelu_both_f(ev[e], ev[e], dv[e]);
+          bstore16(c2r, eo[qt][jj], pack16<T>(dv));
+        }
         if constexpr (ACT == PIPE_ACT_HH) {
           float h[8];
           unpack16<T>(eh[qt][jj], h);
 #pragma unroll
           for (int e = 0; e < 8; ++e) ev[e] *= gelu_grad_f(h[e]);
+        }
+        if constexpr (ACT == PIPE_ACT_MULH) {
+          float h[8];
+          unpack16<T>(eh[qt][jj], h);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ev[e] *= h[e];
         }
         float rres[8];
         unpack16<T>(er[qt][jj], rres);
@@ -817,8 +830,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
       bstore16(cr, eo[qt][jj], pack16<T>(cv));
     }
   };
-  constexpr int stores_per_chunk = (ACT == PIPE_ACT_GELU ? 4 : 2);
-  constexpr int stores_per_tile = (ACT == PIPE_ACT_GELU ? 8 : 4);
+  constexpr int stores_per_chunk = ((ACT == PIPE_ACT_GELU || ACT == PIPE_ACT_GELU_D) ? 4 : 2);
+  constexpr int stores_per_tile = ((ACT == PIPE_ACT_GELU || ACT == PIPE_ACT_GELU_D) ? 8 : 4);
 
   // ---- prologue: 4 groups in flight, stage 0 landed, its fragments requested.  Because a stage's fragments sit in registers one
   // step before they are multiplied, its LDS slot is free again at the top of that step: group k+4 goes into stage k's slot, i.e.
@@ -1128,7 +1141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
       for (int v = 0; v < NV; ++v) {
         const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
         er[mi][v] = bload16(rr, o);
-        if constexpr (ACT == PIPE_ACT_HH) eh[mi][v] = bload16(hr, o);
+        if constexpr (ACT == PIPE_ACT_HH || ACT == PIPE_ACT_MULH) eh[mi][v] = bload16(hr, o);
       }
     }
   };
@@ -1197,11 +1210,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
 #pragma unroll
         for (int e = 0; e < 8; ++e) ev[e] = gelu_f(ev[e]);
       }
+      if constexpr (ACT == PIPE_ACT_GELU_D) {
+        float dv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gelu_both_f(ev[e], ev[e], dv[e]);
+        bstore16(c2r, o, pack16<T>(dv));
+      }
       if constexpr (ACT == PIPE_ACT_HH) {
         float h[8];
         unpack16<T>(eh[mi][v], h);
 #pragma unroll
         for (int e = 0; e < 8; ++e) ev[e] *= gelu_grad_f(h[e]);
+      }
+      if constexpr (ACT == PIPE_ACT_MULH) {
+        float h[8];
+        unpack16<T>(eh[mi][v], h);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ev[e] *= h[e];
       }
       float rres[8];
       unpack16<T>(er[mi][v], rres);
@@ -1366,7 +1391,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const bf16_t* __restric
       for (int v = 0; v < NV; ++v) {
         const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
         er[mi][v] = bload16(rr, o);
-        if constexpr (ACT == PIPE_ACT_HH) eh[mi][v] = bload16(hr, o);
+        if constexpr (ACT == PIPE_ACT_HH || ACT == PIPE_ACT_MULH) eh[mi][v] = bload16(hr, o);
       }
     }
   };
@@ -3260,8 +3285,10 @@ static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M,
   const int tiles_m = cdiv(M, BM);
   const long xb = (conv ? (long)M * g.Ci : (long)M * ldx) * 2L, wb = (long)N * K * 2L;
   const long cb = ((long)(M - 1) * ldc + N) * 2;
-  const int pact = epi.gelu_h ? PIPE_ACT_HH : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : PIPE_ACT_NONE);
-  const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE) && (epi.C2 == nullptr || pact == PIPE_ACT_GELU) &&
+  const int pact = epi.gelu_h ? (epi.act == SPG_ACT_MUL_H ? PIPE_ACT_MULH : PIPE_ACT_HH)
+                                 : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : (epi.act == SPG_ACT_GELU_SAVE_GRAD ? PIPE_ACT_GELU_D : PIPE_ACT_NONE));
+  const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE && epi.act != SPG_ACT_MUL_H) &&
+                      (epi.C2 == nullptr || pact == PIPE_ACT_GELU || pact == PIPE_ACT_GELU_D) && (pact != PIPE_ACT_GELU_D || epi.C2 != nullptr) &&
                       !(conv && pact != PIPE_ACT_NONE);
   if (nt_v3_enabled() && N % 8 == 0 && ldc % 8 == 0 && K % 8 == 0 && (conv ? g.Ci % 8 == 0 : ldx % 8 == 0) && cb < 0xFFFFFFF0L &&
       xb < 0xFFFFFFF0L && wb < 0xFFFFFFF0L && epi_ok) {
@@ -3281,7 +3308,7 @@ static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M,
       // the CFI fusion GEMM), it loses 10-60 %.  Dispatch on exactly that.
       const int cus3 = hw_cus();
 #ifdef SPG_DEV_KERNELS
-      if (nt_v5_mode() == 1 || (nt_v5_mode() == 2 && !conv && K > 1536)) {   // A/B runs of the specialised-wave NT kernel
+      if (pact <= PIPE_ACT_HH && (nt_v5_mode() == 1 || (nt_v5_mode() == 2 && !conv && K > 1536))) {   // A/B runs of the specialised-wave NT kernel
         const int cus5 = num_cus(cu_budget);
         const int grid5 = grid3 < cus5 ? grid3 : cus5;
 #define SPG_LAUNCH5(C_, A_, NB_)                                                                                                           \
@@ -3323,6 +3350,8 @@ static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M,
       if (conv) SPG_LAUNCH3_NB(true, PIPE_ACT_NONE);
       else if (pact == PIPE_ACT_GELU) SPG_LAUNCH3_NB(false, PIPE_ACT_GELU);
       else if (pact == PIPE_ACT_HH) SPG_LAUNCH3_NB(false, PIPE_ACT_HH);
+      else if (pact == PIPE_ACT_GELU_D) SPG_LAUNCH3_NB(false, PIPE_ACT_GELU_D);
+      else if (pact == PIPE_ACT_MULH) SPG_LAUNCH3_NB(false, PIPE_ACT_MULH);
       else SPG_LAUNCH3_NB(false, PIPE_ACT_NONE);
 #undef SPG_LAUNCH3_NB
 #undef SPG_LAUNCH3
@@ -3384,8 +3413,10 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
       // pipelined kernel: bf16, >= 2 K steps per tile, 8-element-aligned rows, operands addressable by 32-bit offsets, and an
       // epilogue it has an instance for (ReLU, or GELU together with gelu_h, go to the plain DMA kernel below)
       const long cb = ((long)(M - 1) * ldc + N) * 2;
-      const int pact = epi.gelu_h ? PIPE_ACT_HH : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : PIPE_ACT_NONE);
-      const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE) && (epi.C2 == nullptr || pact == PIPE_ACT_GELU) &&
+      const int pact = epi.gelu_h ? (epi.act == SPG_ACT_MUL_H ? PIPE_ACT_MULH : PIPE_ACT_HH)
+                                 : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : (epi.act == SPG_ACT_GELU_SAVE_GRAD ? PIPE_ACT_GELU_D : PIPE_ACT_NONE));
+      const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE && epi.act != SPG_ACT_MUL_H) &&
+                      (epi.C2 == nullptr || pact == PIPE_ACT_GELU || pact == PIPE_ACT_GELU_D) && (pact != PIPE_ACT_GELU_D || epi.C2 != nullptr) &&
                           !(conv && pact != PIPE_ACT_NONE);
       if (waves == 8 && pipe && K > ROWB / (int)sizeof(T) && N % 8 == 0 && ldc % 8 == 0 && cb < 0xFFFFFFF0L && epi_ok) {
         static int force_nb = -1;
@@ -3441,6 +3472,8 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
           else if (defer && nb == 2) SPG_LAUNCHP(false, PIPE_ACT_HH, 2, true, 0);
           else SPG_LAUNCHP_NB(false, PIPE_ACT_HH, false);
         }
+        else if (pact == PIPE_ACT_GELU_D) SPG_LAUNCHP_NB(false, PIPE_ACT_GELU_D, false);
+        else if (pact == PIPE_ACT_MULH) SPG_LAUNCHP_NB(false, PIPE_ACT_MULH, false);
         else { if (defer) SPG_LAUNCHP_NB(false, PIPE_ACT_NONE, true); else SPG_LAUNCHP_NB(false, PIPE_ACT_NONE, false); }
 #undef SPG_LAUNCHP_NB
 #undef SPG_LAUNCHP
@@ -3518,8 +3551,10 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     // pipelined kernel: bf16, >= 2 K steps per tile, 8-element-aligned rows, operands addressable by 32-bit offsets, and an
     // epilogue it has an instance for (ReLU, or GELU together with gelu_h, go to the plain DMA kernel below)
     const long cb = ((long)(M - 1) * ldc + N) * 2;
-    const int pact = epi.gelu_h ? PIPE_ACT_HH : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : PIPE_ACT_NONE);
-    const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE) && (epi.C2 == nullptr || pact == PIPE_ACT_GELU) &&
+    const int pact = epi.gelu_h ? (epi.act == SPG_ACT_MUL_H ? PIPE_ACT_MULH : PIPE_ACT_HH)
+                                 : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : (epi.act == SPG_ACT_GELU_SAVE_GRAD ? PIPE_ACT_GELU_D : PIPE_ACT_NONE));
+    const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE && epi.act != SPG_ACT_MUL_H) &&
+                      (epi.C2 == nullptr || pact == PIPE_ACT_GELU || pact == PIPE_ACT_GELU_D) && (pact != PIPE_ACT_GELU_D || epi.C2 != nullptr) &&
                         !(conv && pact != PIPE_ACT_NONE);
     {
       const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s, cu_budget);
@@ -3548,11 +3583,18 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
       if (conv) SPG_LAUNCHP_NB(true, PIPE_ACT_NONE);
       else if (pact == PIPE_ACT_GELU) SPG_LAUNCHP_NB(false, PIPE_ACT_GELU);
       else if (pact == PIPE_ACT_HH) SPG_LAUNCHP_NB(false, PIPE_ACT_HH);
+      else if (pact == PIPE_ACT_GELU_D) SPG_LAUNCHP_NB(false, PIPE_ACT_GELU_D);
+      else if (pact == PIPE_ACT_MULH) SPG_LAUNCHP_NB(false, PIPE_ACT_MULH);
       else SPG_LAUNCHP_NB(false, PIPE_ACT_NONE);
 #undef SPG_LAUNCHP_NB
 #undef SPG_LAUNCHP
       return check_launch("gemm_nt(pipe)");
     }
+  }
+  if (epi.act == SPG_ACT_GELU_SAVE_GRAD || epi.act == SPG_ACT_MUL_H) {
+    set_error("gemm_nt: act %d (saved GELU derivative) exists only in the bf16 pipelined kernels: needs bf16, K > 64, 8-element-aligned "
+              "N / K / ldc / ldx (M=%d N=%d K=%d)", epi.act, M, N, K);
+    return SPG_ERR_UNSUPPORTED;
   }
   constexpr int LDS8 = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
   static bool attr8 = false;

@@ -265,7 +265,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------ linear helpers
     def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
-                residual: Optional[Tensor] = None, bias: bool = True) -> Optional[Tensor]:
+                residual: Optional[Tensor] = None, bias: bool = True, h_is_grad: bool = False) -> Optional[Tensor]:
         """dW += dy^T x, db += colsum(dy), returns dx = dy W (optionally * gelu'(h), + residual)."""
         gw, gb = self.grad(name + ".weight").view(dy.shape[-1], -1), (self.grad(name + ".bias") if bias else None)
         if self._wg_jobs is not None:
@@ -276,7 +276,8 @@ class Engine:
             self._wgrad(lambda: ops.gemm_tn(dy, x, gw, dbias=gb), dy, x)
         if not need_dx:
             return None
-        return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual)
+        act = ops.ACT_MUL_H if (gelu_h is not None and h_is_grad) else ops.ACT_NONE    # gelu_h: saved derivative | pre-activation
+        return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual, act=act)
 
     # ================================================================================================ trunk
     def pos_basis(self, h: int, w: int, B: int) -> Tensor:
@@ -355,13 +356,19 @@ class Engine:
         x1 = ops.gemm_nt(att, W[p + "attn.proj.weight"], bias=P[p + "attn.proj.bias"], residual=shortcut)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, P[p + "norm2.weight"], P[p + "norm2.bias"], eps)
         hpre = torch.empty((x1.shape[0], 4 * do), dtype=x.dtype, device=x.device) if save else None
-        g = ops.gemm_nt(ln2, W[p + "mlp.layers.0.weight"], bias=P[p + "mlp.layers.0.bias"], act=ops.ACT_GELU, preact_out=hpre)
+        # bf16: the GEMM saves gelu'(pre-activation) instead of the pre-activation (ACT_GELU_SAVE_GRAD; its exponential is the one the erf
+        # already needs) and the backward GEMM multiplies by it (ACT_MUL_H) -- the backward epilogue was bound by re-deriving it (erf + exp
+        # per element).  The fp32 parity path keeps the pre-activation.
+        # (the modes exist in the bf16 pipelined GEMM kernels: K = do > 64, 8-element-aligned -- every Hiera size, not the 16-wide test trunk)
+        save_grad = save and self.dtype == torch.bfloat16 and do > 64 and do % 8 == 0
+        act = ops.ACT_GELU_SAVE_GRAD if save_grad else ops.ACT_GELU
+        g = ops.gemm_nt(ln2, W[p + "mlp.layers.0.weight"], bias=P[p + "mlp.layers.0.bias"], act=act, preact_out=hpre)
         x2 = ops.gemm_nt(g, W[p + "mlp.layers.1.weight"], bias=P[p + "mlp.layers.1.bias"], residual=x1)
         x2 = x2.view(B, Hq, Wq, do)
         c = None
         if save:
             c = dict(x=x, ln1=ln1, mean1=mean1, rstd1=rstd1, sc_idx=sc_idx, qkv=qkv, qp=qp, q_idx=q_idx, att=att, lse=lse,
-                     x1=x1, ln2=ln2, mean2=mean2, rstd2=rstd2, h=hpre, g=g, H=H, W=Wd)
+                     x1=x1, ln2=ln2, mean2=mean2, rstd2=rstd2, h=hpre, h_is_grad=save_grad, g=g, H=H, W=Wd)
         return x2, c
 
     def block_bwd(self, b, c, dx2: Tensor, B: int) -> Tensor:
@@ -373,7 +380,7 @@ class Engine:
         dx2 = dx2.reshape(-1, do)
         self._wg_jobs = [] if self.group_wgrads else None
         # MLP
-        dh = self.lin_bwd(p + "mlp.layers.1", dx2, c["g"], gelu_h=c["h"])
+        dh = self.lin_bwd(p + "mlp.layers.1", dx2, c["g"], gelu_h=c["h"], h_is_grad=c["h_is_grad"])
         dln2 = self.lin_bwd(p + "mlp.layers.0", dh, c["ln2"])
         dx1 = self.ln_bwd(dln2, c["x1"], P[p + "norm2.weight"], c["mean2"], c["rstd2"], G(p + "norm2.weight"),
                           G(p + "norm2.bias"), dres=dx2)

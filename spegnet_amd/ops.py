@@ -7,7 +7,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, SPG_BF16, SPG_F32  # noqa: F401
+from ._lib import ACT_GELU, ACT_GELU_SAVE_GRAD, ACT_MUL_H, ACT_NONE, ACT_RELU, SPG_BF16, SPG_F32  # noqa: F401
 
 Tensor = torch.Tensor
 

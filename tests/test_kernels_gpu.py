@@ -724,6 +724,30 @@ def test_pack_cols2_and_add_cols_batch(ops):
     assert torch.equal(d0, r0) and torch.equal(d1, r1) and torch.equal(d2, r2)
 
 
+@pytest.mark.parametrize("M,N,K", [(4608, 2304, 576), (1000, 576, 2304), (300, 200, 144)])
+def test_gemm_nt_saved_gelu_derivative_modes(ops, M, N, K):
+    """bf16 MLP epilogues: the forward GEMM stores gelu'(pre-activation) next to gelu(.) (ACT_GELU_SAVE_GRAD), the backward GEMM multiplies
+    by it (ACT_MUL_H).  Shapes cover both bf16 kernel families (two workgroups per CU / persistent)."""
+    dt = torch.bfloat16
+    x, w, b = rnd(M, K, seed=1).to(dt), (rnd(N, K, seed=2) * K ** -0.5).to(dt), rnd(N, seed=3)
+    pre = x.float() @ w.float().t() + b
+    pr = pre.clone().requires_grad_(True)
+    gl = F.gelu(pr)
+    gl.sum().backward()
+    d_out = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+    out = ops.gemm_nt(x, w, bias=b, act=ops.ACT_GELU_SAVE_GRAD, preact_out=d_out)
+    check(out.float(), gl.detach(), 2.5e-2, "gelu")
+    check(d_out.float(), pr.grad, 2.5e-2, "gelu'")
+    ref_plain = ops.gemm_nt(x, w, bias=b, act=ops.ACT_GELU)
+    assert torch.equal(out, ref_plain)                     # the value path is bit-identical to the plain GELU epilogue
+    dy, w2, res = rnd(M, K, seed=4).to(dt), (rnd(N, K, seed=5) * K ** -0.5).to(dt), rnd(M, N, seed=6).to(dt)
+    got = ops.gemm_nt(dy, w2, gelu_h=d_out, residual=res, act=ops.ACT_MUL_H)
+    want = (dy.float() @ w2.float().t()) * d_out.float() + res.float()
+    check(got.float(), want, 2.5e-2, "acc * saved derivative + residual")
+    with pytest.raises(RuntimeError):                      # fp32 (parity) kernels keep the pre-activation: the modes are refused there
+        ops.gemm_nt(x.float(), w.float(), bias=b, act=ops.ACT_GELU_SAVE_GRAD, preact_out=d_out.float())
+
+
 # ------------------------------------------------------------------------------------------- CU budget
 @pytest.mark.parametrize("budget", [240, 96, 8])
 def test_gemms_under_a_cu_budget(ops, budget):
