@@ -102,7 +102,7 @@ template <int NT> __device__ __forceinline__ float block_sum(float v, float* sme
 // ~40-instruction libm erff -- the exact-erf GELU of nn.GELU() to within the parity budget, at a fraction of the epilogue cost.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);   // v_rcp_f32 (1 ulp): the IEEE sequence of __frcp_rn is ~10 VALU per element
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.f - poly * __expf(-ax * ax);
   return copysignf(r, x);
@@ -119,14 +119,14 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 __device__ __forceinline__ void gelu_both_f(float x, float& g, float& d) {
   const float u = x * 0.70710678118654752440f;
   const float ax = fabsf(u);
-  const float t = __frcp_rn(1.f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);   // v_rcp_f32 (1 ulp): the IEEE sequence of __frcp_rn is ~10 VALU per element
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float e = __expf(-ax * ax);
   const float erf = copysignf(1.f - poly * e, u);
   g = 0.5f * x * (1.f + erf);
   d = 0.5f * (1.f + erf) + x * (0.39894228040143267794f * e);
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }   // (v_rcp_f32, 1 ulp)
 
 // ---- deterministic cross-workgroup reductions ----------------------------------------------------------
 // Every reduction that spans workgroups writes one partial vector per workgroup and the workgroup that arrives LAST at a counter
