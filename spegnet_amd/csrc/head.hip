@@ -154,13 +154,14 @@ __global__ __launch_bounds__(256) void ped_gather_bwd_kernel(const T* __restrict
   constexpr int VEC = ST<T>::VEC;
   constexpr int N = 2 * S;
   const int nch = C / VEC;
-  const long total = (long)B * h * w * nch;
-  for (long it = blockIdx.x * 256L + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
-    const int ch = (int)(it % nch);
-    long p = it / nch;
-    const int j = (int)(p % w); p /= w;
-    const int i = (int)(p % h);
-    const int b = (int)(p / h);
+  // (32-bit index arithmetic: the 64-bit % and / of a long item index cost more VALU than the gather itself; the host checks the range)
+  const unsigned total = (unsigned)B * h * w * nch;
+  for (unsigned it = blockIdx.x * 256u + threadIdx.x; it < total; it += gridDim.x * 256u) {
+    const int ch = (int)(it % (unsigned)nch);
+    unsigned p = it / (unsigned)nch;
+    const int j = (int)(p % (unsigned)w); p /= (unsigned)w;
+    const int i = (int)(p % (unsigned)h);
+    const int b = (int)(p / (unsigned)h);
     const int Y0 = S * i - S / 2, X0 = S * j - S / 2;
     float wy[N], wx[N];
 #pragma unroll
@@ -470,6 +471,7 @@ extern "C" int spg_ped_gather_bwd(int dtype, const void* dy, void* dx, int B, in
   SPG_REQUIRE(C % v == 0 && ldy % v == 0 && c0 % v == 0, "ped_gather_bwd: alignment");
   const int sc = H / h;
   SPG_REQUIRE((sc == 2 || sc == 4) && h * sc == H && w * sc == W, "ped_gather_bwd: scale must be exactly 2 or 4");
+  SPG_REQUIRE((long)B * H * W * ldy < 0x7fffffffL, "ped_gather_bwd: tensor too large for 32-bit index arithmetic");
   const int grid = head_grid((long)B * h * w * (C / v));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SPG_BF16) {
