@@ -321,7 +321,7 @@ def main():
             "config": {"workload": f"SPEGNet (Hiera-L trunk + CFI + EFE + PED) train step: fwd + CODLoss + bwd + clip + AdamW, "
                                    f"batch {args.batch}/GPU @{args.size}x{args.size}, random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
-                       "launch": "eager, bucketed all-reduce overlapped with backward" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph segments (fwd+loss+bwd in 4 pieces) with RCCL all-reduce of finished gradient ranges on a side stream | hipGraph optimizer"),
+                       "launch": "eager, bucketed all-reduce overlapped with backward" if args.no_graph else ("hipGraph" if world == 1 else f"hipGraph segments (fwd+loss+bwd in {getattr(step, 'n_segments', 8)} pieces) with RCCL all-reduce (bf16 payload) of finished gradient ranges on a side stream | hipGraph optimizer"),
                        "final_loss": round(loss_val, 5)},
             "roofline": roof, "cpu_baseline": cpu,
         }
