@@ -145,15 +145,16 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(float* __restrict__ p, 
             const long i = jb.off + (long)r * jb.lds + c;
             const int grp = group_of_chunk[i >> 8];
             const float lr_ = lr[grp], wd_ = wd[grp];
-            f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
-            f32x4 mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+            // (streamed once per step, 3.4 GB in and out: non-temporal so they do not displace the packed weights in L2 / MALL)
+            f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + i));
+            const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
+            f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + i)), vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + i));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float pe = pv[e], me = mv[e], ve = vv[e]; adam1(pe, gv[e], me, ve, lr_, wd_, a); pv[e] = pe; mv[e] = me; vv[e] = ve; }
-            *reinterpret_cast<f32x4*>(p + i) = pv;
-            *reinterpret_cast<f32x4*>(m + i) = mv;
-            *reinterpret_cast<f32x4*>(v + i) = vv;
-            if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p + i));
+            __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + i));
+            __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + i));
+            if (zero_grad) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(g + i));
             if (dst) {
               T* d = dst + (long)r * jb.ldd + c;
               if constexpr (sizeof(T) == 2) *reinterpret_cast<u32x2*>(d) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
