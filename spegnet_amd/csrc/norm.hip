@@ -126,7 +126,13 @@ struct BnFin {
   int gc;       // channels per parameter group (== C for a single BatchNorm)
 };
 constexpr int RED_SLAB_CHUNKS = 16;
-constexpr int RED_MAX_GX = 512;
+#ifndef SPG_RED_MAX_GX     // (tools/ builds may override: the last workgroup's fixed-order finish grows with the number of row blocks)
+#define SPG_RED_MAX_GX 512
+#endif
+#ifndef SPG_RED_ROWS_PER_THREAD
+#define SPG_RED_ROWS_PER_THREAD 16
+#endif
+constexpr int RED_MAX_GX = SPG_RED_MAX_GX;
 constexpr int RED_MAX_BLOCKS = 2048;
 
 template <typename T, int MODE>
@@ -255,7 +261,7 @@ static inline RedPlan red_plan(long rows, int nch, int nimg) {
   p.nslabs = cdiv(nch, p.nchs);
   const int rpar = 256 / p.nchs;
   const int ni = nimg > 0 ? nimg : 1;
-  long want = rows / ((long)rpar * 16);              // >= 16 rows per thread: enough blocks to stream at HBM rate, few partials
+  long want = rows / ((long)rpar * SPG_RED_ROWS_PER_THREAD);   // >= 16 rows per thread: enough blocks to stream at HBM rate, few partials
   long cap = RED_MAX_BLOCKS / ((long)ni * p.nslabs);
   if (cap > RED_MAX_GX) cap = RED_MAX_GX;
   if (cap < 1) cap = 1;
