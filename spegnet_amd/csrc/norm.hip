@@ -10,7 +10,7 @@ namespace spg {
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_MAXCH = 5;
 
-template <typename T>
+template <typename T, int NI = LN_MAXCH>   // NI = 16-byte chunk slots per lane (ceil(C / (64 VEC))): sized per launch, not for the widest row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int M,
@@ -20,10 +20,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nch = C / VEC;
-  float v[LN_MAXCH][VEC];
+  float v[NI][VEC];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       unpack16<T>(ld16(x + (long)row * C + ch * VEC), v[i]);
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   const float mu = wave_sum(s) / C;
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
 #pragma unroll
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   const float rs = rsqrtf(wave_sum(ss) / C + eps);
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       float o[VEC];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) (+dres).  One wave per row, row held in registers (full
 // thread-level parallelism hides HBM latency); the parameter gradients dgamma = sum_rows dy*xhat, dbeta = sum_rows dy are
 // column reductions done by colreduce_kernel<RED_LN> (a second, bandwidth-bound pass over dy and x).
-template <typename T>
+template <typename T, int NI = LN_MAXCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   if (row >= M) return;
   const int nch = C / VEC;
   const float mu = mean[row], rs = rstd[row];
-  float xh[LN_MAXCH][VEC], gd[LN_MAXCH][VEC];
+  float xh[NI][VEC], gd[NI][VEC];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       float xv[VEC], dv[VEC];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   s1 = wave_sum(s1) / C;
   s2 = wave_sum(s2) / C;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       float o[VEC];
@@ -434,10 +434,11 @@ extern "C" int spg_layernorm_fwd(int dtype, const void* x, const float* gamma, c
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(M > 0 && C > 0 && C % vec == 0 && C / vec <= 64 * LN_MAXCH, "layernorm_fwd: C=%d must be a multiple of %d and <= %d", C, vec, 64 * LN_MAXCH * vec);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == SPG_BF16)
-    hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(cdiv(M, 4)), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
-  else
-    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(cdiv(M, 4)), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, C, eps);
+  const int ni = cdiv(C / vec, 64);
+#define SPG_LNF(T_, NI_) hipLaunchKernelGGL((layernorm_fwd_kernel<T_, NI_>), dim3(cdiv(M, 4)), dim3(256), 0, s, (const T_*)x, gamma, beta, (T_*)y, mean, rstd, M, C, eps)
+  if (dtype == SPG_BF16) { if (ni <= 1) SPG_LNF(bf16_t, 1); else if (ni == 2) SPG_LNF(bf16_t, 2); else if (ni == 3) SPG_LNF(bf16_t, 3); else SPG_LNF(bf16_t, LN_MAXCH); }
+  else { if (ni <= 1) SPG_LNF(float, 1); else if (ni == 2) SPG_LNF(float, 2); else if (ni == 3) SPG_LNF(float, 3); else SPG_LNF(float, LN_MAXCH); }
+#undef SPG_LNF
   return check_launch("layernorm_fwd");
 }
 
@@ -447,10 +448,11 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(M > 0 && C > 0 && C % vec == 0 && C / vec <= 64 * LN_MAXCH, "layernorm_bwd: bad C=%d", C);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == SPG_BF16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(cdiv(M, 4)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
-  else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(cdiv(M, 4)), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, M, C);
+  const int ni = cdiv(C / vec, 64);
+#define SPG_LNB(T_, NI_) hipLaunchKernelGGL((layernorm_bwd_kernel<T_, NI_>), dim3(cdiv(M, 4)), dim3(256), 0, s, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (const T_*)dres, (T_*)dx, M, C)
+  if (dtype == SPG_BF16) { if (ni <= 1) SPG_LNB(bf16_t, 1); else if (ni == 2) SPG_LNB(bf16_t, 2); else if (ni == 3) SPG_LNB(bf16_t, 3); else SPG_LNB(bf16_t, LN_MAXCH); }
+  else { if (ni <= 1) SPG_LNB(float, 1); else if (ni == 2) SPG_LNB(float, 2); else if (ni == 3) SPG_LNB(float, 3); else SPG_LNB(float, LN_MAXCH); }
+#undef SPG_LNB
   int rc = check_launch("layernorm_bwd");
   if (rc || (!dgamma && !dbeta)) return rc;
   SPG_REQUIRE(dgamma && dbeta, "layernorm_bwd: dgamma and dbeta must both be given");
