@@ -180,7 +180,9 @@ template <> struct MM<float> {
 // ROW image [token][d]: bf16 through the hardware transpose read ds_read_b64_tr_b16 (a 16-lane group fetches 4 token rows x
 // 16 d columns and each lane receives one column), f32 through plain strided reads.  No transposed copy of the tile exists.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-template <typename T, int HD>
+// NB < 4: only the tile's first NB 16-token blocks count (pv[nb >= NB] is not read; bf16 rounds NB up to a 32-token step, the odd block's
+// operand half zero -- the image rows behind it must be finite, which staged zero rows are).
+template <typename T, int HD, int NB = 4>
 __device__ __forceinline__ void mma_over_tokens(const char* rimg, const float (&pv)[4][4], int lane,
                                                 f32x4 (&acc)[AC<T, HD>::DB]) {
   constexpr int DB = AC<T, HD>::DB, RS = AC<T, HD>::RS;
@@ -188,9 +190,14 @@ __device__ __forceinline__ void mma_over_tokens(const char* rimg, const float (&
   if constexpr (sizeof(T) == 2) {
     const int qq = r15 >> 2, p = r15 & 3;   // lane 4qq+p of its 16-lane group addresses token row qq, d columns 4p..4p+3
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 b = {pack2bf(pv[2 * s][0], pv[2 * s][1]), pack2bf(pv[2 * s][2], pv[2 * s][3]),
-                 pack2bf(pv[2 * s + 1][0], pv[2 * s + 1][1]), pack2bf(pv[2 * s + 1][2], pv[2 * s + 1][3])};
+    for (int s = 0; s < (NB + 1) / 2; ++s) {
+      u32x4 b;
+      if constexpr (NB == 4)
+        b = u32x4{pack2bf(pv[2 * s][0], pv[2 * s][1]), pack2bf(pv[2 * s][2], pv[2 * s][3]),
+                  pack2bf(pv[2 * s + 1][0], pv[2 * s + 1][1]), pack2bf(pv[2 * s + 1][2], pv[2 * s + 1][3])};
+      else
+        b = u32x4{pack2bf(pv[2 * s][0], pv[2 * s][1]), pack2bf(pv[2 * s][2], pv[2 * s][3]),
+                  2 * s + 1 < NB ? pack2bf(pv[2 * s + 1][0], pv[2 * s + 1][1]) : 0u, 2 * s + 1 < NB ? pack2bf(pv[2 * s + 1][2], pv[2 * s + 1][3]) : 0u};
       const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b);
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
@@ -204,7 +211,7 @@ __device__ __forceinline__ void mma_over_tokens(const char* rimg, const float (&
     }
   } else {
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -216,12 +223,12 @@ __device__ __forceinline__ void mma_over_tokens(const char* rimg, const float (&
 }
 
 // score-type product for the whole tile: acc[nb] = sum_d Rimg[token 16nb + lane&15][d] * frag[d][col]
-template <typename T, int HD>
+template <typename T, int HD, int NB = 4>
 __device__ __forceinline__ void mma_scores(const char* rimg, const typename AC<T, HD>::Frag (&bf)[AC<T, HD>::KS], int lane,
                                            f32x4 (&acc)[4]) {
   const int r15 = lane & 15, q = lane >> 4;
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
+  for (int nb = 0; nb < NB; ++nb) {
     acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < AC<T, HD>::KS; ++s)
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
 // backward, key side: dK, dV (keys stationary, queries streamed)
 // =====================================================================================================
 template <typename T, int HD, bool SUB = false>   // SUB: packed 4 x 4 windows (block mask same_sub)
-__global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnP p) {
+__global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(SUB ? 3 : 1, 3))) void attn_bwd_dkv_kernel(AttnP p) {   // (SUB: held to 168 VGPRs, three waves per SIMD)
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
@@ -623,6 +630,59 @@ __device__ __forceinline__ unsigned long long attn_now() {
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
+// One 64-key tile of a resident window for a wave's 16 query rows; NB = the tile's 16-key blocks that hold keys.  A window's last tile
+// often holds the virtual pad key alone (64 / 128 valid keys + 1): NB = 1 does a quarter of the score MFMAs and exponentials and half of
+// the P V steps for it.
+template <typename T, int HD, int NB>
+__device__ __forceinline__ void res_fwd_tile(const char* kimg, const char* vimg, const float* kb, const typename AC<T, HD>::Frag (&qf)[AC<T, HD>::KS],
+                                             int lane, float scale, float& m, float& l, f32x4 (&o)[AC<T, HD>::DB]) {
+  const int q = lane >> 4;
+  f32x4 sacc[4];
+  mma_scores<T, HD, NB>(kimg, qf, lane, sacc);
+  float pv[4][4];
+  float mx = NEG_BIG;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + nb * 16 + q * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pv[nb][r] = sacc[nb][r] * scale + b4[r]; mx = fmaxf(mx, pv[nb][r]); }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mn = fmaxf(m, mx);
+  const float alpha = __expf(m - mn);
+  m = mn;
+  float ps = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pv[nb][r] = __expf(pv[nb][r] - mn); ps += pv[nb][r]; }
+  l = l * alpha + ps;
+#pragma unroll
+  for (int db = 0; db < AC<T, HD>::DB; ++db) o[db] *= alpha;
+  mma_over_tokens<T, HD, NB>(vimg, pv, lane, o);
+}
+template <typename T, int HD, int NB>
+__device__ __forceinline__ void res_dq_tile(const char* kimg, const char* vimg, const float* kb, const typename AC<T, HD>::Frag (&qf)[AC<T, HD>::KS],
+                                            const typename AC<T, HD>::Frag (&dof)[AC<T, HD>::KS], int lane, float scale, float lse, float delta,
+                                            f32x4 (&dq)[AC<T, HD>::DB]) {
+  const int q = lane >> 4;
+  f32x4 sacc[4], pacc[4];
+  mma_scores<T, HD, NB>(kimg, qf, lane, sacc);
+  mma_scores<T, HD, NB>(vimg, dof, lane, pacc);
+  float ds[4][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + nb * 16 + q * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pr = __expf(sacc[nb][r] * scale + b4[r] - lse);
+      ds[nb][r] = pr * (pacc[nb][r] - delta);
+    }
+  }
+  mma_over_tokens<T, HD, NB>(kimg, ds, lane, dq);
+}
+
 template <typename T, int HD, bool DQ, int DBG = 0>
 __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPlan pl) {   // forward (DQ=false) or dQ (DQ=true)
   using A = AC<T, HD>;
@@ -639,11 +699,31 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
   const T* qp = reinterpret_cast<const T*>(p.qp);
   const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);
   const int ntiles = (nkeys + 63) >> 6, nrows = ntiles * 64;
+  const int nfull = (nkeys - (ntiles - 1) * 64) <= 16 ? ntiles - 1 : ntiles;   // a last tile of <= 16 keys takes the one-block path
   // this unit's run of query blocks: part, part + nparts, ... in steps of 8 blocks (one per wave)
   const int rb0 = part * (RES_THREADS / 64);
   if (rb0 * 16 >= w.nq) return;
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
   if constexpr (DBG == 1) t0 = attn_now();
+  // the wave's first query block: its global loads are issued ahead of the K / V staging so both round trips overlap
+  const int rbf = rb0 + wave;
+  typename A::Frag qf0[A::KS], dof0[DQ ? A::KS : 1], of0[DQ ? A::KS : 1];
+  float lse0 = 0.f;
+  {
+    const int qi = rbf * 16 + r15;
+    const bool qvalid = qi < w.nq;
+    const long qrow = q_row(p, w, qvalid ? qi : 0);
+    const T* qptr = !qvalid ? nullptr : (qp ? qp + qrow * p.C + head * HD : qkv + qrow * 3 * p.C + head * HD);
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) qf0[s] = load_row_frag_global<T, HD>(qptr, s, q);
+    if constexpr (DQ) {
+      const T* doptr = qvalid ? reinterpret_cast<const T*>(p.dout) + qrow * p.C + head * HD : nullptr;
+      const T* optr = qvalid ? reinterpret_cast<const T*>(p.out) + qrow * p.C + head * HD : nullptr;
+#pragma unroll
+      for (int s = 0; s < A::KS; ++s) { dof0[s] = load_row_frag_global<T, HD>(doptr, s, q); of0[s] = load_row_frag_global<T, HD>(optr, s, q); }
+      if (qvalid) lse0 = p.lse[qrow * p.heads + head];
+    }
+  }
   // per-key score bias (0 / log(n_pad) for the virtual pad key / -inf for the unused slots of the last tile), then K and V in one pass
   for (int c = tid; c < nrows; c += RES_THREADS)
     kb[c] = c < w.nvalid ? 0.f : ((c == w.nvalid && w.npad > 0) ? __logf((float)w.npad) : NEG_BIG);
@@ -668,40 +748,19 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
     const bool qvalid = qi < w.nq;
     const long qrow = q_row(p, w, qvalid ? qi : 0);
     const T* qptr = qp ? qp + qrow * p.C + head * HD : qkv + qrow * 3 * p.C + head * HD;
+    const bool first = rb == rbf;
     typename A::Frag qf[A::KS];
 #pragma unroll
-    for (int s = 0; s < A::KS; ++s) qf[s] = load_row_frag_global<T, HD>(qptr, s, q);
+    for (int s = 0; s < A::KS; ++s) qf[s] = first ? qf0[s] : load_row_frag_global<T, HD>(qptr, s, q);
     if constexpr (!DQ) {
       f32x4 o[A::DB];
 #pragma unroll
       for (int db = 0; db < A::DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
       float m = NEG_BIG, l = 0.f;
-      for (int t = 0; t < ntiles; ++t) {
-        f32x4 sacc[4];
-        mma_scores<T, HD>(kimg + t * A::ROW_BYTES, qf, lane, sacc);
-        float pv[4][4];
-        float mx = NEG_BIG;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + t * 64 + nb * 16 + q * 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { pv[nb][r] = sacc[nb][r] * p.scale + b4[r]; mx = fmaxf(mx, pv[nb][r]); }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = __expf(m - mn);
-        m = mn;
-        float ps = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { pv[nb][r] = __expf(pv[nb][r] - mn); ps += pv[nb][r]; }
-        l = l * alpha + ps;
-#pragma unroll
-        for (int db = 0; db < A::DB; ++db) o[db] *= alpha;
-        mma_over_tokens<T, HD>(vimg + t * A::ROW_BYTES, pv, lane, o);
-      }
+      for (int t = 0; t < nfull; ++t)
+        res_fwd_tile<T, HD, 4>(kimg + t * A::ROW_BYTES, vimg + t * A::ROW_BYTES, kb + t * 64, qf, lane, p.scale, m, l, o);
+      if (nfull < ntiles)
+        res_fwd_tile<T, HD, 1>(kimg + nfull * A::ROW_BYTES, vimg + nfull * A::ROW_BYTES, kb + nfull * 64, qf, lane, p.scale, m, l, o);
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
       if (qvalid) {
@@ -714,33 +773,21 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
       const T* optr = reinterpret_cast<const T*>(p.out) + qrow * p.C + head * HD;
       typename A::Frag dof[A::KS];
 #pragma unroll
-      for (int s = 0; s < A::KS; ++s) dof[s] = load_row_frag_global<T, HD>(doptr, s, q);
+      for (int s = 0; s < A::KS; ++s) dof[s] = first ? dof0[s] : load_row_frag_global<T, HD>(doptr, s, q);
       float delta = 0.f;   // from 16-byte fragment loads (dO's is already in registers), not element loads
 #pragma unroll
-      for (int s = 0; s < A::KS; ++s) delta = frag_dot(dof[s], load_row_frag_global<T, HD>(optr, s, q), delta);
+      for (int s = 0; s < A::KS; ++s) delta = frag_dot(dof[s], first ? of0[s] : load_row_frag_global<T, HD>(optr, s, q), delta);
       delta += __shfl_xor(delta, 16, 64);
       delta += __shfl_xor(delta, 32, 64);
-      const float lse = qvalid ? p.lse[qrow * p.heads + head] : 0.f;
+      const float lse = first ? lse0 : (qvalid ? p.lse[qrow * p.heads + head] : 0.f);
       if (qvalid && q == 0) p.delta[qrow * p.heads + head] = delta;
       f32x4 dq[A::DB];
 #pragma unroll
       for (int db = 0; db < A::DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int t = 0; t < ntiles; ++t) {
-        f32x4 sacc[4], pacc[4];
-        mma_scores<T, HD>(kimg + t * A::ROW_BYTES, qf, lane, sacc);
-        mma_scores<T, HD>(vimg + t * A::ROW_BYTES, dof, lane, pacc);
-        float ds[4][4];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + t * 64 + nb * 16 + q * 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr = __expf(sacc[nb][r] * p.scale + b4[r] - lse);
-            ds[nb][r] = pr * (pacc[nb][r] - delta);
-          }
-        }
-        mma_over_tokens<T, HD>(kimg + t * A::ROW_BYTES, ds, lane, dq);
-      }
+      for (int t = 0; t < nfull; ++t)
+        res_dq_tile<T, HD, 4>(kimg + t * A::ROW_BYTES, vimg + t * A::ROW_BYTES, kb + t * 64, qf, dof, lane, p.scale, lse, delta, dq);
+      if (nfull < ntiles)
+        res_dq_tile<T, HD, 1>(kimg + nfull * A::ROW_BYTES, vimg + nfull * A::ROW_BYTES, kb + nfull * 64, qf, dof, lane, p.scale, lse, delta, dq);
       if (qvalid) {
         T* dst = p.qp ? reinterpret_cast<T*>(p.dqp) + qrow * p.C + head * HD
                       : reinterpret_cast<T*>(p.dqkv) + qrow * 3 * p.C + head * HD;
@@ -804,6 +851,9 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResP
   }
   __syncthreads();
 
+  // (Measured and dropped, round 2: dealing the pad key's query tiles over the waves instead of giving one wave a second block shortens
+  // the longest wave but doubles the float atomics that land on the same 144 bias-gradient addresses from every window of a head at the
+  // kernel's end -- 23.3 -> 26.9 us; with the atomics compiled out 21.1.  Those same-address atomics are ~2 us of this kernel as it is.)
   for (int kbk = kb0 + wave; kbk * 16 < nkeys; kbk += (RES_THREADS / 64) * nparts) {
     const int c = kbk * 16 + r15;
     const T* kp = nullptr;
