@@ -35,7 +35,16 @@ struct AttnP {
 
 struct Win {
   int b, y0, x0, hv, wv, nvalid, npad, y0q, x0q, wvq, nq;
+  int krow0, qrow0;         // global row of the window's first key / query token
+  float inv_wv, inv_wvq;    // 1 / window width (keys, queries): token -> (line, column) without an integer division
 };
+// c / d for 0 <= c < 2^16 and a small divisor given as inv = 1 / d (hardware reciprocal): (c + 0.5) / d sits at least 0.5 / d away from
+// an integer, far more than the rounding of the two float operations.  An integer division by a run-time divisor is ~40 VALU
+// instructions, and the resident kernels' staging did one per 16-byte chunk: address arithmetic, not the loads, was most of that phase
+// (in-kernel stamps, round 2: 7700 of 9800 cycles before the loads were even issued).
+// (Also measured: the eight dependent integer divisions of res_unit / get_win at the head of every workgroup -- ~3000 stamped cycles --
+// replaced the same way, and a shift-and-mask thread -> (row, chunk) staging map: no change in launch time, 16.3 us either way.)
+__device__ __forceinline__ int fast_div(int c, float inv) { return (int)(((float)c + 0.5f) * inv); }
 
 __device__ __forceinline__ Win get_win(const AttnP& p, int widx) {
   Win w;
@@ -54,17 +63,25 @@ __device__ __forceinline__ Win get_win(const AttnP& p, int widx) {
   } else {
     w.y0q = w.y0; w.x0q = w.x0; w.wvq = w.wv; w.nq = w.nvalid;
   }
+  w.krow0 = (w.b * p.H + w.y0) * p.W + w.x0;
+  w.qrow0 = (w.b * p.Hq + w.y0q) * p.Wq + w.x0q;
+  w.inv_wv = __builtin_amdgcn_rcpf((float)w.wv);
+  w.inv_wvq = __builtin_amdgcn_rcpf((float)max(w.wvq, 1));
   return w;
 }
 // global row index (into [B,H,W]) of key token c (< nvalid) / (into [B,Hq,Wq]) of query token i (< nq)
+// (the launcher checks B * H * W < 2^24 rows and < 2^32 qkv elements: 24-bit multiplies, 32-bit element offsets)
 __device__ __forceinline__ long key_row(const AttnP& p, const Win& w, int c) {
-  const int ly = c / w.wv, lx = c - ly * w.wv;
-  return ((long)w.b * p.H + w.y0 + ly) * p.W + w.x0 + lx;
+  const int ly = fast_div(c, w.inv_wv), lx = c - __mul24(ly, w.wv);
+  return w.krow0 + __mul24(ly, p.W) + lx;
 }
 __device__ __forceinline__ long q_row(const AttnP& p, const Win& w, int i) {
-  const int ly = i / w.wvq, lx = i - ly * w.wvq;
-  return ((long)w.b * p.Hq + w.y0q + ly) * p.Wq + w.x0q + lx;
+  const int ly = fast_div(i, w.inv_wvq), lx = i - __mul24(ly, w.wvq);
+  return w.qrow0 + __mul24(ly, p.Wq) + lx;
 }
+// element offset of a token's row in qkv [rows, 3C] / in a [rows, C] tensor
+__device__ __forceinline__ size_t row3c(const AttnP& p, long row) { return (size_t)__umul24((unsigned)row, (unsigned)(3 * p.C)); }
+__device__ __forceinline__ size_t row1c(const AttnP& p, long row) { return (size_t)__umul24((unsigned)row, (unsigned)p.C); }
 
 // Packed small windows (sub > 0: 4 x 4 windows of stage 2, four side by side in one 4 x 16 'window' = one 64-token tile, so that a
 // workgroup's four waves and the 64-slot tile are all used instead of a quarter of each): a key / query pair interacts only if both lie in
@@ -581,11 +598,14 @@ __device__ __forceinline__ void stage_rows(const T* const* ptrs, int nrows, int 
 // row pointers the callables return (null = zero row), the pad chunks of a row (d >= HD) as zeros.  No pointer table in LDS, no
 // separate zero fill, no barrier before the loads (these kernels are bound by exactly that dependent chain: table -> barrier -> loads
 // -> LDS stores -> barrier).  srcA / srcB: token -> const T* (row start) or nullptr; rimgB == nullptr: one image.
+#ifndef SPG_STAGE_U
+#define SPG_STAGE_U 7
+#endif
 template <typename T, int HD, typename FA, typename FB>
 __device__ __forceinline__ void stage_rows2(int nrows, FA srcA, char* rimgA, FB srcB, char* rimgB) {
   constexpr int VEC = AC<T, HD>::VEC, NCH = AC<T, HD>::NCH, RS = AC<T, HD>::RS;
   constexpr int RCH = RS / 16;        // 16-byte chunks per image row incl. padding
-  constexpr int U = 4;
+  constexpr int U = SPG_STAGE_U;      // chunks per thread and pass: 7 x 512 threads cover a 256-row window (13 chunks a row) in ONE global round trip
   const int total = nrows * RCH;
   for (int base = threadIdx.x; base < total; base += RES_THREADS * U) {
     u32x4 v[U], v2[U];
@@ -619,7 +639,7 @@ template <typename T, int HD> struct ResLds {
 
 #ifdef SPG_DEV_KERNELS
 // in-kernel stamps of the resident forward kernel (tools/attn_stamps.py, SPG_ATTN_STAMPS=1): per workgroup and wave, cycles in
-// [setup + bias table | staging (issue .. landed) + barrier | its query blocks | end]; plus the workgroup's window size
+// [start (absolute) | setup + staging + barrier | its query blocks | end (absolute)]; plus the workgroup's window size
 __device__ unsigned long long attn_stamps[2048 * 8 * 4];
 __device__ int attn_stamp_nq[2048];
 #endif
@@ -713,12 +733,12 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
     const int qi = rbf * 16 + r15;
     const bool qvalid = qi < w.nq;
     const long qrow = q_row(p, w, qvalid ? qi : 0);
-    const T* qptr = !qvalid ? nullptr : (qp ? qp + qrow * p.C + head * HD : qkv + qrow * 3 * p.C + head * HD);
+    const T* qptr = !qvalid ? nullptr : (qp ? qp + row1c(p, qrow) + head * HD : qkv + row3c(p, qrow) + head * HD);
 #pragma unroll
     for (int s = 0; s < A::KS; ++s) qf0[s] = load_row_frag_global<T, HD>(qptr, s, q);
     if constexpr (DQ) {
-      const T* doptr = qvalid ? reinterpret_cast<const T*>(p.dout) + qrow * p.C + head * HD : nullptr;
-      const T* optr = qvalid ? reinterpret_cast<const T*>(p.out) + qrow * p.C + head * HD : nullptr;
+      const T* doptr = qvalid ? reinterpret_cast<const T*>(p.dout) + row1c(p, qrow) + head * HD : nullptr;
+      const T* optr = qvalid ? reinterpret_cast<const T*>(p.out) + row1c(p, qrow) + head * HD : nullptr;
 #pragma unroll
       for (int s = 0; s < A::KS; ++s) { dof0[s] = load_row_frag_global<T, HD>(doptr, s, q); of0[s] = load_row_frag_global<T, HD>(optr, s, q); }
       if (qvalid) lse0 = p.lse[qrow * p.heads + head];
@@ -729,7 +749,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
     kb[c] = c < w.nvalid ? 0.f : ((c == w.nvalid && w.npad > 0) ? __logf((float)w.npad) : NEG_BIG);
   {
     auto ksrc = [&](int c) -> const T* {
-      if (c < w.nvalid) return qkv + key_row(p, w, c) * 3 * p.C + p.C + head * HD;
+      if (c < w.nvalid) return qkv + row3c(p, key_row(p, w, c)) + p.C + head * HD;
       if (c == w.nvalid && w.npad > 0) return reinterpret_cast<const T*>(p.bias) + p.C + head * HD;
       return nullptr;
     };
@@ -747,7 +767,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
     const int qi = rb * 16 + r15;
     const bool qvalid = qi < w.nq;
     const long qrow = q_row(p, w, qvalid ? qi : 0);
-    const T* qptr = qp ? qp + qrow * p.C + head * HD : qkv + qrow * 3 * p.C + head * HD;
+    const T* qptr = qp ? qp + row1c(p, qrow) + head * HD : qkv + row3c(p, qrow) + head * HD;
     const bool first = rb == rbf;
     typename A::Frag qf[A::KS];
 #pragma unroll
@@ -764,13 +784,13 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
       if (qvalid) {
-        T* orow = reinterpret_cast<T*>(p.out) + qrow * p.C + head * HD;
+        T* orow = reinterpret_cast<T*>(p.out) + row1c(p, qrow) + head * HD;
         store_rows_T<T, HD>(orow, o, 1.f / l, lane);
         if (q == 0) p.lse[qrow * p.heads + head] = m + __logf(l);
       }
     } else {
-      const T* doptr = reinterpret_cast<const T*>(p.dout) + qrow * p.C + head * HD;
-      const T* optr = reinterpret_cast<const T*>(p.out) + qrow * p.C + head * HD;
+      const T* doptr = reinterpret_cast<const T*>(p.dout) + row1c(p, qrow) + head * HD;
+      const T* optr = reinterpret_cast<const T*>(p.out) + row1c(p, qrow) + head * HD;
       typename A::Frag dof[A::KS];
 #pragma unroll
       for (int s = 0; s < A::KS; ++s) dof[s] = first ? dof0[s] : load_row_frag_global<T, HD>(doptr, s, q);
@@ -789,8 +809,8 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
       if (nfull < ntiles)
         res_dq_tile<T, HD, 1>(kimg + nfull * A::ROW_BYTES, vimg + nfull * A::ROW_BYTES, kb + nfull * 64, qf, dof, lane, p.scale, lse, delta, dq);
       if (qvalid) {
-        T* dst = p.qp ? reinterpret_cast<T*>(p.dqp) + qrow * p.C + head * HD
-                      : reinterpret_cast<T*>(p.dqkv) + qrow * 3 * p.C + head * HD;
+        T* dst = p.qp ? reinterpret_cast<T*>(p.dqp) + row1c(p, qrow) + head * HD
+                      : reinterpret_cast<T*>(p.dqkv) + row3c(p, qrow) + head * HD;
         store_rows_T<T, HD>(dst, dq, p.scale, lane);
       }
     }
@@ -801,7 +821,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
     const int wg = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;   // (unit-major)
     if (lane == 0 && wg < 2048) {
       unsigned long long* o = attn_stamps + (wg * 8 + wave) * 4;
-      o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0;
+      o[0] = t0; o[1] = t2 - t0; o[2] = t3 - t2; o[3] = t3;   // (t0 / t3 absolute: dispatch skew and the launch's span, tools/attn_stamps.py)
       if (wave == 0) attn_stamp_nq[wg] = w.nq;
     }
   }
@@ -841,11 +861,11 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResP
     auto qsrc = [&](int i) -> const T* {
       if (i >= w.nq) return nullptr;
       const long row = q_row(p, w, i);
-      return qp ? qp + row * p.C + head * HD : qkv + row * 3 * p.C + head * HD;
+      return qp ? qp + row1c(p, row) + head * HD : qkv + row3c(p, row) + head * HD;
     };
     auto dosrc = [&](int i) -> const T* {
       if (i >= w.nq) return nullptr;
-      return reinterpret_cast<const T*>(p.dout) + q_row(p, w, i) * p.C + head * HD;
+      return reinterpret_cast<const T*>(p.dout) + row1c(p, q_row(p, w, i)) + head * HD;
     };
     stage_rows2<T, HD>(nrows, qsrc, qimg, dosrc, doimg);
   }
@@ -859,7 +879,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResP
     const T* kp = nullptr;
     float kbias = NEG_BIG;
     long krow = 0;
-    if (c < w.nvalid) { krow = key_row(p, w, c); kp = qkv + krow * 3 * p.C + p.C + head * HD; kbias = 0.f; }
+    if (c < w.nvalid) { krow = key_row(p, w, c); kp = qkv + row3c(p, krow) + p.C + head * HD; kbias = 0.f; }
     else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; kbias = __logf((float)w.npad); }
     typename A::Frag kf[A::KS], vf[A::KS];
 #pragma unroll
@@ -889,7 +909,7 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResP
       mma_over_tokens<T, HD>(qimg + t * A::ROW_BYTES, ds, lane, dk);
     }
     if (c < w.nvalid) {
-      T* dst = reinterpret_cast<T*>(p.dqkv) + krow * 3 * p.C + p.C + head * HD;
+      T* dst = reinterpret_cast<T*>(p.dqkv) + row3c(p, krow) + p.C + head * HD;
       store_rows_T<T, HD>(dst, dk, p.scale, lane);
       store_rows_T<T, HD>(dst + p.C, dv, 1.f, lane);
     } else if (c == w.nvalid && w.npad > 0) {
@@ -921,7 +941,8 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
   constexpr int use_res = 1;
 #endif
   if constexpr (sizeof(T) == 2 && ResLds<T, HD>::BYTES <= 160 * 1024) {
-    if (use_res && maxk > 65 && maxk <= RES_ROWS && maxq <= 256) {   // multi-tile windows only (stage 3, block 44)
+    const long nrows_ = (long)p.B * p.H * p.W;   // (the resident kernels index rows with 24-bit multiplies and 32-bit element offsets)
+    if (use_res && maxk > 65 && maxk <= RES_ROWS && maxq <= 256 && nrows_ < (1L << 24) && nrows_ * 3 * p.C < (1L << 32)) {   // multi-tile windows only (stage 3, block 44)
       constexpr int LDS = ResLds<T, HD>::BYTES;
       static bool attr = false;
       if (!attr) {
