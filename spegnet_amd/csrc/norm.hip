@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
     }
   }
   if (active) {
-#pragma unroll 4
+#pragma unroll 8   // (4: 40 us for a BatchNorm-backward reduction over 8 x 192 x 192 x 64, 8: 32, 16: 44)
     for (long r = r0 + rl; r < r1; r += rpar) {
       float av[VEC];
       unpack16<T>(ld16(a + (base + r) * lda + ch * VEC), av);
