@@ -704,16 +704,13 @@ __device__ __forceinline__ void res_dq_tile(const char* kimg, const char* vimg, 
 }
 
 template <typename T, int HD, bool DQ, int DBG = 0>
-__global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPlan pl) {   // forward (DQ=false) or dQ (DQ=true)
+__device__ __forceinline__ void res_q_body(const AttnP& p, const int head, const int widx, const int part, const int nparts) {   // forward (DQ=false) or dQ (DQ=true)
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
   char* vimg = kimg + ResLds<T, HD>::IMG;
   float* kb = reinterpret_cast<float*>(vimg + ResLds<T, HD>::IMG + RES_ROWS * 8);   // (LDS map of ResLds: two images, 8 B x rows spare, 3 float arrays)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
-  const int head = blockIdx.x;
-  int widx, part, nparts;
-  res_unit(pl, p, blockIdx.y, widx, part, nparts);
   const Win w = get_win(p, widx);
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
   const T* qp = reinterpret_cast<const T*>(p.qp);
@@ -828,8 +825,16 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPla
 #endif
 }
 
-template <typename T, int HD>
-__global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResPlan pl) {
+template <typename T, int HD, bool DQ, int DBG = 0>
+__global__ __launch_bounds__(RES_THREADS) void attn_res_q_kernel(AttnP p, ResPlan pl) {
+  int widx, part, nparts;
+  res_unit(pl, p, blockIdx.y, widx, part, nparts);
+  res_q_body<T, HD, DQ, DBG>(p, blockIdx.x, widx, part, nparts);
+}
+
+// OWN_DELTA: delta[i] = dO_i . O_i formed here (the merged backward launch: the dQ units that would have written it run beside these)
+template <typename T, int HD, bool OWN_DELTA>
+__device__ __forceinline__ void res_dkv_body(const AttnP& p, const int head, const int widx, const int part, const int nparts) {
   using A = AC<T, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
@@ -838,9 +843,6 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResP
   float* delta_s = lse_s + RES_ROWS;
   long* qrows = nullptr; (void)qrows;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
-  const int head = blockIdx.x;
-  int widx, part, nparts;
-  res_unit(pl, p, blockIdx.y, widx, part, nparts);
   const Win w = get_win(p, widx);
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
   const T* qp = reinterpret_cast<const T*>(p.qp);
@@ -853,7 +855,21 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResP
     if (i < w.nq) {
       const long row = q_row(p, w, i);
       ls = p.lse[row * p.heads + head];
-      dl = p.delta[row * p.heads + head];
+      if constexpr (OWN_DELTA) {
+        const T* dop = reinterpret_cast<const T*>(p.dout) + row1c(p, row) + head * HD;
+        const T* op = reinterpret_cast<const T*>(p.out) + row1c(p, row) + head * HD;
+        typename A::Frag a_[A::NCH], b_[A::NCH];
+#pragma unroll
+        for (int ch = 0; ch < A::NCH; ++ch) {
+          if constexpr (sizeof(T) == 2) { a_[ch] = __builtin_bit_cast(bf16x8_t, ld16(dop + ch * 8)); b_[ch] = __builtin_bit_cast(bf16x8_t, ld16(op + ch * 8)); }
+          else { a_[ch] = 0.f; b_[ch] = 0.f; }   // (fp32: summed element-wise below)
+        }
+#pragma unroll
+        for (int ch = 0; ch < A::NCH; ++ch) dl = frag_dot(a_[ch], b_[ch], dl);
+        if constexpr (sizeof(T) != 2) { for (int d = 0; d < HD; ++d) dl += dop[d] * op[d]; }
+      } else {
+        dl = p.delta[row * p.heads + head];
+      }
     }
     lse_s[i] = ls; delta_s[i] = dl;
   }
@@ -929,6 +945,34 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResP
   }
 }
 
+template <typename T, int HD>
+__global__ __launch_bounds__(RES_THREADS) void attn_res_dkv_kernel(AttnP p, ResPlan pl) {
+  int widx, part, nparts;
+  res_unit(pl, p, blockIdx.y, widx, part, nparts);
+  res_dkv_body<T, HD, false>(p, blockIdx.x, widx, part, nparts);
+}
+// dQ and dK/dV units of a resident-window backward in ONE launch, longest first across both kinds (class by class: the dQ units of
+// a class, then its dK/dV units): ~2.5 rounds of workgroups packed together instead of 1.25 + 1.25 with two ragged tails, one launch less.
+template <typename T, int HD>
+__global__ __launch_bounds__(RES_THREADS) void attn_res_bwd_kernel(AttnP p, ResPlan plq, ResPlan plk) {
+  int u = blockIdx.y, c = 0;
+  bool isk = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nq_ = (i < 3 ? plq.first[i + 1] : plq.total) - plq.first[i];
+    const int nk_ = (i < 3 ? plk.first[i + 1] : plk.total) - plk.first[i];
+    if (u >= 0 && c >= 0) {
+      if (u < nq_) { c = -1 - i; isk = false; }
+      else if (u < nq_ + nk_) { u -= nq_; c = -1 - i; isk = true; }
+      else u -= nq_ + nk_;
+    }
+  }
+  c = -1 - c;                                     // the unit's class; u: its index inside (class, kind)
+  int widx, part, nparts;
+  if (!isk) { res_unit(plq, p, plq.first[c] + u, widx, part, nparts); res_q_body<T, HD, true, 0>(p, blockIdx.x, widx, part, nparts); }
+  else { res_unit(plk, p, plk.first[c] + u, widx, part, nparts); res_dkv_body<T, HD, true>(p, blockIdx.x, widx, part, nparts); }
+}
+
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int HD>
 static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
@@ -949,6 +993,7 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_q_kernel<T, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_q_kernel<T, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_bwd_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
       }
       // units in longest-first order (ResPlan): a full 16 x 16 window is two workgroups.  (Round 2, first attempt: the same split as a
@@ -968,11 +1013,18 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
         hipLaunchKernelGGL((attn_res_q_kernel<T, HD, false>), grid, dim3(RES_THREADS), LDS, s, p, plq);
         return check_launch("attn_fwd(res)");
       }
-      hipLaunchKernelGGL((attn_res_q_kernel<T, HD, true>), grid, dim3(RES_THREADS), LDS, s, p, plq);
-      int rc = check_launch("attn_bwd_dq(res)");
-      if (rc) return rc;
-      hipLaunchKernelGGL((attn_res_dkv_kernel<T, HD>), gridk, dim3(RES_THREADS), LDS, s, p, plk);
-      return check_launch("attn_bwd_dkv(res)");
+#ifdef SPG_DEV_KERNELS
+      static const char* sp_ = getenv("SPG_ATTN_BWD_SPLIT");   // A/B: the two-launch backward
+      if (sp_ && atoi(sp_) == 1) {
+        hipLaunchKernelGGL((attn_res_q_kernel<T, HD, true>), grid, dim3(RES_THREADS), LDS, s, p, plq);
+        int rc = check_launch("attn_bwd_dq(res)");
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_res_dkv_kernel<T, HD>), gridk, dim3(RES_THREADS), LDS, s, p, plk);
+        return check_launch("attn_bwd_dkv(res)");
+      }
+#endif
+      hipLaunchKernelGGL((attn_res_bwd_kernel<T, HD>), dim3(p.heads, plq.total + plk.total, 1), dim3(RES_THREADS), LDS, s, p, plq, plk);
+      return check_launch("attn_bwd(res)");
     }
   }
   const bool sub = p.sub > 0;
