@@ -230,8 +230,10 @@ def test_pack_matrix(ops):
 
 # ------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M,C", [(100, 144), (37, 1152), (64, 16), (513, 576)])
+@pytest.mark.parametrize("M,C", [(100, 144), (37, 1152), (64, 16), (513, 576), (5, 2048), (33, 288)])   # every chunk-slot instance, both dtypes
 def test_layernorm(ops, dt, M, C):
+    if dt == torch.float32 and C > 1280:
+        pytest.skip("fp32 rows are limited to 5 x 64 x 4 columns")
     x = rnd(M, C, seed=1).to(dt)
     g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
     xf = x.float().requires_grad_(True)
@@ -299,6 +301,11 @@ ATTN_CASES = [
     (1, 8, 32, 4, 72, 4, False),     # ... non-square map
     (2, 16, 16, 2, 72, 4, True),     # ... with 2 x 2-pooled queries (the stage 2 -> 3 transition block)
     (1, 12, 16, 2, 16, 4, False),
+    # resident-window kernels (bf16, 65 < keys <= 320) beyond the @384 geometry:
+    (1, 32, 32, 1, 72, 16, False),   # 2 x 2 full windows, no padding (the @768 layout): every tile full, two workgroups per window
+    (1, 26, 26, 1, 72, 16, False),   # 16 + 10: 160 / 100 valid keys + the pad key inside a partly filled last tile
+    (1, 20, 24, 2, 72, 16, False),   # non-square: 16 x 8 (pad key alone in its tile), 4 x 16 and 4 x 8 edge windows
+    (2, 24, 24, 1, 72, 16, True),    # pooled queries, two images
 ]
 
 
