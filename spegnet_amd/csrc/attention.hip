@@ -118,6 +118,9 @@ __device__ __forceinline__ void res_unit(const ResPlan& pl, const AttnP& p, int 
   else { wy = nfy; wx = nfx; }
   widx = (b * p.nwy + wy) * p.nwx + wx;
 }
+// (Measured and dropped, round 2: running an image's corner window as a second pass of its bottom-edge unit -- 256 workgroups, one round,
+// instead of 320 -- left the forward at 16.9 us and cost the merged backward 4 us (the folded units became the longest and sat late in
+// the order): a launch lasts as long as its longest workgroup, a full window's half, plus ~5 us; the short second-round units are free.)
 static ResPlan res_plan(const AttnP& p, bool keys) {
   ResPlan pl;
   const int nfy = p.H / p.ws, nfx = p.W / p.wsx, ry = p.H % p.ws, rx = p.W % p.wsx;
