@@ -213,7 +213,13 @@ __global__ __launch_bounds__(256) void ped_gather_bwd_kernel(const T* __restrict
 // Grid (row blocks, 1, channel slabs) as colreduce_kernel (norm.hip); partial layout [slab][row block][4][SW].
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr int HB_SLAB_CHUNKS = 16;
-constexpr int HB_MAX_GX = 512;
+#ifndef SPG_HB_MAX_GX
+#define SPG_HB_MAX_GX 512
+#endif
+#ifndef SPG_HB_ROWS_PER_THREAD
+#define SPG_HB_ROWS_PER_THREAD 16
+#endif
+constexpr int HB_MAX_GX = SPG_HB_MAX_GX;
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_head_reduce_kernel(const T* __restrict__ dnext, const T* __restrict__ x, const T* __restrict__ dpred,
@@ -398,7 +404,7 @@ static inline HbPlan hb_plan(long rows, int nch) {
   p.nchs = nch < HB_SLAB_CHUNKS ? nch : HB_SLAB_CHUNKS;
   p.nslabs = cdiv(nch, p.nchs);
   const int rpar = 256 / p.nchs;
-  long want = rows / ((long)rpar * 16);
+  long want = rows / ((long)rpar * SPG_HB_ROWS_PER_THREAD);
   long cap = 2048 / p.nslabs;
   if (cap > HB_MAX_GX) cap = HB_MAX_GX;
   if (want > cap) want = cap;
