@@ -3943,7 +3943,10 @@ extern "C" int spg_gemm_tn_group_reduce_batch(int n, const void* const* descs, c
   if (m == 0) return SPG_OK;
   for (int i = m; i < TN_REDUCE_BATCH; ++i) { b.g[i] = b.g[0]; b.slabs[i] = b.slabs[0]; b.G[i] = 0; }
   b.n = m;
-  hipLaunchKernelGGL(tn_group_reduce_batch_kernel, dim3(maxG - 1, 8, m), dim3(256), 0, (hipStream_t)stream, b);
+  #ifndef SPG_TN_REDUCE_YPARTS
+#define SPG_TN_REDUCE_YPARTS 8
+#endif
+  hipLaunchKernelGGL(tn_group_reduce_batch_kernel, dim3(maxG - 1, SPG_TN_REDUCE_YPARTS, m), dim3(256), 0, (hipStream_t)stream, b);
   return check_launch("gemm_tn_group_reduce_batch");
 }
 
