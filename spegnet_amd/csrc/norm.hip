@@ -467,7 +467,10 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
 // costs ~4.5 us of launch floor on this GPU).  Jobs travel in the kernel-argument struct: no device table.
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_BATCH_MAX = 48;
-constexpr int LN_BATCH_BLOCKS = 64;   // row blocks per job (upper bound): the partials of a job are <= 64 x 2C floats
+#ifndef SPG_LN_BATCH_BLOCKS
+#define SPG_LN_BATCH_BLOCKS 32   // (16: 178 us per batched launch, 24: 158, 32: 150, 64: 157, 128: 198)
+#endif
+constexpr int LN_BATCH_BLOCKS = SPG_LN_BATCH_BLOCKS;   // row blocks per job (upper bound): the partials of a job are <= LN_BATCH_BLOCKS x 2C floats
 struct LnJob {
   const void* dy; const void* x; const float* mean; const float* rstd; float* dgamma; float* dbeta;
   int M, C, ld, block0, rpb, nblk, poff;  // C: columns of this job (<= 256 16-byte chunks), ld: row stride; block0: first block; rpb: rows per block;
