@@ -61,6 +61,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 struct ConvGeom {
   int B, H, W, Ci;  // NHWC input of a 3x3/pad1/stride1 convolution
 };
+// conv_halo.hip: bf16 3x3 convolution with an LDS-resident input tile; returns 1 when the problem is outside its domain
+int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bias, int B, int H, int W, int Ci, int Co, int ldc,
+                        int cus, int force_bn, hipStream_t s);
 
 // Branch-free operand loads: raw buffer loads with hardware bounds checking (out-of-range offsets return 0), so
 // hipcc keeps every load of a K-tile in flight behind a counted vmcnt instead of branching around each one
@@ -3272,6 +3275,22 @@ static inline int pick_nb(int N, int tiles_m, int cus) {
   return nb;
 }
 
+
+// bf16 3x3 convolutions without a fused activation / residual go to the halo-tile kernel (conv_halo.hip) when it has an instance
+// for them; 1 = not taken.  Dev builds: SPG_CONV_HALO=0 keeps them on the implicit GEMM, 64 / 128 / 256 force that tile width.
+static int try_conv_halo(const void* X, const void* W, void* C, const NtEpi& epi, int N, int ldc, int conv, const ConvGeom& g, int cus,
+                         hipStream_t s) {
+  if (!conv || epi.act != SPG_ACT_NONE || epi.residual || epi.gelu_h || epi.C2) return 1;
+  int force = 0;
+#ifdef SPG_DEV_KERNELS
+  static const int mode = dev_env("SPG_CONV_HALO", 1);
+  if (mode == 0) return 1;
+  static const int dbg = dev_env("SPG_CONV_HALO_DBG", 0);   // ablation instances of conv_halo.hip (1 no DMA, 2 no reads, 3 no MFMAs, 4 no stores)
+  force = (mode == 1 ? 0 : mode) + 1000 * dbg;
+#endif
+  return launch_conv3x3_halo(X, W, C, epi.bias, g.B, g.H, g.W, g.Ci, N, ldc, cus, force, s);
+}
+
 // bf16 problems the 4-wave two-per-CU kernel has an instance for: 8-element-aligned rows, operands addressable by 32-bit offsets, no ReLU
 // (NT_V3_NA = not applicable, the caller falls through to the older kernels)
 constexpr int NT_V3_NA = -1000;
@@ -3372,6 +3391,8 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     return SPG_ERR_UNSUPPORTED;
   }
   if constexpr (sizeof(T) == 2) {
+    const int rch = try_conv_halo(X, W, C, epi, N, ldc, conv, g, num_cus(cu_budget), s);
+    if (rch != 1) return rch;
     const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s, cu_budget);
     if (rc3 != NT_V3_NA) return rc3;
   }
@@ -3557,6 +3578,8 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
                       (epi.C2 == nullptr || pact == PIPE_ACT_GELU || pact == PIPE_ACT_GELU_D) && (pact != PIPE_ACT_GELU_D || epi.C2 != nullptr) &&
                         !(conv && pact != PIPE_ACT_NONE);
     {
+      const int rch = try_conv_halo(X, W, C, epi, N, ldc, conv, g, cus, s);
+      if (rch != 1) return rch;
       const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s, cu_budget);
       if (rc3 != NT_V3_NA) return rc3;
     }
