@@ -51,9 +51,11 @@ __device__ __forceinline__ void halo_dma16(hrsrc_words_t rsrc, unsigned lds_addr
 template <int N_> __device__ __forceinline__ void halo_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 template <int BN> struct HaloCfg;
-template <> struct HaloCfg<256> { static constexpr int WM = 2, WN = 4, NW = 64, NPH = 4, NSLOT = 2, NG = 2, PPW = 2, LEAD = 2, VMW = 4; };
-template <> struct HaloCfg<128> { static constexpr int WM = 4, WN = 2, NW = 64, NPH = 2, NSLOT = 4, NG = 2, PPW = 1, LEAD = 3, VMW = 5; };
-template <> struct HaloCfg<64>  { static constexpr int WM = 4, WN = 2, NW = 32, NPH = 1, NSLOT = 8, NG = 1, PPW = 1, LEAD = 6, VMW = 5; };
+// WM x WN waves, NW output channels per wave, NPH phases per step (a phase = one m-half of the wave tile x all its n-blocks),
+// NSLOT ring slots, LEAD = how many steps the weight stream runs ahead, VMW = vmcnt that retires the next step's weights
+template <> struct HaloCfg<256> { static constexpr int WM = 2, WN = 4, NW = 64, NPH = 2, NSLOT = 2, LEAD = 2, VMW = 4; };
+template <> struct HaloCfg<128> { static constexpr int WM = 4, WN = 2, NW = 64, NPH = 1, NSLOT = 4, LEAD = 3, VMW = 4; };
+template <> struct HaloCfg<64>  { static constexpr int WM = 4, WN = 2, NW = 32, NPH = 1, NSLOT = 8, LEAD = 7, VMW = 6; };
 
 constexpr int HALO_TH = 8, HALO_TW = 32;                    // output tile (rows x columns of pixels)
 constexpr int HALO_PITCH = HALO_TW + 2;                     // halo columns per halo row
@@ -67,7 +69,7 @@ constexpr int HALO_LDS_BYTES = HALO_BIAS + 2048;
 constexpr unsigned HALO_DEAD = 0x80000000u;                 // source offset of a piece that must fill zeros (>= every buffer size)
 
 #ifdef SPG_DEV_KERNELS
-__device__ unsigned long long halo_stamps[256 * 8 * 6];   // DBG 5: per workgroup and wave: cycles in [issue | barrier 1 + lgkm wait | MFMA | barrier 2], phases, -
+__device__ unsigned long long halo_stamps[256 * 8 * 6];   // DBG 5: per workgroup and wave: cycles in [issue | barrier 1 | MFMA | barrier 2], phases, -
 #endif
 
 struct HaloArgs {
@@ -77,18 +79,20 @@ struct HaloArgs {
   unsigned xbytes, wbytes, cbytes;
 };
 
-// DBG (dev builds, wrong results by construction): 1 no LDS-DMA in the loop, 2 no fragment reads, 3 no MFMAs, 4 no epilogue stores
+// DBG (dev builds, wrong results by construction): 1 no LDS-DMA in the loop, 2 no fragment reads, 3 no MFMAs, 4 no epilogue stores,
+// 5 in-kernel stamps (tools/halo_stamps.py)
 template <int BN, int DBG = 0>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   using Cfg = HaloCfg<BN>;
-  constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, NPH = Cfg::NPH, NSLOT = Cfg::NSLOT, NG = Cfg::NG, PPW = Cfg::PPW, LEAD = Cfg::LEAD;
+  constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, NPH = Cfg::NPH, NSLOT = Cfg::NSLOT, LEAD = Cfg::LEAD;
   constexpr int RPW = HALO_TH / WM;            // tile rows per wave
-  constexpr int MB = RPW * 2;                  // 16-pixel m-blocks per wave
+  constexpr int MB = RPW * 2;                  // 16-pixel m-blocks per wave (4 per phase)
   constexpr int NBW = NW / 16;                 // n-blocks per wave
-  constexpr int RG = WN * 32 * 128;            // bytes of one weight region (the rows every wave reads in one phase)
-  constexpr int SLOT = NG * RG;                // bytes of one step's weight tile
+  constexpr int SLOT = BN * 128;               // bytes of one step's weight tile
+  constexpr int PPW = SLOT / 8192;             // weight pieces per wave and step
+  constexpr int NM = 4 * NBW * 2;              // MFMAs per phase
   static_assert(SLOT * NSLOT == HALO_WRING_BYTES, "ring");
-  static_assert(RG == 8 * PPW * 1024, "pieces per region");
+  static_assert(MB == 4 * NPH, "a phase covers four m-blocks");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,304 +130,325 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   unsigned a_lane[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) a_lane[d] = (unsigned)((d + r15) * 128 + ((q ^ ((d + r15) & 7)) << 4));
-  // B fragments: row rho = wc * 32 + 16 b + r15 of a region, chunk (4 s + q) ^ (rho & 7)
+  // B fragments: row rho = wc * (NW/2) + 16 b + r15 of each 32-column half, chunk (4 s + q) ^ (rho & 7)
+  // weight tile image: [n-half g][wave column wc][32 rows]: row = g * (WN * 32) + wc * 32 + 16 b + 4 qq + jj <-> n = wc NW + 32 g + 8 qq + 4 b + jj
   const unsigned b_lane = (unsigned)((wc * 32 + r15) * 128 + ((q ^ (r15 & 7)) << 4)) + (unsigned)HALO_WRING;
-  // weight pieces: piece pi = wave * PPW + j of a region covers its rows 8 pi .. 8 pi + 7; lane -> row rho, chunk c
+  constexpr int RG = WN * 32 * 128;            // bytes of one n-half of the weight tile
+  // weight pieces: piece pi = wave * PPW + j covers image rows 8 pi .. 8 pi + 7; lane -> row rho, chunk c
   const unsigned rowB = (unsigned)(9 * Ci * 2);
   unsigned w_rel[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
     const int rho = 8 * (wave * PPW + j) + (lane >> 3);
-    const int wc_ = rho >> 5, l = rho & 31, b = l >> 4, qq = (l >> 2) & 3, jj = l & 3;
-    const int nrel = wc_ * NW + 8 * qq + 4 * b + jj;            // (+ 32 g for region g)
+    const int g_ = rho / (WN * 32), r_ = rho % (WN * 32);
+    const int wc_ = r_ >> 5, l = r_ & 31, b = l >> 4, qq = (l >> 2) & 3, jj = l & 3;
+    const int nrel = wc_ * NW + 32 * g_ + 8 * qq + 4 * b + jj;
     w_rel[j] = (unsigned)nrel * rowB + (unsigned)((((lane & 7) ^ (rho & 7))) << 4);
   }
 
-  // ---- stream states (wave-uniform)
-  // compute stream
-  int c_k = 0;                      // ordinal of the tile being multiplied
-  int c_kc = 0, c_dyi = 0;          // 64-channel chunk, tap row (dy + 1)
-  int c_slot = 0;                   // ring slot of the current step
-  int c_hb = 0;                     // halo image of the current chunk
-  // weight stream: LEAD steps ahead
-  int w_k = 0, w_kc = 0, w_tap = 0, w_n0 = 0;
+  // ---- stream states (wave-uniform).  The nine taps of a chunk are unrolled, so a step's tap, the weight stream's tap and the halo
+  // piece it issues are compile-time constants; what remains at run time is chunk-level state, advanced once per nine steps.
+  const int nchunks = my_tiles * KC;
+  int c_k = 0, c_kc = 0;              // compute stream: tile ordinal and 64-channel chunk of the current chunk
+  int c_hb = 0;                       // halo image the current chunk reads
+  bool tile_start = false;            // the current chunk is the first of a tile other than the first (the previous tile's last m-half is pending)
+  unsigned slot_off = 0;              // ring slot (byte offset) of the current step
+  int w_k = 0, w_kc = 0, w_n0 = 0;    // weight stream (LEAD steps ahead): tile ordinal, chunk, first channel
   bool w_live = true;
-  // halo stream: one chunk ahead
-  int h_img = 0, h_y0 = 0, h_x0 = 0, h_kc = 0;
+  unsigned w_delta = 0;
+  int h_kc = 0;                       // halo stream = the chunk after the compute stream's
   bool h_live = false;
-  // epilogue parameters of the tile being multiplied
-  unsigned e_base = 0;
+  int h_y1 = 0, h_x1 = 0;             // its tile origin - 1 (halo row / column 0)
+  int h_sbase = 0;                    // byte offset of (image, h_y1, h_x1, channel 64 h_kc); may be negative
+  unsigned e_base = 0;                // epilogue parameters of the tile being multiplied
   bool e_xok0 = false, e_xok1 = false;
-  int e_y0 = 0, e_n0 = 0;
-
-  auto w_soff = [&]() __attribute__((always_inline)) -> unsigned {
-    return w_live ? (unsigned)(((w_n0 * 9 + w_tap) * Ci + w_kc * 64) * 2) : HALO_DEAD;
-  };
-  auto w_advance = [&]() __attribute__((always_inline)) {
-    if (++w_tap == 9) {
-      w_tap = 0;
-      if (++w_kc == KC) {
-        w_kc = 0;
-        ++w_k;
-        if (w_k < my_tiles) {
-          if (a.tiles_n > 1) w_n0 = ((first + w_k * G) % a.tiles_n) * BN;
-        } else {
-          w_live = false;
-        }
-      }
-    }
-  };
-  // the PPW pieces of region g of the weight stream's current step, into ring slot `slot`
+  int e_y0 = 0;
+  int n0_next = 0;                    // first output channel of the next tile (finished accumulators restart at its bias)
+  // values the issue segments of the current step use, prepared inside the previous step's last MFMA cluster
+  unsigned pa1 = 0, pb0 = 0, pb1 = 0, pw_off[PPW], ph_off = HALO_DEAD;
+  unsigned pw_dst = 0, ph_dst = 0;
   bool in_loop = false;
-  auto w_issue = [&](int g, int slot) __attribute__((always_inline)) {
-    if (DBG == 1 && in_loop) return;
-    const unsigned so = w_soff() + (unsigned)(g * 32) * rowB;
-    const unsigned dst = smem_base + (unsigned)(HALO_WRING + slot * SLOT + g * RG + wave * PPW * 1024);
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) halo_dma16(wr, dst + j * 1024, w_live ? w_rel[j] + so : HALO_DEAD);
+  const int ci2 = Ci * 2;
+
+  auto w_soff = [&](int tap) __attribute__((always_inline)) -> unsigned {
+    return (unsigned)(((w_n0 * 9 + tap) * Ci + w_kc * 64) * 2);
   };
-  // piece k (0..5) of this wave of the halo stream's chunk, into halo image hb
-  auto h_issue = [&](int k, int hb) __attribute__((always_inline)) {
-    if (DBG == 1 && in_loop) return;
-    const int pc = k * 8 + wave;
-    const int p = pc * 8 + (lane >> 3);
-    const int hy = (p * 241) >> 13, hx = p - hy * HALO_PITCH;
-    const int y = h_y0 - 1 + hy, x = h_x0 - 1 + hx;
-    const bool ok = h_live && p < HALO_ROWS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-    const unsigned off = (unsigned)((((h_img * H + y) * W + x) * Ci + h_kc * 64) * 2) + (unsigned)((((lane & 7) ^ (hx & 7))) << 4);
-    const int pcd = pc < HALO_PIECES ? pc : HALO_PIECES;
-    halo_dma16(xr, smem_base + (unsigned)(hb * HALO_BUF + pcd * 1024), ok ? off : HALO_DEAD);
+  auto tile_n0 = [&](int k) __attribute__((always_inline)) -> int {
+    return a.tiles_n > 1 ? ((first + k * G) % a.tiles_n) * BN : 0;
   };
-  auto e_load = [&](int t) __attribute__((always_inline)) {
+  auto e_load = [&]() __attribute__((always_inline)) {   // epilogue addresses of tile c_k
     int n0, x0, y0, img;
-    decode(t, n0, x0, y0, img);
-    e_y0 = y0; e_n0 = n0;
+    decode(first + c_k * G, n0, x0, y0, img);
+    e_y0 = y0;
     e_xok0 = x0 + r15 < W; e_xok1 = x0 + 16 + r15 < W;
     e_base = ((unsigned)((img * H + y0 + wm * RPW) * W + x0 + r15) * (unsigned)a.ldc + (unsigned)(n0 + wc * NW + 8 * q)) * 2u;
   };
+  // aim the halo stream at chunk (tile ordinal k, chunk kc)
+  auto h_aim = [&](int k, int kc, bool new_tile) __attribute__((always_inline)) {
+    h_live = k < my_tiles;
+    if (new_tile && h_live) {
+      int n0, x0, y0, img;
+      decode(first + k * G, n0, x0, y0, img);
+      h_y1 = y0 - 1; h_x1 = x0 - 1;
+      h_sbase = ((img * H + h_y1) * W + h_x1) * ci2;
+    }
+    h_kc = kc;
+  };
+  // source offset of halo piece k of the halo stream's chunk (piece k of this wave covers halo rows p = (8 k + wave) * 8 + lane / 8);
+  // split in four parts so that each fits an MFMA gap
+  int hv_p = 0, hv_hy = 0, hv_hx = 0, hv_lin = 0;
+  bool hv_ok = false;
+  auto h_part = [&](int part, int k) __attribute__((always_inline)) {
+    if (part == 0) {
+      hv_p = (lane >> 3) + (k * 8 + wave) * 8;
+      hv_hy = (hv_p * 241) >> 13;                                  // p / 34 for p < 392
+    } else if (part == 1) {
+      hv_hx = hv_p - hv_hy * HALO_PITCH;
+      hv_lin = hv_hy * W + hv_hx;
+    } else if (part == 2) {
+      hv_ok = h_live && hv_p < HALO_ROWS && (unsigned)(h_y1 + hv_hy) < (unsigned)H && (unsigned)(h_x1 + hv_hx) < (unsigned)W;
+    } else {
+      const unsigned off = (unsigned)(hv_lin * ci2 + h_sbase + h_kc * 128) + (unsigned)((((lane ^ hv_hx) & 7)) << 4);
+      ph_off = hv_ok ? off : HALO_DEAD;
+    }
+  };
 
   f32x4 acc[MB][NBW];
+  bf16x8_t Af[8], Bf[2 * NBW];
+  // the accumulators of m-half h restart at the bias of tile n0 (so the epilogue adds nothing)
+  auto acc_init = [&](auto H_, int n0) __attribute__((always_inline)) {
+    constexpr int h = decltype(H_)::value;
+    const float* bl = reinterpret_cast<const float*>(smem + HALO_BIAS) + n0 + wc * NW + 8 * q;
 #pragma unroll
-  for (int i = 0; i < MB; ++i)
+    for (int nb = 0; nb < NBW; ++nb) {
+      // n-block nb = 2 v + b holds channels 32 v + 8 q + 4 b + (0..3) of the wave's range in its four D rows 4 q + (0..3)
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + 32 * (nb >> 1) + 4 * (nb & 1));
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t Af[8], Bf[NG][4];
-
-  // ---- epilogue of quadrant (m-half h, n-half g): + bias, bf16, 16-byte stores; the quadrant's accumulators restart at zero
-  auto epilogue = [&](auto H_, auto G_) __attribute__((always_inline)) {
-    constexpr int h = decltype(H_)::value, g = decltype(G_)::value;
-    const float* bl = reinterpret_cast<const float*>(smem + HALO_BIAS) + e_n0 + wc * NW + g * 32 + 8 * q;
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl), b1 = *reinterpret_cast<const f32x4*>(bl + 4);
+      for (int i = 0; i < 4; ++i) acc[4 * h + i][nb] = bv;
+    }
+  };
+  // ---- epilogue of m-half h: bf16, 16-byte stores (n-blocks 2v, 2v+1 hold 8 consecutive channels of a pixel)
+  auto epilogue = [&](auto H_) __attribute__((always_inline)) {
+    constexpr int h = decltype(H_)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mi = 4 * h + i;
       const int row = 2 * h + (i >> 1);                                    // tile row inside the wave's rows
       const bool ok = ((i & 1) ? e_xok1 : e_xok0) && (e_y0 + wm * RPW + row < H);
-      const unsigned off = e_base + (unsigned)(((row * W + 16 * (i & 1)) * a.ldc + g * 32) * 2);
-      float ev[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { ev[e] = acc[mi][2 * g][e] + b0[e]; ev[4 + e] = acc[mi][2 * g + 1][e] + b1[e]; }
-      const u32x4 v = pack16<bf16_t>(ev);
-      if constexpr (DBG != 4) __builtin_amdgcn_raw_buffer_store_b128(hbufvec_t{v.x, v.y, v.z, v.w}, cr, ok ? off : 0xFFFFFFF0u, 0, 0);
-      else asm volatile("" ::"v"(v));
-      acc[mi][2 * g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc[mi][2 * g + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  // quadrant of phase p
-  auto epilogue_of_phase = [&](auto P_) __attribute__((always_inline)) {
-    constexpr int p = decltype(P_)::value;
-    if constexpr (NPH == 4) {
-      if constexpr (p == 0) epilogue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-      if constexpr (p == 1) epilogue(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-      if constexpr (p == 2) epilogue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-      if constexpr (p == 3) epilogue(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-    } else if constexpr (NPH == 2) {
-      if constexpr (p == 0) epilogue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-      if constexpr (p == 1) epilogue(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-    } else {
-      epilogue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      for (int v = 0; v < NBW / 2; ++v) {
+        const unsigned off = e_base + (unsigned)(((row * W + 16 * (i & 1)) * a.ldc + v * 32) * 2);
+        float ev[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ev[e] = acc[mi][2 * v][e]; ev[4 + e] = acc[mi][2 * v + 1][e]; }
+        const u32x4 pk = pack16<bf16_t>(ev);
+        if constexpr (DBG != 4) __builtin_amdgcn_raw_buffer_store_b128(hbufvec_t{pk.x, pk.y, pk.z, pk.w}, cr, ok ? off : 0xFFFFFFF0u, 0, 0);
+        else asm volatile("" ::"v"(pk));
+      }
     }
   };
 
   // ---- prologue: bias -> LDS, halo image of chunk 0, weight steps 0 .. LEAD-1
   for (int i = tid; i < a.Co; i += 512) reinterpret_cast<float*>(smem + HALO_BIAS)[i] = a.bias ? a.bias[i] : 0.f;
-  {
-    int n0, x0, y0, img;
-    decode(first, n0, x0, y0, img);
-    w_n0 = n0;
-    h_img = img; h_y0 = y0; h_x0 = x0; h_kc = 0; h_live = true;
-    e_load(first);
-  }
+  w_n0 = tile_n0(0);
+  n0_next = my_tiles > 1 ? tile_n0(1) : 0;
+  e_load();
+  h_aim(0, 0, true);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) h_issue(k, 0);
+  for (int k = 0; k < 6; ++k) {
+    const int pc = k * 8 + wave;
+#pragma unroll
+    for (int part = 0; part < 4; ++part) h_part(part, k);
+    halo_dma16(xr, smem_base + (unsigned)((pc < HALO_PIECES ? pc : HALO_PIECES) * 1024), ph_off);
+  }
+  static_assert(LEAD < 9, "the prologue's weight steps stay inside chunk 0");
 #pragma unroll
   for (int s = 0; s < LEAD; ++s) {
+    const unsigned so = w_soff(s);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) w_issue(g, s);
-    w_advance();
+    for (int j = 0; j < PPW; ++j) halo_dma16(wr, smem_base + (unsigned)(HALO_WRING + s * SLOT + (wave * PPW + j) * 1024), w_rel[j] + so);
+  }
+  // step 0's prepared values; the halo stream moves on to chunk 1
+  if (KC > 1) h_aim(0, 1, false); else h_aim(1, 0, true);
+  {
+    const unsigned so = w_soff(LEAD);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) pw_off[j] = w_rel[j] + so;
+    pw_dst = smem_base + (unsigned)(HALO_WRING + (LEAD & (NSLOT - 1)) * SLOT + wave * PPW * 1024);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) a_lane[d] += (unsigned)((wm * RPW) * (HALO_PITCH * 128));   // from here on: the read base in halo image c_hb
+    pa1 = a_lane[0] ^ 64u;
+    pb0 = b_lane; pb1 = pb0 ^ 64u;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  acc_init(std::integral_constant<int, 0>{}, tile_n0(0));
+  if constexpr (NPH == 2) acc_init(std::integral_constant<int, 1>{}, tile_n0(0));
   in_loop = true;
   if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier interval behind group 0
 
   unsigned long long st_sum0 = 0, st_sum1 = 0, st_sum2 = 0, st_sum3 = 0, st_n = 0;
-  const int total_it = my_tiles * KC * 3;              // iterations = (tile, chunk, tap row), three steps (dx) each
-  bool prev_fin = false;                               // the previous step ended a tile: its last quadrant is still to be stored
-  for (int it = 0; it < total_it; ++it) {
-    const bool last_it = (c_kc == KC - 1) && (c_dyi == 2);
-    if (c_dyi == 0) {   // a new chunk starts: aim the halo stream at the chunk after it
-      if (c_kc + 1 < KC) {
-        h_kc = c_kc + 1;          // same tile (h_img / h_y0 / h_x0 already describe it)
-        h_live = true;
-      } else if (c_k + 1 < my_tiles) {
-        int n0;
-        decode(first + (c_k + 1) * G, n0, h_x0, h_y0, h_img);
-        h_kc = 0;
-        h_live = true;
-      } else {
-        h_live = false;
+
+  // ---- one step = tap T of the current chunk.  What the NEXT step's issue segments need is formed in the gaps of this step's last
+  // MFMA cluster, a few instructions per gap (VALU / SALU between a wave's own MFMAs is nearly free; in the issue segment it
+  // competes with the partner wave's MFMAs and stretches the interval; a long block in ONE gap drains the matrix pipe).
+  auto step = [&](auto T_) __attribute__((always_inline)) {
+    constexpr int t = decltype(T_)::value;
+    constexpr int dyi = t / 3, dxi = t % 3;
+    constexpr int nt = (t + 1) % 9, ndxi = nt % 3;          // the next step's tap
+    constexpr int nwt = (nt + LEAD) % 9;                     // the weight stream's tap during the next step
+    constexpr bool nh = nt >= 1 && nt <= 6;                  // the next step issues halo piece nt - 1
+    auto hook = [&](int m) __attribute__((always_inline)) {  // gap after MFMA m of the step's LAST cluster
+      if (m == 0) {
+        slot_off = (slot_off + (unsigned)SLOT) & (unsigned)(HALO_WRING_BYTES - 1);
+        pw_dst = smem_base + (unsigned)HALO_WRING + ((slot_off + (unsigned)(LEAD * SLOT)) & (unsigned)(HALO_WRING_BYTES - 1)) + (unsigned)(wave * PPW * 1024);
       }
-    }
-    const unsigned sA = (unsigned)(c_hb * HALO_BUF + (wm * RPW + c_dyi) * (HALO_PITCH * 128));
-
-    auto step = [&](auto DXI_) __attribute__((always_inline)) {
-      constexpr int dxi = decltype(DXI_)::value;
-      const unsigned a0 = a_lane[dxi] + sA, a1 = a0 ^ 64u;
-      const unsigned b0 = b_lane + (unsigned)(c_slot * SLOT), b1 = b0 ^ 64u;
-      const int sidx = c_dyi * 3 + dxi;                       // step of the chunk, 0..8
-      const int w_slot = (c_slot + LEAD) & (NSLOT - 1);
-      const bool fin = last_it && dxi == 2;
-
-      auto read_A = [&](auto H_) __attribute__((always_inline)) {
-        constexpr int h = decltype(H_)::value;
+      if (m == 1) { pb0 = b_lane + slot_off; }
+      if (m == 2) { pb1 = pb0 ^ 64u; }
+      if constexpr (t == 8) {   // the compute stream enters the next chunk
+        if (m == 3) {
+          c_hb ^= 1;
+          if (++c_kc == KC) { c_kc = 0; ++c_k; tile_start = true; } else tile_start = false;
+        }
+        if (m == 4) {   // halo stream: the chunk after that
+          if (c_kc + 1 < KC) h_aim(c_k, c_kc + 1, false); else h_aim(c_k + 1, 0, true);
+        }
+        if (m == 5) {
+          const unsigned sa = c_hb ? (unsigned)HALO_BUF : (unsigned)-HALO_BUF;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) a_lane[d] += sa;
+        }
+      }
+      if (m == 6) { pa1 = a_lane[ndxi] ^ 64u; }
+      if constexpr (nwt == 0) {   // the weight stream enters its next chunk
+        if (m == 7) {   // scalar offset of (chunk, tap 0) minus that of (previous chunk, tap 8); a dead stream: everything out of range
+          const unsigned so_old = w_soff(8);
+          if (++w_kc == KC) {
+            w_kc = 0;
+            ++w_k;
+            if (w_k < my_tiles) { if (a.tiles_n > 1) w_n0 = tile_n0(w_k); } else w_live = false;
+          }
+          w_delta = w_soff(0) - so_old;
+        }
+        if (m == 8) {
+#pragma unroll
+          for (int j = 0; j < PPW; ++j) pw_off[j] = w_live ? pw_off[j] + w_delta : HALO_DEAD;
+        }
+      } else {
+        if (m == 8) {
+#pragma unroll
+          for (int j = 0; j < PPW; ++j) pw_off[j] += (unsigned)ci2;    // (a dead stream stays dead: DEAD + 8 tap strides does not wrap)
+        }
+      }
+      if constexpr (nh) {
+        if (m == 9) {
+          const int pc = (nt - 1) * 8 + wave;
+          ph_dst = smem_base + (unsigned)((c_hb ^ 1) * HALO_BUF + (pc < HALO_PIECES ? pc : HALO_PIECES) * 1024);
+        }
+        if (m == 10) h_part(0, nt - 1);
+        if (m == 11) h_part(1, nt - 1);
+        if (m == 12) h_part(2, nt - 1);
+        if (m == 13) h_part(3, nt - 1);
+      }
+    };
+    auto phase = [&](auto P_) __attribute__((always_inline)) {
+      constexpr int p = decltype(P_)::value;            // = the m-half this phase multiplies
+      constexpr bool lastp = p == NPH - 1;
+      unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+      if constexpr (DBG == 5) tA = __builtin_amdgcn_s_memtime();
+      // ================= issue segment: fragment reads, LDS-DMA pieces, (rarely) a finished tile's stores
+      if constexpr (DBG != 2) {
+        if constexpr (p == 0) {
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb) {
+            const int imm = (nb >> 1) * RG + (nb & 1) * 2048;
+            Bf[2 * nb] = *reinterpret_cast<const bf16x8_t*>(smem + pb0 + imm);
+            Bf[2 * nb + 1] = *reinterpret_cast<const bf16x8_t*>(smem + pb1 + imm);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int imm = (2 * h + (i >> 1)) * (HALO_PITCH * 128) + (i & 1) * 2048;
-          Af[2 * i] = *reinterpret_cast<const bf16x8_t*>(smem + a0 + imm);
-          Af[2 * i + 1] = *reinterpret_cast<const bf16x8_t*>(smem + a1 + imm);
+          const int imm = (2 * p + (i >> 1) + dyi) * (HALO_PITCH * 128) + (i & 1) * 2048;
+          Af[2 * i] = *reinterpret_cast<const bf16x8_t*>(smem + a_lane[dxi] + imm);
+          Af[2 * i + 1] = *reinterpret_cast<const bf16x8_t*>(smem + pa1 + imm);
         }
-      };
-      auto read_B = [&](auto G_) __attribute__((always_inline)) {
-        constexpr int g = decltype(G_)::value;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DBG == 1 && in_loop)) {
+        if constexpr (lastp) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          Bf[g][2 * b] = *reinterpret_cast<const bf16x8_t*>(smem + b0 + g * RG + b * 2048);
-          Bf[g][2 * b + 1] = *reinterpret_cast<const bf16x8_t*>(smem + b1 + g * RG + b * 2048);
+          for (int j = 0; j < PPW; ++j) halo_dma16(wr, pw_dst + j * 1024, pw_off[j]);
         }
-      };
-      auto mfmas = [&](auto H_, auto G_) __attribute__((always_inline)) {
-        constexpr int h = decltype(H_)::value, g = decltype(G_)::value;
+        if constexpr (p == 0 && t >= 1 && t <= 6) halo_dma16(xr, ph_dst, ph_off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (p == 0 && t == 0) {
+        if (tile_start) {   // the previous tile's last m-half; its accumulators restart at this tile's bias
+          epilogue(std::integral_constant<int, NPH - 1>{});
+          acc_init(std::integral_constant<int, NPH - 1>{}, n0_next);
+        }
+      }
+      if constexpr (p == 1 && t == 8) {
+        if (c_kc == KC - 1) {    // the tile's last step: m-half 0 is complete
+          epilogue(std::integral_constant<int, 0>{});
+          acc_init(std::integral_constant<int, 0>{}, n0_next);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the next step's weights have landed (this wave's pieces; the barrier publishes everyone's); this wave's reads have returned
+      if constexpr (lastp) halo_wait_vm<Cfg::VMW>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (DBG == 5) tB = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DBG == 5) tC = __builtin_amdgcn_s_memtime();
+      // ================= MFMA segment
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-              acc[4 * h + i][2 * g + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[g][2 * b + s], Af[2 * i + s], acc[4 * h + i][2 * g + b], 0, 0, 0);
-      };
-      auto phase = [&](auto P_) __attribute__((always_inline)) {
-        constexpr int p = decltype(P_)::value;
-        constexpr int ph = NPH == 4 ? (p >= 2 ? 1 : 0) : 0;                     // m-half of this phase's quadrant
-        constexpr int pg = NPH == 4 ? ((p == 1 || p == 2) ? 1 : 0) : (NPH == 2 ? p : 0);   // n-half
-        unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
-        if constexpr (DBG == 5) tA = __builtin_amdgcn_s_memtime();
-        // ---- fragment reads
-        if constexpr (DBG == 2) {
-        } else if constexpr (NPH == 4) {
-          if constexpr (p == 0) { read_B(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0); read_A(std::integral_constant<int, 0>{}); }
-          if constexpr (p == 1) read_B(std::integral_constant<int, 1>{});
-          if constexpr (p == 2) read_A(std::integral_constant<int, 1>{});
-        } else if constexpr (NPH == 2) {
-          if constexpr (p == 0) { read_B(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0); read_A(std::integral_constant<int, 0>{}); }
-          if constexpr (p == 1) read_B(std::integral_constant<int, 1>{});
+      for (int m = 0; m < NM; ++m) {
+        const int s = m / (4 * NBW), r = m % (4 * NBW), i = r / NBW, nb = r % NBW;
+        if constexpr (DBG != 3) {
+          acc[4 * p + i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[2 * nb + s], Af[2 * i + s], acc[4 * p + i][nb], 0, 0, 0);
         } else {
-          read_B(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0); read_A(std::integral_constant<int, 0>{});
+          asm volatile("" ::"v"(Af[2 * i + s]), "v"(Bf[2 * nb + s]));
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- LDS-DMA issue: the weight stream's region for this phase, one halo piece in steps 1..6 of a chunk
-        if constexpr (NPH == 4) {
-          if constexpr (p == 2) w_issue(0, w_slot);
-          if constexpr (p == 3) { w_issue(1, w_slot); }
-        } else if constexpr (NPH == 2) {
-          w_issue(p, w_slot);
-        } else {
-          w_issue(0, w_slot);
-        }
-        if constexpr (p == 0) {
-          if (sidx >= 1 && sidx <= 6) h_issue(sidx - 1, c_hb ^ 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue pieces of a finished tile (in the other group's MFMA shadow)
-        if constexpr (p == 0) {
-          if constexpr (dxi == 0) {
-            if (prev_fin) {
-              epilogue_of_phase(std::integral_constant<int, NPH - 1>{});
-              e_load(first + c_k * G);
+        if constexpr (p == 0 && t == 0) {
+          if (m == 14) {
+            if (tile_start) {   // a new tile has begun: its epilogue addresses, the first channel of the tile after it
+              n0_next = c_k + 1 < my_tiles ? tile_n0(c_k + 1) : 0;
+              e_load();
             }
           }
-        } else {
-          if constexpr (dxi == 2) {
-            if (fin) epilogue_of_phase(std::integral_constant<int, p - 1>{});
-          }
         }
+        if constexpr (lastp) hook(m);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- the weight regions read in the next phase have landed (this wave's pieces; the barrier publishes everyone's)
-        if constexpr (NPH == 4) {
-          if constexpr (p == 3) halo_wait_vm<Cfg::VMW>();
-        } else {
-          halo_wait_vm<Cfg::VMW>();
-        }
-        if constexpr (DBG == 5) tB = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_barrier();
-#ifndef HALO_NO_LGKM0
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DBG == 5) tC = __builtin_amdgcn_s_memtime();
-#ifndef HALO_NO_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-        if constexpr (DBG != 3) mfmas(std::integral_constant<int, ph>{}, std::integral_constant<int, pg>{});
-        else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(Af[i]));
-#pragma unroll
-          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(Bf[pg][i]));
-        }
-#ifndef HALO_NO_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DBG == 5) tD = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_barrier();
-        if constexpr (DBG == 5) {
-          const unsigned long long tE = __builtin_amdgcn_s_memtime();
-          st_sum0 += tB - tA; st_sum1 += tC - tB; st_sum2 += tD - tC; st_sum3 += tE - tD; st_n += 1;
-        }
-      };
-      phase(std::integral_constant<int, 0>{});
-      if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
-      if constexpr (NPH == 4) { phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{}); }
-      // ---- advance one step
-      w_advance();
-      c_slot = (c_slot + 1) & (NSLOT - 1);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DBG == 5) tD = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      if constexpr (DBG == 5) {
+        const unsigned long long tE = __builtin_amdgcn_s_memtime();
+        st_sum0 += tB - tA; st_sum1 += tC - tB; st_sum2 += tD - tC; st_sum3 += tE - tD; st_n += 1;
+      }
     };
+    phase(std::integral_constant<int, 0>{});
+    if constexpr (NPH == 2) phase(std::integral_constant<int, 1>{});
+  };
+  for (int ch = 0; ch < nchunks; ++ch) {
     step(std::integral_constant<int, 0>{});
-    prev_fin = false;
     step(std::integral_constant<int, 1>{});
     step(std::integral_constant<int, 2>{});
-    prev_fin = last_it;
-    // ---- advance one iteration
-    if (++c_dyi == 3) {
-      c_dyi = 0;
-      c_hb ^= 1;
-      if (++c_kc == KC) { c_kc = 0; ++c_k; }
-    }
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
   }
-  // the last tile's last quadrant (c_k has moved past it: e_* still describe it)
-  epilogue_of_phase(std::integral_constant<int, NPH - 1>{});
+  // the last tile's last m-half (the epilogue parameters still describe that tile)
+  epilogue(std::integral_constant<int, NPH - 1>{});
   if (grp == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SPG_DEV_KERNELS
@@ -449,14 +474,13 @@ int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bia
   const int tx = cdiv(W, HALO_TW), ty = cdiv(H, HALO_TH);
   const long sp_tiles = (long)B * tx * ty;
   // tile width: the widest that divides Co, unless a narrower one fills the CUs' rounds markedly better
-  int bn = Co % 256 == 0 ? 256 : (Co % 128 == 0 ? 128 : 64);
+  int bn = Co % 128 == 0 ? 128 : 64;
   auto util = [&](int b) {
     const long t = sp_tiles * (Co / b);
     return (double)t / (double)((t + cus - 1) / cus * cus);
   };
-  if (bn == 256 && util(256) < 0.8 * util(128)) bn = 128;
   if (bn == 128 && util(128) < 0.8 * util(64)) bn = 64;
-  if (force_bn == 256 || force_bn == 128 || force_bn == 64) {
+  if (force_bn == 128 || force_bn == 64) {
     if (Co % force_bn != 0) return 1;
     bn = force_bn;
   }
@@ -481,8 +505,7 @@ int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bia
   } while (0)
 #define SPG_HALO_LAUNCH_BN(D_)                   \
   do {                                           \
-    if (bn == 256) SPG_HALO_LAUNCH(256, D_);     \
-    else if (bn == 128) SPG_HALO_LAUNCH(128, D_); \
+    if (bn == 128) SPG_HALO_LAUNCH(128, D_);     \
     else SPG_HALO_LAUNCH(64, D_);                \
   } while (0)
 #ifdef SPG_DEV_KERNELS
