@@ -26,6 +26,7 @@
 // first piece can be issued), and is read again only in a phase that follows a phase in which EVERY wave has waited (vmcnt) for its
 // own pieces of it (the barrier between the two phases publishes them).  vmcnt values are computed for the weight pieces alone;
 // halo pieces and epilogue stores only add younger operations, which makes the waits stricter, never weaker.
+#include <algorithm>
 #include <type_traits>
 #include "common.h"
 
@@ -53,7 +54,6 @@ template <int N_> __device__ __forceinline__ void halo_wait_vm() { asm volatile(
 template <int BN> struct HaloCfg;
 // WM x WN waves, NW output channels per wave, NPH phases per step (a phase = one m-half of the wave tile x all its n-blocks),
 // NSLOT ring slots, LEAD = how many steps the weight stream runs ahead, VMW = vmcnt that retires the next step's weights
-template <> struct HaloCfg<256> { static constexpr int WM = 2, WN = 4, NW = 64, NPH = 2, NSLOT = 2, LEAD = 2, VMW = 4; };
 template <> struct HaloCfg<128> { static constexpr int WM = 4, WN = 2, NW = 64, NPH = 1, NSLOT = 4, LEAD = 3, VMW = 4; };
 template <> struct HaloCfg<64>  { static constexpr int WM = 4, WN = 2, NW = 32, NPH = 1, NSLOT = 8, LEAD = 7, VMW = 6; };
 
@@ -84,20 +84,20 @@ struct HaloArgs {
 template <int BN, int DBG = 0>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   using Cfg = HaloCfg<BN>;
-  constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, NPH = Cfg::NPH, NSLOT = Cfg::NSLOT, LEAD = Cfg::LEAD;
+  constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, NSLOT = Cfg::NSLOT, LEAD = Cfg::LEAD;
   constexpr int RPW = HALO_TH / WM;            // tile rows per wave
-  constexpr int MB = RPW * 2;                  // 16-pixel m-blocks per wave (4 per phase)
+  constexpr int MB = RPW * 2;                  // 16-pixel m-blocks per wave
   constexpr int NBW = NW / 16;                 // n-blocks per wave
   constexpr int SLOT = BN * 128;               // bytes of one step's weight tile
   constexpr int PPW = SLOT / 8192;             // weight pieces per wave and step
-  constexpr int NM = 4 * NBW * 2;              // MFMAs per phase
+  constexpr int NM = MB * NBW * 2;             // MFMAs per step
   static_assert(SLOT * NSLOT == HALO_WRING_BYTES, "ring");
-  static_assert(MB == 4 * NPH, "a phase covers four m-blocks");
+  static_assert(MB == 4 && NM >= 16, "the step hooks use gaps 0..15");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
-  const int wm = WM == 2 ? grp : (wave >> 1), wc = WM == 2 ? (wave & 3) : (wave & 1);
+  const int wm = wave >> 1, wc = wave & 1;
   const int r15 = lane & 15, q = lane >> 4;
   const int H = a.H, W = a.W, Ci = a.Ci;
   const int KC = Ci >> 6;
@@ -115,13 +115,35 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, a.cbytes, 0x00020000);
   const unsigned smem_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem[0]
 
-  // tile id -> (n tile, x tile, y tile, image)
-  auto decode = [&](int t, int& n0, int& x0, int& y0, int& img) __attribute__((always_inline)) {
-    const int nt = t % a.tiles_n, sp = t / a.tiles_n;
-    const int xt = sp % a.tiles_x, r2 = sp / a.tiles_x;
-    const int yt = r2 % a.tiles_y;
-    img = r2 / a.tiles_y;
-    n0 = nt * BN; x0 = xt * HALO_TW; y0 = yt * HALO_TH;
+  // ---- tile walk.  This workgroup multiplies tiles first, first + G, ...; a tile id is the mixed-radix number (image, y tile, x tile,
+  // n tile), so "+ G" is an add with carries of G's digits: no division after this block.
+  int gd_n, gd_x, gd_y, gd_i;          // digits of G
+  int ed_n, ed_x, ed_y, ed_i;          // digits of the tile being multiplied (epilogue addresses, bias)
+  int hd_n, hd_x, hd_y, hd_i;          // digits of the halo stream's tile (it runs one chunk ahead)
+  int wd_n;                            // n digit of the weight stream's tile (it runs LEAD steps ahead; the lowest digit needs no carry in)
+  {
+    int r = G;
+    gd_n = r % a.tiles_n; r /= a.tiles_n;
+    gd_x = r % a.tiles_x; r /= a.tiles_x;
+    gd_y = r % a.tiles_y; gd_i = r / a.tiles_y;
+    r = first;
+    ed_n = r % a.tiles_n; r /= a.tiles_n;
+    ed_x = r % a.tiles_x; r /= a.tiles_x;
+    ed_y = r % a.tiles_y; ed_i = r / a.tiles_y;
+    hd_n = ed_n; hd_x = ed_x; hd_y = ed_y; hd_i = ed_i;
+    wd_n = ed_n;
+  }
+  auto walk = [&](int& dn, int& dx, int& dy, int& di) __attribute__((always_inline)) {   // (dn, dx, dy, di) += G
+    int v = dn + gd_n;
+    int c = v >= a.tiles_n ? 1 : 0;
+    dn = c ? v - a.tiles_n : v;
+    v = dx + gd_x + c;
+    c = v >= a.tiles_x ? 1 : 0;
+    dx = c ? v - a.tiles_x : v;
+    v = dy + gd_y + c;
+    c = v >= a.tiles_y ? 1 : 0;
+    dy = c ? v - a.tiles_y : v;
+    di = di + gd_i + c;
   };
 
   // ---- per-lane constants
@@ -129,21 +151,24 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   // hx = 16 ch + dxi + r15, i.e. (dxi + r15) & 7: the swizzle depends on the tap's dx only.
   unsigned a_lane[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) a_lane[d] = (unsigned)((d + r15) * 128 + ((q ^ ((d + r15) & 7)) << 4));
-  // B fragments: row rho = wc * (NW/2) + 16 b + r15 of each 32-column half, chunk (4 s + q) ^ (rho & 7)
+  for (int d = 0; d < 3; ++d) a_lane[d] = (unsigned)((d + r15) * 128 + ((q ^ ((d + r15) & 7)) << 4)) + (unsigned)((wm * RPW) * (HALO_PITCH * 128));
+  // B fragments: row rho = wc * 32 + 16 b + r15 of each 32-column half, chunk (4 s + q) ^ (rho & 7)
   // weight tile image: [n-half g][wave column wc][32 rows]: row = g * (WN * 32) + wc * 32 + 16 b + 4 qq + jj <-> n = wc NW + 32 g + 8 qq + 4 b + jj
   const unsigned b_lane = (unsigned)((wc * 32 + r15) * 128 + ((q ^ (r15 & 7)) << 4)) + (unsigned)HALO_WRING;
   constexpr int RG = WN * 32 * 128;            // bytes of one n-half of the weight tile
-  // weight pieces: piece pi = wave * PPW + j covers image rows 8 pi .. 8 pi + 7; lane -> row rho, chunk c
   const unsigned rowB = (unsigned)(9 * Ci * 2);
-  unsigned w_rel[PPW];
+  const int ci2 = Ci * 2;
+  // halo pieces: piece k (0..5) of this wave covers halo rows p = (8 k + wave) * 8 + lane / 8 = halo (row hy, column hx); per piece
+  // the row, the column (out of range past the image's end) and the source offset relative to the halo's first pixel
+  int hk_y[6], hk_x[6];
+  unsigned hk_c[6];
 #pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int rho = 8 * (wave * PPW + j) + (lane >> 3);
-    const int g_ = rho / (WN * 32), r_ = rho % (WN * 32);
-    const int wc_ = r_ >> 5, l = r_ & 31, b = l >> 4, qq = (l >> 2) & 3, jj = l & 3;
-    const int nrel = wc_ * NW + 32 * g_ + 8 * qq + 4 * b + jj;
-    w_rel[j] = (unsigned)nrel * rowB + (unsigned)((((lane & 7) ^ (rho & 7))) << 4);
+  for (int k = 0; k < 6; ++k) {
+    const int p = (k * 8 + wave) * 8 + (lane >> 3);
+    const int hy = p / HALO_PITCH, hx = p - hy * HALO_PITCH;
+    hk_y[k] = hy;
+    hk_x[k] = p < HALO_ROWS ? hx : 0x4000;
+    hk_c[k] = (unsigned)((hy * W + hx) * ci2) + (unsigned)((((lane ^ hx) & 7)) << 4);
   }
 
   // ---- stream states (wave-uniform).  The nine taps of a chunk are unrolled, so a step's tap, the weight stream's tap and the halo
@@ -151,93 +176,62 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   const int nchunks = my_tiles * KC;
   int c_k = 0, c_kc = 0;              // compute stream: tile ordinal and 64-channel chunk of the current chunk
   int c_hb = 0;                       // halo image the current chunk reads
-  bool tile_start = false;            // the current chunk is the first of a tile other than the first (the previous tile's last m-half is pending)
+  bool tile_start = false;            // the current chunk is the first of a tile other than the first (the previous tile's accumulators are pending)
   unsigned slot_off = 0;              // ring slot (byte offset) of the current step
   int w_k = 0, w_kc = 0, w_n0 = 0;    // weight stream (LEAD steps ahead): tile ordinal, chunk, first channel
   bool w_live = true;
   unsigned w_delta = 0;
-  int h_kc = 0;                       // halo stream = the chunk after the compute stream's
-  bool h_live = false;
-  int h_y1 = 0, h_x1 = 0;             // its tile origin - 1 (halo row / column 0)
-  int h_sbase = 0;                    // byte offset of (image, h_y1, h_x1, channel 64 h_kc); may be negative
+  int h_y1 = 0, h_x1 = 0;             // halo stream (= the chunk after the compute stream's): its tile's origin - 1 (halo row / column 0)
+  int h_sbase = 0;                    // byte offset of (image, h_y1, h_x1, channel 0); may be negative
+  unsigned h_soff = HALO_DEAD;        // h_sbase + 128 * chunk, or DEAD when the stream has run out (every piece then fills zeros)
   unsigned e_base = 0;                // epilogue parameters of the tile being multiplied
   bool e_xok0 = false, e_xok1 = false;
   int e_y0 = 0;
-  int n0_next = 0;                    // first output channel of the next tile (finished accumulators restart at its bias)
-  // values the issue segments of the current step use, prepared inside the previous step's last MFMA cluster
+  // values the issue segments of the current step use, prepared inside the previous step's MFMA cluster
   unsigned pa1 = 0, pb0 = 0, pb1 = 0, pw_off[PPW], ph_off = HALO_DEAD;
   unsigned pw_dst = 0, ph_dst = 0;
   bool in_loop = false;
-  const int ci2 = Ci * 2;
 
   auto w_soff = [&](int tap) __attribute__((always_inline)) -> unsigned {
     return (unsigned)(((w_n0 * 9 + tap) * Ci + w_kc * 64) * 2);
   };
-  auto tile_n0 = [&](int k) __attribute__((always_inline)) -> int {
-    return a.tiles_n > 1 ? ((first + k * G) % a.tiles_n) * BN : 0;
-  };
-  auto e_load = [&]() __attribute__((always_inline)) {   // epilogue addresses of tile c_k
-    int n0, x0, y0, img;
-    decode(first + c_k * G, n0, x0, y0, img);
+  auto e_load = [&]() __attribute__((always_inline)) {   // epilogue addresses of the tile being multiplied
+    const int x0 = ed_x * HALO_TW, y0 = ed_y * HALO_TH, n0 = ed_n * BN;
     e_y0 = y0;
     e_xok0 = x0 + r15 < W; e_xok1 = x0 + 16 + r15 < W;
-    e_base = ((unsigned)((img * H + y0 + wm * RPW) * W + x0 + r15) * (unsigned)a.ldc + (unsigned)(n0 + wc * NW + 8 * q)) * 2u;
+    e_base = ((unsigned)((ed_i * H + y0 + wm * RPW) * W + x0 + r15) * (unsigned)a.ldc + (unsigned)(n0 + wc * NW + 8 * q)) * 2u;
   };
-  // aim the halo stream at chunk (tile ordinal k, chunk kc)
-  auto h_aim = [&](int k, int kc, bool new_tile) __attribute__((always_inline)) {
-    h_live = k < my_tiles;
-    if (new_tile && h_live) {
-      int n0, x0, y0, img;
-      decode(first + k * G, n0, x0, y0, img);
-      h_y1 = y0 - 1; h_x1 = x0 - 1;
-      h_sbase = ((img * H + h_y1) * W + h_x1) * ci2;
-    }
-    h_kc = kc;
+  auto h_aim = [&]() __attribute__((always_inline)) {    // the halo stream has entered tile hd
+    h_y1 = hd_y * HALO_TH - 1; h_x1 = hd_x * HALO_TW - 1;
+    h_sbase = ((hd_i * H + h_y1) * W + h_x1) * ci2;
   };
-  // source offset of halo piece k of the halo stream's chunk (piece k of this wave covers halo rows p = (8 k + wave) * 8 + lane / 8);
-  // split in four parts so that each fits an MFMA gap
-  int hv_p = 0, hv_hy = 0, hv_hx = 0, hv_lin = 0;
-  bool hv_ok = false;
-  auto h_part = [&](int part, int k) __attribute__((always_inline)) {
-    if (part == 0) {
-      hv_p = (lane >> 3) + (k * 8 + wave) * 8;
-      hv_hy = (hv_p * 241) >> 13;                                  // p / 34 for p < 392
-    } else if (part == 1) {
-      hv_hx = hv_p - hv_hy * HALO_PITCH;
-      hv_lin = hv_hy * W + hv_hx;
-    } else if (part == 2) {
-      hv_ok = h_live && hv_p < HALO_ROWS && (unsigned)(h_y1 + hv_hy) < (unsigned)H && (unsigned)(h_x1 + hv_hx) < (unsigned)W;
-    } else {
-      const unsigned off = (unsigned)(hv_lin * ci2 + h_sbase + h_kc * 128) + (unsigned)((((lane ^ hv_hx) & 7)) << 4);
-      ph_off = hv_ok ? off : HALO_DEAD;
-    }
+  auto h_off = [&](int k) __attribute__((always_inline)) -> unsigned {   // source offset of halo piece k (all at once: prologue only)
+    const unsigned o = hk_c[k] + h_soff;
+    return ((unsigned)(hk_y[k] + h_y1) < (unsigned)H && (unsigned)(hk_x[k] + h_x1) < (unsigned)W) ? o : HALO_DEAD;
   };
 
   f32x4 acc[MB][NBW];
   bf16x8_t Af[8], Bf[2 * NBW];
-  // the accumulators of m-half h restart at the bias of tile n0 (so the epilogue adds nothing)
-  auto acc_init = [&](auto H_, int n0) __attribute__((always_inline)) {
-    constexpr int h = decltype(H_)::value;
+  // the accumulators restart at the bias of the tile whose first channel is n0 (so the epilogue adds nothing)
+  auto acc_init = [&](int n0) __attribute__((always_inline)) {
     const float* bl = reinterpret_cast<const float*>(smem + HALO_BIAS) + n0 + wc * NW + 8 * q;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
       // n-block nb = 2 v + b holds channels 32 v + 8 q + 4 b + (0..3) of the wave's range in its four D rows 4 q + (0..3)
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + 32 * (nb >> 1) + 4 * (nb & 1));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[4 * h + i][nb] = bv;
+      for (int i = 0; i < MB; ++i) acc[i][nb] = bv;
     }
   };
-  // ---- epilogue of m-half h: bf16, 16-byte stores (n-blocks 2v, 2v+1 hold 8 consecutive channels of a pixel)
-  auto epilogue = [&](auto H_) __attribute__((always_inline)) {
-    constexpr int h = decltype(H_)::value;
+  // ---- epilogue: bf16, 16-byte stores (n-blocks 2v, 2v+1 hold 8 consecutive channels of a pixel)
+  auto epilogue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int mi = 4 * h + i;
-      const int row = 2 * h + (i >> 1);                                    // tile row inside the wave's rows
-      const bool ok = ((i & 1) ? e_xok1 : e_xok0) && (e_y0 + wm * RPW + row < H);
+    for (int mi = 0; mi < MB; ++mi) {
+      const int row = mi >> 1;                                             // tile row inside the wave's rows
+      const bool ok = ((mi & 1) ? e_xok1 : e_xok0) && (e_y0 + wm * RPW + row < H);
 #pragma unroll
       for (int v = 0; v < NBW / 2; ++v) {
-        const unsigned off = e_base + (unsigned)(((row * W + 16 * (i & 1)) * a.ldc + v * 32) * 2);
+        const unsigned off = e_base + (unsigned)(((row * W + 16 * (mi & 1)) * a.ldc + v * 32) * 2);
         float ev[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ev[e] = acc[mi][2 * v][e]; ev[4 + e] = acc[mi][2 * v + 1][e]; }
@@ -250,191 +244,219 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
 
   // ---- prologue: bias -> LDS, halo image of chunk 0, weight steps 0 .. LEAD-1
   for (int i = tid; i < a.Co; i += 512) reinterpret_cast<float*>(smem + HALO_BIAS)[i] = a.bias ? a.bias[i] : 0.f;
-  w_n0 = tile_n0(0);
-  n0_next = my_tiles > 1 ? tile_n0(1) : 0;
+  w_n0 = wd_n * BN;
   e_load();
-  h_aim(0, 0, true);
+  h_aim();
+  h_soff = (unsigned)h_sbase;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int pc = k * 8 + wave;
-#pragma unroll
-    for (int part = 0; part < 4; ++part) h_part(part, k);
-    halo_dma16(xr, smem_base + (unsigned)((pc < HALO_PIECES ? pc : HALO_PIECES) * 1024), ph_off);
+    halo_dma16(xr, smem_base + (unsigned)((pc < HALO_PIECES ? pc : HALO_PIECES) * 1024), h_off(k));
   }
   static_assert(LEAD < 9, "the prologue's weight steps stay inside chunk 0");
-#pragma unroll
-  for (int s = 0; s < LEAD; ++s) {
-    const unsigned so = w_soff(s);
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) halo_dma16(wr, smem_base + (unsigned)(HALO_WRING + s * SLOT + (wave * PPW + j) * 1024), w_rel[j] + so);
-  }
-  // step 0's prepared values; the halo stream moves on to chunk 1
-  if (KC > 1) h_aim(0, 1, false); else h_aim(1, 0, true);
   {
+    // weight pieces: piece pi = wave * PPW + j covers image rows 8 pi .. 8 pi + 7; lane -> row rho, chunk c
+    unsigned w_rel[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int rho = 8 * (wave * PPW + j) + (lane >> 3);
+      const int g_ = rho / (WN * 32), r_ = rho % (WN * 32);
+      const int wc_ = r_ >> 5, l = r_ & 31, b = l >> 4, qq = (l >> 2) & 3, jj = l & 3;
+      const int nrel = wc_ * NW + 32 * g_ + 8 * qq + 4 * b + jj;
+      w_rel[j] = (unsigned)nrel * rowB + (unsigned)((((lane & 7) ^ (rho & 7))) << 4);
+    }
+#pragma unroll
+    for (int s = 0; s < LEAD; ++s) {
+      const unsigned so = w_soff(s);
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) halo_dma16(wr, smem_base + (unsigned)(HALO_WRING + s * SLOT + (wave * PPW + j) * 1024), w_rel[j] + so);
+    }
     const unsigned so = w_soff(LEAD);
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) pw_off[j] = w_rel[j] + so;
-    pw_dst = smem_base + (unsigned)(HALO_WRING + (LEAD & (NSLOT - 1)) * SLOT + wave * PPW * 1024);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) a_lane[d] += (unsigned)((wm * RPW) * (HALO_PITCH * 128));   // from here on: the read base in halo image c_hb
-    pa1 = a_lane[0] ^ 64u;
-    pb0 = b_lane; pb1 = pb0 ^ 64u;
+    for (int j = 0; j < PPW; ++j) pw_off[j] = w_rel[j] + so;     // (from here on the offsets move by scalar deltas)
   }
+  // the halo stream moves on to chunk 1; step 0's prepared values
+  if (KC > 1) {
+    h_soff = (unsigned)(h_sbase + 128);
+  } else if (my_tiles > 1) {
+    walk(hd_n, hd_x, hd_y, hd_i);
+    h_aim();
+    h_soff = (unsigned)h_sbase;
+  } else {
+    h_soff = HALO_DEAD;
+  }
+  pw_dst = smem_base + (unsigned)(HALO_WRING + (LEAD & (NSLOT - 1)) * SLOT + wave * PPW * 1024);
+  pa1 = a_lane[0] ^ 64u;
+  pb0 = b_lane; pb1 = pb0 ^ 64u;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  acc_init(std::integral_constant<int, 0>{}, tile_n0(0));
-  if constexpr (NPH == 2) acc_init(std::integral_constant<int, 1>{}, tile_n0(0));
+  acc_init(ed_n * BN);
   in_loop = true;
   if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier interval behind group 0
 
   unsigned long long st_sum0 = 0, st_sum1 = 0, st_sum2 = 0, st_sum3 = 0, st_n = 0;
 
-  // ---- one step = tap T of the current chunk.  What the NEXT step's issue segments need is formed in the gaps of this step's last
-  // MFMA cluster, a few instructions per gap (VALU / SALU between a wave's own MFMAs is nearly free; in the issue segment it
-  // competes with the partner wave's MFMAs and stretches the interval; a long block in ONE gap drains the matrix pipe).
+#define HALO_PIN_V(x) asm volatile("" : "+v"(x))
+#define HALO_PIN_S(x) asm volatile("" : "+s"(x))
+  // ---- one step = tap T of the current chunk.  What the NEXT step's issue segment needs is formed in the gaps of this step's MFMA
+  // cluster, one to three instructions per gap (VALU / SALU between a wave's own MFMAs is nearly free; in the issue segment it competes
+  // with the partner wave's MFMAs and stretches the interval; a long block in ONE gap drains the matrix pipe).  Every piece is pinned to
+  // its gap: its inputs and results pass through empty volatile asm statements, which the compiler keeps in order with the scheduling
+  // fences (sched_barrier alone pins machine instructions, not where the arithmetic is materialised).
   auto step = [&](auto T_) __attribute__((always_inline)) {
     constexpr int t = decltype(T_)::value;
     constexpr int dyi = t / 3, dxi = t % 3;
     constexpr int nt = (t + 1) % 9, ndxi = nt % 3;          // the next step's tap
     constexpr int nwt = (nt + LEAD) % 9;                     // the weight stream's tap during the next step
     constexpr bool nh = nt >= 1 && nt <= 6;                  // the next step issues halo piece nt - 1
-    auto hook = [&](int m) __attribute__((always_inline)) {  // gap after MFMA m of the step's LAST cluster
+    constexpr int hk = nh ? nt - 1 : 0;
+    int hv_y = 0, hv_x = 0;
+    unsigned hv_o = 0;
+    auto hook = [&](int m) __attribute__((always_inline)) {  // gap after MFMA m
       if (m == 0) {
+        HALO_PIN_S(slot_off);
         slot_off = (slot_off + (unsigned)SLOT) & (unsigned)(HALO_WRING_BYTES - 1);
+        HALO_PIN_S(slot_off);
+      }
+      if (m == 1) { pb0 = b_lane + slot_off; HALO_PIN_V(pb0); }
+      if (m == 2) { pb1 = pb0 ^ 64u; HALO_PIN_V(pb1); }
+      if (m == 3) {
         pw_dst = smem_base + (unsigned)HALO_WRING + ((slot_off + (unsigned)(LEAD * SLOT)) & (unsigned)(HALO_WRING_BYTES - 1)) + (unsigned)(wave * PPW * 1024);
+        HALO_PIN_S(pw_dst);
       }
-      if (m == 1) { pb0 = b_lane + slot_off; }
-      if (m == 2) { pb1 = pb0 ^ 64u; }
-      if constexpr (t == 8) {   // the compute stream enters the next chunk
-        if (m == 3) {
-          c_hb ^= 1;
-          if (++c_kc == KC) { c_kc = 0; ++c_k; tile_start = true; } else tile_start = false;
-        }
-        if (m == 4) {   // halo stream: the chunk after that
-          if (c_kc + 1 < KC) h_aim(c_k, c_kc + 1, false); else h_aim(c_k + 1, 0, true);
-        }
-        if (m == 5) {
-          const unsigned sa = c_hb ? (unsigned)HALO_BUF : (unsigned)-HALO_BUF;
-#pragma unroll
-          for (int d = 0; d < 3; ++d) a_lane[d] += sa;
-        }
-      }
-      if (m == 6) { pa1 = a_lane[ndxi] ^ 64u; }
       if constexpr (nwt == 0) {   // the weight stream enters its next chunk
-        if (m == 7) {   // scalar offset of (chunk, tap 0) minus that of (previous chunk, tap 8); a dead stream: everything out of range
+        if (m == 4) {   // scalar offset of (chunk, tap 0) minus that of (previous chunk, tap 8); a dead stream: everything out of range
+          HALO_PIN_S(w_kc);
           const unsigned so_old = w_soff(8);
           if (++w_kc == KC) {
             w_kc = 0;
             ++w_k;
-            if (w_k < my_tiles) { if (a.tiles_n > 1) w_n0 = tile_n0(w_k); } else w_live = false;
-          }
-          w_delta = w_soff(0) - so_old;
-        }
-        if (m == 8) {
-#pragma unroll
-          for (int j = 0; j < PPW; ++j) pw_off[j] = w_live ? pw_off[j] + w_delta : HALO_DEAD;
-        }
-      } else {
-        if (m == 8) {
-#pragma unroll
-          for (int j = 0; j < PPW; ++j) pw_off[j] += (unsigned)ci2;    // (a dead stream stays dead: DEAD + 8 tap strides does not wrap)
-        }
-      }
-      if constexpr (nh) {
-        if (m == 9) {
-          const int pc = (nt - 1) * 8 + wave;
-          ph_dst = smem_base + (unsigned)((c_hb ^ 1) * HALO_BUF + (pc < HALO_PIECES ? pc : HALO_PIECES) * 1024);
-        }
-        if (m == 10) h_part(0, nt - 1);
-        if (m == 11) h_part(1, nt - 1);
-        if (m == 12) h_part(2, nt - 1);
-        if (m == 13) h_part(3, nt - 1);
-      }
-    };
-    auto phase = [&](auto P_) __attribute__((always_inline)) {
-      constexpr int p = decltype(P_)::value;            // = the m-half this phase multiplies
-      constexpr bool lastp = p == NPH - 1;
-      unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
-      if constexpr (DBG == 5) tA = __builtin_amdgcn_s_memtime();
-      // ================= issue segment: fragment reads, LDS-DMA pieces, (rarely) a finished tile's stores
-      if constexpr (DBG != 2) {
-        if constexpr (p == 0) {
-#pragma unroll
-          for (int nb = 0; nb < NBW; ++nb) {
-            const int imm = (nb >> 1) * RG + (nb & 1) * 2048;
-            Bf[2 * nb] = *reinterpret_cast<const bf16x8_t*>(smem + pb0 + imm);
-            Bf[2 * nb + 1] = *reinterpret_cast<const bf16x8_t*>(smem + pb1 + imm);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int imm = (2 * p + (i >> 1) + dyi) * (HALO_PITCH * 128) + (i & 1) * 2048;
-          Af[2 * i] = *reinterpret_cast<const bf16x8_t*>(smem + a_lane[dxi] + imm);
-          Af[2 * i + 1] = *reinterpret_cast<const bf16x8_t*>(smem + pa1 + imm);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(DBG == 1 && in_loop)) {
-        if constexpr (lastp) {
-#pragma unroll
-          for (int j = 0; j < PPW; ++j) halo_dma16(wr, pw_dst + j * 1024, pw_off[j]);
-        }
-        if constexpr (p == 0 && t >= 1 && t <= 6) halo_dma16(xr, ph_dst, ph_off);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (p == 0 && t == 0) {
-        if (tile_start) {   // the previous tile's last m-half; its accumulators restart at this tile's bias
-          epilogue(std::integral_constant<int, NPH - 1>{});
-          acc_init(std::integral_constant<int, NPH - 1>{}, n0_next);
-        }
-      }
-      if constexpr (p == 1 && t == 8) {
-        if (c_kc == KC - 1) {    // the tile's last step: m-half 0 is complete
-          epilogue(std::integral_constant<int, 0>{});
-          acc_init(std::integral_constant<int, 0>{}, n0_next);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // the next step's weights have landed (this wave's pieces; the barrier publishes everyone's); this wave's reads have returned
-      if constexpr (lastp) halo_wait_vm<Cfg::VMW>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if constexpr (DBG == 5) tB = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DBG == 5) tC = __builtin_amdgcn_s_memtime();
-      // ================= MFMA segment
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int m = 0; m < NM; ++m) {
-        const int s = m / (4 * NBW), r = m % (4 * NBW), i = r / NBW, nb = r % NBW;
-        if constexpr (DBG != 3) {
-          acc[4 * p + i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[2 * nb + s], Af[2 * i + s], acc[4 * p + i][nb], 0, 0, 0);
-        } else {
-          asm volatile("" ::"v"(Af[2 * i + s]), "v"(Bf[2 * nb + s]));
-        }
-        if constexpr (p == 0 && t == 0) {
-          if (m == 14) {
-            if (tile_start) {   // a new tile has begun: its epilogue addresses, the first channel of the tile after it
-              n0_next = c_k + 1 < my_tiles ? tile_n0(c_k + 1) : 0;
-              e_load();
+            if (w_k < my_tiles) {
+              const int v = wd_n + gd_n;
+              wd_n = v >= a.tiles_n ? v - a.tiles_n : v;
+              w_n0 = wd_n * BN;
+            } else {
+              w_live = false;
             }
           }
+          w_delta = w_soff(0) - so_old;
+          HALO_PIN_S(w_delta);
         }
-        if constexpr (lastp) hook(m);
-        __builtin_amdgcn_sched_barrier(0);
+        if (m == 5) {
+#pragma unroll
+          for (int j = 0; j < PPW; ++j) { pw_off[j] = w_live ? pw_off[j] + w_delta : HALO_DEAD; HALO_PIN_V(pw_off[j]); }
+        }
+      } else {
+        if (m == 4) {
+#pragma unroll
+          for (int j = 0; j < PPW; ++j) { HALO_PIN_V(pw_off[j]); pw_off[j] += (unsigned)ci2; HALO_PIN_V(pw_off[j]); }   // (a dead stream stays dead: DEAD + 8 tap strides does not wrap)
+        }
       }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DBG == 5) tD = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      if constexpr (DBG == 5) {
-        const unsigned long long tE = __builtin_amdgcn_s_memtime();
-        st_sum0 += tB - tA; st_sum1 += tC - tB; st_sum2 += tD - tC; st_sum3 += tE - tD; st_n += 1;
+      if constexpr (nh) {   // the next step's halo piece
+        if (m == 7) {
+          const int pc = hk * 8 + wave;
+          ph_dst = smem_base + (unsigned)((c_hb ^ 1) * HALO_BUF + (pc < HALO_PIECES ? pc : HALO_PIECES) * 1024);
+          HALO_PIN_S(ph_dst);
+        }
+        if (m == 8) { hv_y = hk_y[hk] + h_y1; HALO_PIN_V(hv_y); }
+        if (m == 9) { hv_x = hk_x[hk] + h_x1; HALO_PIN_V(hv_x); }
+        if (m == 10) { hv_o = hk_c[hk] + h_soff; HALO_PIN_V(hv_o); }
+        if (m == 11) { hv_o = (unsigned)hv_y < (unsigned)H ? hv_o : HALO_DEAD; HALO_PIN_V(hv_o); }
+        if (m == 12) { ph_off = (unsigned)hv_x < (unsigned)W ? hv_o : HALO_DEAD; HALO_PIN_V(ph_off); }
+      }
+      if constexpr (t == 8) {   // the compute stream enters the next chunk; the halo stream the chunk after that
+        if (m == 7) {
+          HALO_PIN_S(c_kc);
+          c_hb ^= 1;
+          if (++c_kc == KC) { c_kc = 0; ++c_k; tile_start = true; walk(ed_n, ed_x, ed_y, ed_i); } else tile_start = false;
+          HALO_PIN_S(c_kc);
+        }
+        if (m == 8) {
+          const unsigned sa = c_hb ? (unsigned)HALO_BUF : (unsigned)-HALO_BUF;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { a_lane[d] += sa; HALO_PIN_V(a_lane[d]); }
+        }
+        if (m == 9) {
+          if (c_kc + 1 < KC) {
+            h_soff = c_k < my_tiles ? (unsigned)(h_sbase + (c_kc + 1) * 128) : HALO_DEAD;
+          } else if (c_k + 1 < my_tiles) {
+            walk(hd_n, hd_x, hd_y, hd_i);
+            h_aim();
+            h_soff = (unsigned)h_sbase;
+          } else {
+            h_soff = HALO_DEAD;
+          }
+          HALO_PIN_S(h_soff);
+        }
+      }
+      if (m == 14) { pa1 = a_lane[ndxi] ^ 64u; HALO_PIN_V(pa1); }   // (after the halo image switch of t == 8)
+      if constexpr (t == 0) {   // a new tile has begun (its predecessor's stores left in the issue segment): its epilogue addresses
+        if (m == 13) { if (tile_start) e_load(); }
       }
     };
-    phase(std::integral_constant<int, 0>{});
-    if constexpr (NPH == 2) phase(std::integral_constant<int, 1>{});
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+    if constexpr (DBG == 5) tA = __builtin_amdgcn_s_memtime();
+    // ================= issue segment: fragment reads, LDS-DMA pieces, (at a tile's first step) the previous tile's stores
+    if constexpr (DBG != 2) {
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const int imm = (nb >> 1) * RG + (nb & 1) * 2048;
+        Bf[2 * nb] = *reinterpret_cast<const bf16x8_t*>(smem + pb0 + imm);
+        Bf[2 * nb + 1] = *reinterpret_cast<const bf16x8_t*>(smem + pb1 + imm);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int imm = ((i >> 1) + dyi) * (HALO_PITCH * 128) + (i & 1) * 2048;
+        Af[2 * i] = *reinterpret_cast<const bf16x8_t*>(smem + a_lane[dxi] + imm);
+        Af[2 * i + 1] = *reinterpret_cast<const bf16x8_t*>(smem + pa1 + imm);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DBG == 1 && in_loop)) {
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) halo_dma16(wr, pw_dst + j * 1024, pw_off[j]);
+      if constexpr (t >= 1 && t <= 6) halo_dma16(xr, ph_dst, ph_off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (t == 0) {
+      if (tile_start) {   // the previous tile is complete; the accumulators restart at this tile's bias (ed already holds this tile's digits, the epilogue addresses still the previous tile's)
+        epilogue();
+        acc_init(ed_n * BN);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next step's weights have landed (this wave's pieces; the barrier publishes everyone's); this wave's reads have returned.
+    // A chunk's last step also retires the next chunk's halo pieces: the youngest was issued in step 6, only the weight pieces of steps
+    // 7 and 8 are younger.
+    halo_wait_vm<(t == 8 && 2 * PPW < Cfg::VMW) ? 2 * PPW : Cfg::VMW>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (DBG == 5) tB = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG == 5) tC = __builtin_amdgcn_s_memtime();
+    // ================= MFMA segment
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int s = m / (MB * NBW), r = m % (MB * NBW), i = r / NBW, nb = r % NBW;
+      if constexpr (DBG != 3) {
+        acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[2 * nb + s], Af[2 * i + s], acc[i][nb], 0, 0, 0);
+      } else {
+        asm volatile("" ::"v"(Af[2 * i + s]), "v"(Bf[2 * nb + s]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      hook(m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG == 5) tD = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (DBG == 5) {
+      const unsigned long long tE = __builtin_amdgcn_s_memtime();
+      st_sum0 += tB - tA; st_sum1 += tC - tB; st_sum2 += tD - tC; st_sum3 += tE - tD; st_n += 1;
+    }
   };
   for (int ch = 0; ch < nchunks; ++ch) {
     step(std::integral_constant<int, 0>{});
@@ -447,8 +469,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
     step(std::integral_constant<int, 7>{});
     step(std::integral_constant<int, 8>{});
   }
-  // the last tile's last m-half (the epilogue parameters still describe that tile)
-  epilogue(std::integral_constant<int, NPH - 1>{});
+#undef HALO_PIN_V
+#undef HALO_PIN_S
+  // the last tile (the epilogue parameters still describe it)
+  epilogue();
   if (grp == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SPG_DEV_KERNELS
@@ -470,7 +494,18 @@ int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bia
   if (Ci % 64 != 0 || Co % 64 != 0 || Co > 512 || ldc % 8 != 0 || H < 1 || W < 1) return 1;
   const long M = (long)B * H * W;
   const long xb = M * Ci * 2L, wb = (long)Co * 9 * Ci * 2L, cb = ((M - 1) * ldc + Co) * 2L;
-  if (xb >= 0x7FFFFFF0L || wb >= 0x7FFFFFF0L || cb >= 0xFFFFFFF0L) return 1;
+  if (wb >= 0x7FFFFFF0L) return 1;
+  if (xb >= 0x7FFFFFF0L || cb >= 0xFFFFFFF0L) {   // operands beyond one buffer descriptor's reach (batch 64 inference): images are independent, launch them in groups
+    const long xi = (long)H * W * Ci * 2L, ci_ = (long)H * W * ldc * 2L;
+    const long per = std::min(0x7FFFFFF0L / xi, 0xFFFFFFF0L / ci_);
+    if (per < 1) return 1;
+    for (long b0 = 0; b0 < B; b0 += per) {
+      const int nb = (int)std::min(per, (long)B - b0);
+      const int rc = launch_conv3x3_halo((const char*)X + b0 * xi, Wp, (char*)C + b0 * ci_, bias, nb, H, W, Ci, Co, ldc, cus, force_bn + 1000 * dbg, s);
+      if (rc != SPG_OK) return rc;     // (1 cannot happen here: the first group decides)
+    }
+    return SPG_OK;
+  }
   const int tx = cdiv(W, HALO_TW), ty = cdiv(H, HALO_TH);
   const long sp_tiles = (long)B * tx * ty;
   // tile width: the widest that divides Co, unless a narrower one fills the CUs' rounds markedly better
@@ -479,7 +514,7 @@ int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bia
     const long t = sp_tiles * (Co / b);
     return (double)t / (double)((t + cus - 1) / cus * cus);
   };
-  if (bn == 128 && util(128) < 0.8 * util(64)) bn = 64;
+  if (bn == 128 && util(64) > 1.1 * util(128)) bn = 64;      // (measured: the 64-wide instance runs ~7 % behind at equal fill)
   if (force_bn == 128 || force_bn == 64) {
     if (Co % force_bn != 0) return 1;
     bn = force_bn;
