@@ -33,6 +33,9 @@ enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
         * needs nothing else from it) -- and its partner for the backward GEMM: C = acc * gelu_h (+ residual), gelu_h = that derivative */
        SPG_ACT_GELU_SAVE_GRAD = 3, SPG_ACT_MUL_H = 4 };
 
+/* ABI revision: bumped with every change of an exported signature.  Bindings must compare spg_version() with the SPG_ABI_VERSION they
+ * were written against and refuse to run on a mismatch (spegnet_amd/_lib.py does).  300 = round 3. */
+#define SPG_ABI_VERSION 300
 int spg_version(void);
 const char* spg_last_error(void);
 

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPG_LIBRARY") or os.path.join(_HERE, "libspegnet_hip.so")
 
 SPG_F32, SPG_BF16 = 0, 1
+ABI_VERSION = 300   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 ACT_GELU_SAVE_GRAD, ACT_MUL_H = 3, 4   # bf16: C2 = gelu'(pre) saved by the forward GEMM | C = acc * gelu_h in the backward GEMM
 
@@ -119,6 +120,10 @@ def load() -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH)
     lib.spg_last_error.restype = ctypes.c_char_p
     lib.spg_version.restype = _I
+    have = int(lib.spg_version())
+    if have != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} is ABI revision {have}, this binding was written for {ABI_VERSION}: a stale library would receive "
+                           "shifted arguments. Rebuild it (`python spegnet_amd/build.py --force`, or `--dev` for the tools/ library).")
     for name, (res, sig) in QUERIES.items():   # size queries: return a count, not a status
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = _CT[res], [_CT[c] for c in sig]

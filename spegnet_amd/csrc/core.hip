@@ -20,5 +20,7 @@ int check_launch(const char* what) {
 }
 }  // namespace spg
 
-extern "C" int spg_version(void) { return 100; }
+// bumped with every change of an exported signature; spegnet_amd/_lib.py refuses a library whose number differs from the one its
+// argument table was written for (a stale .so would receive shifted arguments)
+extern "C" int spg_version(void) { return SPG_ABI_VERSION; }
 extern "C" const char* spg_last_error(void) { return spg::g_err; }

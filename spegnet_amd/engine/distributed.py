@@ -28,8 +28,9 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL's resident all-reduce blocks and the persistent GEMM kernels (which fill a CU completely) would fight for CUs while a
         # collective overlaps the backward pass: RCCL is capped to 16 channels here and the trainer sizes the GEMM grids that run
-        # beside a collective to COMM_CU_BUDGET CUs (engine/trainer.py; the cu_budget argument of the GEMM entry points).  862 MB of fp32 gradients per step have
-        # > 20 ms of backward to hide in, so 16 channels are plenty.  A default only (set the variable to override).
+        # beside a collective to COMM_CU_BUDGET CUs (engine/trainer.py; the cu_budget argument of the GEMM entry points).  The step's
+        # gradients (431 MB as bf16, 862 MB as fp32: GradSync's payload type) have > 15 ms of backward to hide in, so 16 channels are plenty.
+        # Both numbers are defaults chosen without an 8-GPU measurement (none was available): set the variable to override.  A default only (set the variable to override).
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         # "nccl" IS RCCL on ROCm.  SPG_DIST_BACKEND=gloo exists only to rehearse the N>1 code path with several ranks on ONE GPU
         backend = os.environ.get("SPG_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
@@ -56,9 +57,10 @@ def make_buckets(unit_ends: List[int], bucket_elems: int) -> List[Tuple[int, int
 
 
 class GradSync:
-    """Gradient all-reduce over the flat arena.  Payload bf16 by default (431 MB instead of 862 MB per step over xGMI; the
-    sum of <= 8 ranks is formed in bf16 by RCCL, the fp32 gradient is rounded once going in and widened coming out); compress_bf16=False
-    keeps fp32 on the wire."""
+    """Gradient all-reduce over the flat arena.  compress_bf16=True sends bf16 (SURVEY 8(e): 431 MB instead of 862 MB per step over xGMI;
+    the sum of <= 8 ranks is formed in bf16 by RCCL, the fp32 gradient is rounded once going in and widened coming out); False keeps fp32
+    on the wire.  The Trainer chooses: `training.grad_allreduce_dtype` ('bf16' | 'fp32'), default = the compute dtype, so the fp32 parity
+    mode never rounds its gradients silently."""
 
     def __init__(self, grad_flat: torch.Tensor, unit_ends: List[int], bucket_mb: float = 48.0, group=None,
                  compress_bf16: bool = True):
@@ -85,6 +87,10 @@ class GradSync:
             s, e = self.buckets[self._next]
             self._next += 1
             self._launch(s, e)
+
+    def drop_staging(self):
+        """Frees the bf16 staging buffers (a warm-up that reduced the whole arena at once leaves a 431 MB one the segmented replay never uses)."""
+        self._tmp = {}
 
     def reduce_range(self, s: int, e: int):
         """all-reduce (sum) of g[s:e] on the CURRENT stream; bf16 payload through a persistent staging buffer (HIP cast kernels)"""

@@ -151,6 +151,8 @@ class TrainStep:
             t.copy_(c)
         eng.pack()
         torch.cuda.synchronize()
+        if self.sync is not None:
+            self.sync.drop_staging()     # the warm-up reduced the arena in one piece: its staging buffer is never used again
         self.comm_stream = torch.cuda.Stream()
         self.segments = []
         # CU budget per segment (grid sizes are frozen at capture): the first segment and the optimizer run with no collective in
@@ -265,6 +267,14 @@ class TrainStep:
         return self.losses
 
 
+def _rank() -> int:
+    return torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+
+
+def _world() -> int:
+    return torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+
+
 class TrainingMonitor:
     """Running means + best-model bookkeeping (reference engine/trainer.py:42-199, JSON written atomically)."""
 
@@ -280,19 +290,35 @@ class TrainingMonitor:
             self._sums[k] = self._sums.get(k, 0.0) + float(v) * n
         self._n += n
 
-    def check_best_model(self, metrics: Dict[str, float], key: str = "s_alpha") -> bool:
-        """True when the structure measure improved as well (reference engine/trainer.py:156-183 keeps the best S_alpha)."""
-        v = float(metrics.get(key, metrics.get("weighted_f", -metrics.get("loss", 0.0))))
+    def check_best_model(self, metrics: Dict[str, float], key: str = "weighted_f") -> bool:
+        """True when `key` improved.  The default is the SAME quantity Trainer.train gates early stopping and the plateau scheduler on
+        (weighted F-measure, -loss when validation does not compute it), so "best checkpoint" and "epochs without improvement" cannot
+        disagree (the reference tracks weighted_f for both, engine/trainer.py:559-579)."""
+        v = float(metrics[key]) if key in metrics else -float(metrics.get("loss", 0.0))
         if v > self.best:
             self.best = v
             return True
         return False
 
+    def all_reduce(self, device):
+        """Sums the running totals over the ranks (each rank saw its own shard): every rank then holds the job-wide means, so the
+        scheduler / early-stop / best-checkpoint decisions taken from them are identical everywhere."""
+        if _world() == 1 or not self._sums:
+            return
+        keys = sorted(self._sums)
+        t = torch.tensor([self._sums[k] for k in keys] + [float(self._n)], dtype=torch.float64, device=device)
+        if t.is_cuda and torch.distributed.get_backend() == "gloo":
+            t = t.cpu()
+        torch.distributed.all_reduce(t)
+        t = t.cpu()
+        self._sums = {k: float(v) for k, v in zip(keys, t[:-1])}
+        self._n = int(round(float(t[-1])))
+
     def end_epoch(self, epoch: int, phase: str) -> Dict[str, float]:
         m = {k: v / max(self._n, 1) for k, v in self._sums.items()}
         self.history.append({"epoch": epoch, "phase": phase, **m})
         self._sums, self._n = {}, 0
-        if self.dir_manager is not None and hasattr(self.dir_manager, "run_dir"):
+        if self.dir_manager is not None and hasattr(self.dir_manager, "run_dir") and _rank() == 0:   # one writer per job
             os.makedirs(str(self.dir_manager.run_dir), exist_ok=True)
             path = os.path.join(str(self.dir_manager.run_dir), "metrics.json")
             tmp = path + ".tmp"
@@ -321,7 +347,12 @@ class Trainer:
         self.monitor = TrainingMonitor(dir_manager)
         self.sync = None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            self.sync = GradSync(self.arena.g, self.arena.unit_ends)
+            # payload type of the gradient all-reduce: the compute dtype unless `training.grad_allreduce_dtype` says otherwise (fp32
+            # parity mode must not round its gradients to bf16 on the wire)
+            wire = str(self.config.get('grad_allreduce_dtype', self.model_config['compute_dtype'])).lower()
+            if wire not in ('bf16', 'fp32'):
+                raise ValueError(f"training.grad_allreduce_dtype must be 'bf16' or 'fp32', got {wire!r}")
+            self.sync = GradSync(self.arena.g, self.arena.unit_ends, compress_bf16=(wire == 'bf16'))
         self.step_fn = TrainStep(self.model, self.criterion, self.arena, self.grad_clip, self.sync,
                                  capture=bool(self.config.get('capture_graph', False)))
         self._plateau_best, self._plateau_bad = -float("inf"), 0
@@ -412,6 +443,7 @@ class Trainer:
         for batch in loader:
             metrics, _ = self._process_batch(batch, is_train=True)
             self.monitor.update_batch(metrics, len(batch['masks']))
+        self.monitor.all_reduce(self.device)
         return self.monitor.end_epoch(epoch, "train")
 
     @torch.no_grad()
@@ -420,6 +452,7 @@ class Trainer:
         for batch in loader:
             metrics, _ = self._process_batch(batch, is_train=False)
             self.monitor.update_batch(metrics, len(batch['masks']))
+        self.monitor.all_reduce(self.device)     # the validation set is sharded over the ranks: the score below is the job-wide mean
         return self.monitor.end_epoch(-1, "val")
 
     def _loaders(self, dataset_dirs: Sequence[str]):
@@ -427,15 +460,22 @@ class Trainer:
         `training.use_host_loader: true` -- the host tree's utils.data_loader when the package is dropped into the reference checkout."""
         kw = dict(dataset_dirs=list(dataset_dirs), model_config=self.model_config, batch_size=self.batch_size,
                   num_workers=self.config.get('num_workers', 8), val_ratio=self.config.get('val_ratio', 0.1))
+        world = _world()
         if self.config.get('use_host_loader', False):
             try:
                 from utils.data_loader import get_training_loaders as host_loaders   # the reference's module (utils/data_loader.py:214-314)
             except ImportError as e:
                 raise ImportError("training.use_host_loader is set but `utils.data_loader` is not importable: run from the reference "
                                   "checkout (its utils/ on sys.path) or unset the flag to use spegnet_amd.utils.data_loader") from e
+            if world > 1:
+                raise RuntimeError("training.use_host_loader: the reference's loader is single-GPU (no sampler sharding, "
+                                   "utils/data_loader.py:287-301); multi-GPU runs need spegnet_amd.utils.data_loader")
             return host_loaders(**kw)
         from ..utils.data_loader import get_training_loaders
-        return get_training_loaders(device_preprocess=bool(self.config.get('device_preprocess', False)), **kw)
+        # one shard of the training / validation sets per rank; graph mode (and any multi-GPU run) drops the ragged last batch so that
+        # every rank issues the same number of steps and collectives
+        return get_training_loaders(device_preprocess=bool(self.config.get('device_preprocess', False)), rank=_rank(), world=world,
+                                    drop_last=bool(self.config.get('drop_last', world > 1 or self.step_fn.capture)), **kw)
 
     def _batches(self, loader):
         """batches one step ahead of the compute stream (pinned H2D + batched device preprocessing on a copy stream)"""
@@ -453,10 +493,14 @@ class Trainer:
         driven by the validation weighted F-measure when validation computes it (Evaluator metrics), by -loss otherwise."""
         train_loader, val_loader = self._loaders(dataset_dirs)
         logger.info("Training samples: %d", len(train_loader.dataset))
-        best, bad = 0.0, 0
+        best, bad = getattr(self, "_resume_best", 0.0), getattr(self, "_resume_bad", 0)   # (restored by resume())
         min_delta = self.config.get('min_delta', 1e-4)
         start = getattr(self, "_start_epoch", 0)
         for epoch in range(start, self.num_epochs):
+            for ld in (train_loader, val_loader):
+                if ld is not None and hasattr(getattr(ld, "sampler", None), "set_epoch"):
+                    ld.sampler.set_epoch(epoch)       # DistributedSampler: a new permutation per epoch, the same on every rank
+            self._epoch_state = (best, bad)
             tr = self.train_epoch(self._batches(train_loader), epoch)
             va = tr
             if val_loader is not None:
@@ -469,6 +513,7 @@ class Trainer:
                         self._save_checkpoint(epoch, va, is_best=True)
                 else:
                     bad += 1
+                self._epoch_state = (best, bad)
                 if bad >= self.early_stop_patience:
                     logger.info("Early stopping triggered")
                     break
@@ -484,6 +529,10 @@ class Trainer:
         self.arena.load_state_dict(ckpt['optimizer_state_dict'])
         sch = ckpt.get('scheduler_state_dict') or {}
         self._plateau_best, self._plateau_bad = sch.get('best', self._plateau_best), sch.get('bad', self._plateau_bad)
+        # early-stop / best-checkpoint bookkeeping: without it the first validated epoch after a resume would overwrite model_best.pth
+        # with a possibly worse model and restart the patience counter
+        self._resume_best, self._resume_bad = sch.get('early_stop_best', 0.0), sch.get('early_stop_bad', 0)
+        self.monitor.best = sch.get('monitor_best', self.monitor.best)
         self.model.mark_params_changed()
         self._start_epoch = int(ckpt.get('epoch', -1)) + 1
         return self._start_epoch
@@ -491,9 +540,13 @@ class Trainer:
     def _save_checkpoint(self, epoch: int, metrics: Dict, is_best: bool = False):
         """Same checkpoint schema as reference engine/trainer.py:588-606 (model_state_dict + config are what
         Predictor / main.py read back)."""
+        if _rank() != 0:      # ranks hold identical parameters / optimizer state after every step: one writer per job
+            return
+        es_best, es_bad = getattr(self, "_epoch_state", (0.0, 0))
         ckpt = {'epoch': epoch, 'model_state_dict': {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
                 'optimizer_state_dict': {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.arena.state_dict().items()},
-                'scheduler_state_dict': dict(self._sched, best=self._plateau_best, bad=self._plateau_bad), 'scaler': None,
+                'scheduler_state_dict': dict(self._sched, best=self._plateau_best, bad=self._plateau_bad, early_stop_best=es_best,
+                                             early_stop_bad=es_bad, monitor_best=self.monitor.best), 'scaler': None,
                 'metrics': metrics, 'config': {'training': self.config, 'model': self.model_config}}
         d = str(getattr(self.dir_manager, "checkpoint_dir", getattr(self.dir_manager, "run_dir", ".")))
         os.makedirs(d, exist_ok=True)

@@ -95,23 +95,33 @@ def _processor_params(model_config: Dict) -> Dict:
     return {'target_size': ip['target_size'], 'normalize_mean': tuple(ip['normalize_mean']), 'normalize_std': tuple(ip['normalize_std'])}
 
 
-def _loader(ds, batch_size, shuffle, num_workers) -> DataLoader:
-    return DataLoader(ds, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers, collate_fn=collate_fn,
-                      pin_memory=torch.cuda.is_available(), persistent_workers=num_workers > 0)
+def _loader(ds, batch_size, shuffle, num_workers, rank: int = 0, world: int = 1, drop_last: bool = False) -> DataLoader:
+    """world > 1: each rank iterates its own shard (DistributedSampler: the reference's loader, utils/data_loader.py:287-301, is
+    single-GPU; this is SURVEY 8(e)'s addition to it).  The caller calls `loader.sampler.set_epoch(epoch)` once per epoch."""
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=42, drop_last=drop_last)
+        shuffle = False
+    return DataLoader(ds, batch_size=batch_size, shuffle=shuffle, sampler=sampler, num_workers=num_workers, collate_fn=collate_fn,
+                      pin_memory=torch.cuda.is_available(), persistent_workers=num_workers > 0, drop_last=drop_last)
 
 
 def get_training_loaders(dataset_dirs: List[str], model_config: Dict, batch_size: int = 16, num_workers: int = 4, val_ratio: float = 0.1,
-                         device: str = 'cuda', device_preprocess: bool = False) -> Tuple[DataLoader, Optional[DataLoader]]:
+                         device: str = 'cuda', device_preprocess: bool = False, rank: int = 0, world: int = 1,
+                         drop_last: bool = False) -> Tuple[DataLoader, Optional[DataLoader]]:
+    """rank / world: this process's shard of both splits (the 90/10 split itself is seeded and identical on every rank).  drop_last
+    applies to the TRAINING loader only (fixed-shape captured steps, equal step counts across ranks)."""
     params = _processor_params(model_config)
     sets = [CODDataset(os.path.join(d, 'train'), params, True, device_preprocess) for d in dataset_dirs if os.path.exists(os.path.join(d, 'train'))]
     if not sets:
         raise ValueError("No valid training datasets found")
     full = ConcatDataset(sets)
     if val_ratio <= 0:
-        return _loader(full, batch_size, True, num_workers), None
+        return _loader(full, batch_size, True, num_workers, rank, world, drop_last), None
     n_train = int((1 - val_ratio) * len(full))
     tr, va = torch.utils.data.random_split(full, [n_train, len(full) - n_train], generator=torch.Generator().manual_seed(42))
-    return _loader(tr, batch_size, True, num_workers), _loader(va, batch_size, False, num_workers)
+    return _loader(tr, batch_size, True, num_workers, rank, world, drop_last), _loader(va, batch_size, False, num_workers, rank, world, False)
 
 
 def get_test_loaders(dataset_dirs: List[str], model_config: Dict, batch_size: int = 16, num_workers: int = 4,
@@ -196,10 +206,19 @@ def prefetch(loader, batcher: Optional[DeviceBatcher], device) -> Iterator[Dict]
         return b, ev
 
     def finish(b, ev):
-        torch.cuda.current_stream(device).wait_event(ev)
+        cur_stream = torch.cuda.current_stream(device)
+        cur_stream.wait_event(ev)
         pending = b.pop('_images_pending', None)
         if pending is not None:
             b['images'] = batcher.result(pending)
+        else:
+            b['images'].record_stream(cur_stream)
+        # the tensors were allocated on the copy stream's pool but are read on the compute stream: tell the allocator, or their blocks
+        # could be handed to the upload of batch k+2 while kernels reading batch k are still queued
+        for k in ('masks', 'edges'):
+            for t in b.get(k, ()):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur_stream)
         return b
 
     it = iter(loader)

@@ -37,7 +37,7 @@ def test_library_builds_and_exports_header_symbols():
     g.build()
     from spegnet_amd import _lib
     lib = _lib.load()
-    assert lib.spg_version() >= 100
+    assert lib.spg_version() == _lib.ABI_VERSION
     decls = parse_header()
     assert len(decls) >= 30
     for name in decls:

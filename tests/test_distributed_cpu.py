@@ -130,3 +130,94 @@ def test_product_path_refuses_cpu_and_bad_shapes():
     import inspect, spegnet_amd.models.engine as E, spegnet_amd.models.spegnet as SP, spegnet_amd.ops as OP
     for mod in (E, SP, OP):
         assert "oracle" not in inspect.getsource(mod).replace("the CPU oracle", ""), f"{mod.__name__} must not touch oracle/"
+
+
+# ---- multi-GPU hygiene of the Trainer's host side (world 2 over gloo; the reference is single-GPU: utils/data_loader.py:287-301,
+# ---- engine/trainer.py:559-579 -- sharding, one writer per job and a job-wide validation score are SURVEY 8(e)'s additions) ----
+def _make_dataset(root, n=10, size=24):
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for sub in ("Imgs", "GT", "Edges"):
+        os.makedirs(os.path.join(root, "train", sub), exist_ok=True)
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 255, (size, size, 3), dtype=np.uint8)).save(os.path.join(root, "train", "Imgs", f"s{i:02d}.jpg"))
+        for sub in ("GT", "Edges"):
+            Image.fromarray((rng.random((size, size)) > 0.5).astype(np.uint8) * 255).save(os.path.join(root, "train", sub, f"s{i:02d}.png"))
+
+
+_MODEL_CFG = {"image_processing": {"target_size": 32, "normalize_mean": [0.485, 0.456, 0.406], "normalize_std": [0.229, 0.224, 0.225]}}
+
+
+def _shard_worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spegnet_amd.engine.trainer import TrainingMonitor, _rank, _world
+    from spegnet_amd.utils.data_loader import get_training_loaders
+    tr, va = get_training_loaders([root], _MODEL_CFG, batch_size=2, num_workers=0, val_ratio=0.2, rank=rank, world=world, drop_last=True)
+    seen = {}
+    for ep in (0, 1):
+        tr.sampler.set_epoch(ep)
+        seen[ep] = [tuple(b["images"].shape) + (float(b["images"].sum()),) for b in tr]
+    nval = sum(len(b["masks"]) for b in va)
+    # job-wide means: each rank contributes its own shard's sums
+    class DM:
+        run_dir = os.path.join(root, f"run")
+    mon = TrainingMonitor(DM())
+    mon.update_batch({"loss": torch.tensor(float(rank + 1))}, 3 + rank)
+    mon.all_reduce(torch.device("cpu"))
+    mean = mon.end_epoch(0, "val")["loss"]
+    q.put((rank, _rank(), _world(), seen, nval, mean, os.path.exists(os.path.join(DM.run_dir, "metrics.json"))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_loader_shards_and_monitor_reduces(tmp_path):
+    root = str(tmp_path / "ds")
+    _make_dataset(root, n=10)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+    (r0, rk0, w0, seen0, nv0, m0, f0), (r1, rk1, w1, seen1, nv1, m1, f1) = res
+    assert (rk0, rk1, w0, w1) == (0, 1, 2, 2)
+    # 8 training samples -> 4 per rank -> 2 full batches of 2 each, every batch full (drop_last), shards disjoint, epochs reshuffled
+    for ep in (0, 1):
+        assert len(seen0[ep]) == len(seen1[ep]) == 2 and all(s[0] == 2 for s in seen0[ep] + seen1[ep])
+        assert not ({s[-1] for s in seen0[ep]} & {s[-1] for s in seen1[ep]}), "ranks must not train on the same samples"
+    assert {s[-1] for s in seen0[0]} != {s[-1] for s in seen0[1]}, "set_epoch must change the permutation"
+    assert nv0 == nv1 == 1                                       # 2 validation samples, one per rank
+    want = (1.0 * 3 + 2.0 * 4) / 7.0
+    assert abs(m0 - want) < 1e-12 and abs(m1 - want) < 1e-12     # identical job-wide mean on both ranks
+    assert f0 or f1                                              # rank 0 wrote metrics.json ...
+    assert os.path.exists(os.path.join(root, "run", "metrics.json"))
+
+
+def test_monitor_best_key_is_the_early_stop_key():
+    from spegnet_amd.engine.trainer import TrainingMonitor
+    m = TrainingMonitor(None)
+    assert m.check_best_model({"weighted_f": 0.5, "s_alpha": 0.9})
+    assert not m.check_best_model({"weighted_f": 0.4, "s_alpha": 0.95})      # a better S_alpha alone is not "best"
+    assert m.check_best_model({"weighted_f": 0.6, "s_alpha": 0.1})
+    m2 = TrainingMonitor(None)
+    assert m2.check_best_model({"loss": 2.0}) and m2.check_best_model({"loss": 1.0}) and not m2.check_best_model({"loss": 1.5})
+
+
+def test_lib_refuses_a_stale_abi(monkeypatch):
+    import __graft_entry__ as g
+    g.build()
+    from spegnet_amd import _lib
+    lib = _lib.load()
+    assert lib.spg_version() == _lib.ABI_VERSION
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "spegnet_hip.h")).read()
+    assert int(re.search(r"#define\s+SPG_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.ABI_VERSION
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI revision"):
+        _lib.load()

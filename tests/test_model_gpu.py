@@ -247,6 +247,65 @@ def test_train_backward_bf16_gradients_close_to_oracle():
     assert rs[len(rs) // 2] < 0.6 and rs[-1] < 0.9, rep
 
 
+def test_trunk_backward_bf16_per_parameter_matches_fp32_oracle():
+    """Well-conditioned check of the bf16 backward kernels composed at Hiera-L shapes (gemm_nt v3 / pipe with the saved GELU derivative,
+    grouped wgrad, resident / tiled attention backward, LayerNorm backward, pooling, position embeddings): the trunk alone -- LayerNorm
+    only, no train-mode BatchNorm over a handful of samples -- driven by fixed upstream gradients on its four stage maps, against the
+    fp32 CPU oracle's gradients PER PARAMETER.  A wrong kernel moves the parameters downstream of it far outside these bounds; the
+    five worst parameters are printed."""
+    m, sd, cfg = make_model("large", "bf16", train=True)
+    B, S = 4, 128
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, 3, S, S, generator=g)
+    eng = m.engine
+    xg = x.cuda()
+    feats, tctx = eng.trunk_fwd(xg, True, True)            # NHWC, bf16
+    ws = [(torch.randn(f.shape, generator=g) * (f.shape[-1] ** -0.5)).to(torch.bfloat16) for f in feats]     # d(loss)/d(stage map i)
+    for p_ in m.parameters():
+        p_.grad = None
+    eng.trunk_bwd(tctx, [w.cuda() for w in ws])
+    torch.cuda.synchronize()
+    # oracle: loss = sum_i <stage map i, w_i>
+    osd = {k: v.clone() for k, v in sd.items()}
+    params = {k: v.requires_grad_(True) for k, v in osd.items() if not O.is_buffer_key(k) and k.startswith("encoder.")}
+    of = O.hiera_trunk(osd, x, cfg=cfg)                    # NCHW, fp32
+    loss = sum((f * w.float().permute(0, 3, 1, 2)).sum() for f, w in zip(of, ws))
+    grads = dict(zip(params.keys(), torch.autograd.grad(loss, list(params.values()), allow_unused=True)))
+    for a_, b_ in zip(feats, of):
+        assert rel_err(a_.float().permute(0, 3, 1, 2), b_) < 6e-2
+    gmax = max(float(v.abs().max()) for v in grads.values() if v is not None)
+    cos, rn = {}, {}
+    P = dict(m.named_parameters())
+    for k, r in grads.items():
+        if r is None or float(r.abs().max()) < 1e-3 * gmax:
+            continue
+        a_, b_ = P[k].grad.detach().cpu().double().flatten(), r.double().flatten()
+        cos[k] = float(torch.dot(a_, b_) / (a_.norm() * b_.norm()).clamp_min(1e-30))
+        rn[k] = float((a_ - b_).norm() / b_.norm())
+    cs, rs = sorted(cos.values()), sorted(rn.values())
+    worst = sorted(rn.items(), key=lambda kv: -kv[1])[:5]
+    rep = (f"{len(cs)} parameters: cosine min {cs[0]:.5f} p05 {cs[int(0.05 * len(cs))]:.5f} median {cs[len(cs) // 2]:.5f}; relative L2 "
+           f"median {rs[len(rs) // 2]:.4f} p95 {rs[int(0.95 * len(rs))]:.4f} max {rs[-1]:.4f}; worst 5 {[(k, round(v, 4), round(cos[k], 5)) for k, v in worst]}")
+    print("bf16 trunk gradients vs fp32 oracle:", rep)
+    # rounding accumulates with the distance from the driven outputs (a gradient of block 2 has passed through 45 bf16 blocks): report
+    # the relative error by block range; the parameters closest to the outputs carry the tightest bound
+    import re
+    by = {}
+    for k, v in rn.items():
+        mm = re.search(r"blocks\.(\d+)\.", k)
+        by.setdefault(min(int(mm.group(1)) // 12, 3) if mm else -1, []).append(v)
+    for b_ in sorted(by):
+        v = sorted(by[b_])
+        print(f"  blocks {'embeddings' if b_ < 0 else f'{12 * b_}-{12 * b_ + 11}'}: {len(v)} parameters, relative L2 median {v[len(v) // 2]:.4f} max {v[-1]:.4f}")
+    assert len(cs) > 500
+    assert cs[0] > 0.98 and cs[int(0.05 * len(cs))] > 0.99 and cs[len(cs) // 2] > 0.998, rep
+    assert rs[-1] < 0.2 and rs[len(rs) // 2] < 0.05, rep
+    last = sorted(by[3])
+    lw = sorted(((k, v) for k, v in rn.items() if re.search(r"blocks\.(3[6-9]|4\d)\.", k)), key=lambda kv: -kv[1])[:4]
+    print("  worst of blocks 36-47:", [(k, round(v, 4), round(cos[k], 5)) for k, v in lw])
+    assert last[len(last) // 2] < 0.03 and last[int(0.9 * len(last))] < 0.06 and last[-1] < 0.16, ("blocks 36-47", last[len(last) // 2], last[-1], lw)
+
+
 def test_config2_train_step_matches_oracle():
     """BASELINE config #2 at full size: batch 8 @384x384, bf16, hipGraph-captured step (what bench.py times).  Loss and global gradient
     norm of the first step against the fp32 CPU oracle on the same batch and weights (the oracle step takes ~30 s of CPU)."""
@@ -399,7 +458,7 @@ def test_high_res_768_train_step_runs():
     m.mark_params_changed()
     arena.set_hyper(1e-4, 1e-5, 0.05)
     step = TrainStep(m, CODLoss().cuda(), arena, grad_clip=1.0)
-    x, masks, edges = O.synthetic_batch(2, 768, seed=50)
+    x, masks, edges = O.synthetic_batch(4, 768, seed=50)       # config #5's per-GPU batch
     out = step(x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda())
     l0 = float(out["loss"])
     l1 = float(step(x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda())["loss"])
@@ -407,7 +466,53 @@ def test_high_res_768_train_step_runs():
     m.eval()
     with torch.no_grad():
         o = m(x.cuda())
-    assert o["predictions"][2].shape == (2, 1, 768, 768) and o["edge"].shape == (2, 1, 96, 96)
+    assert o["predictions"][2].shape == (4, 1, 768, 768) and o["edge"].shape == (4, 1, 96, 96)
+
+
+def test_high_res_768_forward_fp32_matches_oracle():
+    """768 x 768 against the CPU oracle (config #5's resolution: 192 / 96 / 48 / 24-token stage maps, 2304-token global attention,
+    PED up to 768 x 768): the fp32 parity mode within 1e-3 relative, masks as in the 384 px test."""
+    m, sd, cfg = make_model("large", "fp32", seed=3)
+    x = torch.randn(1, 3, 768, 768, generator=torch.Generator().manual_seed(51))
+    with torch.no_grad():
+        ref = O.spegnet_forward(sd, x, training=False, cfg=cfg)
+        out = m(x.cuda())
+    errs = cmp_outputs(out, ref, 1e-3, "large@768")
+    rep = mask_report(out["predictions"][2], ref["predictions"][2], "fp32 large@768")
+    assert rep["thr_diff_outside_band"] == 0 and rep["band_pixels"] < 0.01 * rep["pixels"]
+    assert rep["u8_max_step"] <= 1 and rep["u8_diff"] <= 0.002 * rep["pixels"], rep
+    print("rel errs @768 fp32:", errs)
+
+
+def test_config3_captured_batch64_forward_matches_oracle():
+    """BASELINE config #3 at full size: ONE hipGraph of the bf16 Hiera-L eval forward at batch 64 @384 x 384, replayed on fresh inputs;
+    two images of the batch are checked against the fp32 CPU oracle (bf16 tolerance), every output must be finite."""
+    m, sd, cfg = make_model("large", "bf16", seed=3)
+    g = torch.Generator().manual_seed(52)
+    x0 = torch.randn(64, 3, 384, 384, generator=g)
+    x1 = torch.randn(64, 3, 384, 384, generator=g)
+    static = x0.cuda()
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(static)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = m(static)
+        static.copy_(x1.cuda())          # the replay must compute from the NEW contents
+        graph.replay()
+        torch.cuda.synchronize()
+        for t in out["predictions"] + [out["edge"]]:
+            assert bool(torch.isfinite(t.float()).all())
+        for i in (5, 63):
+            ref = O.spegnet_forward(sd, x1[i:i + 1], training=False, cfg=cfg)
+            got = {"predictions": [p[i:i + 1] for p in out["predictions"]], "edge": out["edge"][i:i + 1],
+                   "features": {k: v[i:i + 1] for k, v in out["features"].items()}}
+            cmp_outputs(got, ref, 6e-2, f"bf16 large@384 image {i} of a captured batch of 64")
+            rep = mask_report(got["predictions"][2], ref["predictions"][2], f"bf16 captured batch 64, image {i}")
+            assert rep["thr_diff"] <= 0.02 * rep["pixels"], rep
 
 
 def test_segmented_graph_step_equals_eager_step():
