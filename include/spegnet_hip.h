@@ -35,7 +35,7 @@ enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
 
 /* ABI revision: bumped with every change of an exported signature.  Bindings must compare spg_version() with the SPG_ABI_VERSION they
  * were written against and refuse to run on a mismatch (spegnet_amd/_lib.py does).  300 = round 3. */
-#define SPG_ABI_VERSION 300
+#define SPG_ABI_VERSION 302
 int spg_version(void);
 const char* spg_last_error(void);
 
@@ -171,6 +171,19 @@ int spg_bn_stats(int dtype, const void* x, float* stats, long M, int C, float* r
 int spg_bn_stats_finalize(int dtype, const void* x, float* stats, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, long long* num_batches_tracked, float* scale_shift, float* mean_invstd, long M, int C,
                           float eps, float momentum, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
+/* ---- 3x3 convolution + BatchNorm batch statistics in one launch (bf16; the LDS-resident-input kernel of csrc/conv_halo.hip)
+ * Replaces nn.Conv2d(3x3, pad 1) followed by the statistics pass of the nn.BatchNorm2d behind it (reference
+ * models/object_detection.py:115-123, 193-199, 230-236).  C = conv(X) + bias as spg_gemm_nt(conv3x3=1) writes it (ldc = Co), and
+ * stats_part f32 [rows][2*Co]: partial sums and sums of squares of the ROUNDED outputs over disjoint pixel sets (one row per workgroup and
+ * wave row when Co is 64 or 128, per 8 x 32 pixel tile and wave row otherwise), every row written; cu_budget must match the launch's.
+ * rows = spg_conv3x3_stats_rows(...) (0: no instance for the shape -- use spg_gemm_nt + spg_bn_stats_finalize).
+ * spg_bn_stats_finalize_part sums the rows in a fixed order and finalises exactly as spg_bn_stats_finalize (M = B*H*W samples).      */
+long spg_conv3x3_stats_rows(int dtype, int B, int H, int Wd, int Ci, int Co, int cu_budget);
+int spg_conv3x3_fwd_stats(int dtype, const void* X, const void* Wp, void* C, const float* bias, float* stats_part, long part_rows,
+                          int B, int H, int Wd, int Ci, int Co, int cu_budget, spg_stream_t stream);
+int spg_bn_stats_finalize_part(const float* part, long R, float* stats, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float* scale_shift, float* mean_invstd, long M, int C,
+                               float eps, float momentum, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
 /* the same for FOUR BatchNorms of C/4 channels each over one [M, C] tensor (the e-ASPP branches stored branch-major in one tensor):
  * gamma4 ... num_batches_tracked4 are HOST arrays of 4 device pointers (running_* / num_batches_tracked arrays or entries may be NULL). */
 int spg_bn_stats_finalize4(int dtype, const void* x, float* stats, const float* const* gamma4, const float* const* beta4,

@@ -74,6 +74,7 @@ __device__ unsigned long long halo_stamps[256 * 8 * 6];   // DBG 5: per workgrou
 
 struct HaloArgs {
   const bf16_t* X; const bf16_t* Wp; bf16_t* C; const float* bias;
+  float* stats;       // STATS instances: per (spatial tile, wave row) partial [2][Co] = sum and sum of squares of the bf16 outputs
   int B, H, W, Ci, Co, ldc;
   int tiles_x, tiles_y, tiles_n, ntiles;
   unsigned xbytes, wbytes, cbytes;
@@ -81,7 +82,19 @@ struct HaloArgs {
 
 // DBG (dev builds, wrong results by construction): 1 no LDS-DMA in the loop, 2 no fragment reads, 3 no MFMAs, 4 no epilogue stores,
 // 5 in-kernel stamps (tools/halo_stamps.py)
-template <int BN, int DBG = 0>
+// STATS: the epilogue also forms the BatchNorm batch statistics of its tile (reference: nn.BatchNorm2d right behind every one of these
+// convolutions, models/object_detection.py:119,194,198): per wave the column sums / sums of squares of the ROUNDED outputs over its 64
+// pixels (in-lane over the four m-blocks, then a fixed 4-step DPP reduction over the 16 pixel lanes) go to row (spatial tile, wave row)
+// of a partial matrix; spg_bn_stats_finalize_part sums the rows in a fixed order and finalises -- no second pass over the output.
+__device__ __forceinline__ float halo_row_sum16(float v) {   // sum over the 16 lanes of a DPP row; the total lands in the row's lane 15
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+  return v;
+}
+
+template <int BN, int DBG = 0, bool STATS = false>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   using Cfg = HaloCfg<BN>;
   constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, NSLOT = Cfg::NSLOT, LEAD = Cfg::LEAD;
@@ -174,6 +187,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   // ---- stream states (wave-uniform).  The nine taps of a chunk are unrolled, so a step's tap, the weight stream's tap and the halo
   // piece it issues are compile-time constants; what remains at run time is chunk-level state, advanced once per nine steps.
   const int nchunks = my_tiles * KC;
+  const bool wg_stats = a.tiles_n == 1;   // STATS: one partial row per (workgroup, wave row) instead of per (tile, wave row)
   int c_k = 0, c_kc = 0;              // compute stream: tile ordinal and 64-channel chunk of the current chunk
   int c_hb = 0;                       // halo image the current chunk reads
   bool tile_start = false;            // the current chunk is the first of a tile other than the first (the previous tile's accumulators are pending)
@@ -187,6 +201,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   unsigned e_base = 0;                // epilogue parameters of the tile being multiplied
   bool e_xok0 = false, e_xok1 = false;
   int e_y0 = 0;
+  long e_prow = 0;                    // STATS: this wave's row of the partial-statistics matrix, as a float offset
   // values the issue segments of the current step use, prepared inside the previous step's MFMA cluster
   unsigned pa1 = 0, pb0 = 0, pb1 = 0, pw_off[PPW], ph_off = HALO_DEAD;
   unsigned pw_dst = 0, ph_dst = 0;
@@ -200,6 +215,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
     e_y0 = y0;
     e_xok0 = x0 + r15 < W; e_xok1 = x0 + 16 + r15 < W;
     e_base = ((unsigned)((ed_i * H + y0 + wm * RPW) * W + x0 + r15) * (unsigned)a.ldc + (unsigned)(n0 + wc * NW + 8 * q)) * 2u;
+    if constexpr (STATS) {
+      const long r_ = wg_stats ? (long)blockIdx.x : (long)((ed_i * a.tiles_y + ed_y) * a.tiles_x + ed_x);
+      e_prow = (r_ * WM + wm) * (2L * a.Co) + n0 + wc * NW + 8 * q;
+    }
   };
   auto h_aim = [&]() __attribute__((always_inline)) {    // the halo stream has entered tile hd
     h_y1 = hd_y * HALO_TH - 1; h_x1 = hd_x * HALO_TW - 1;
@@ -212,6 +231,38 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
 
   f32x4 acc[MB][NBW];
   bf16x8_t Af[8], Bf[2 * NBW];
+  // STATS: per-lane running sums / sums of squares of this lane's pixels for its 8 (NBW / 2) channels.  With one n-tile per pixel tile
+  // (tiles_n == 1) they run over ALL tiles of the workgroup and are reduced and stored once, at the end: one partial row per (workgroup,
+  // wave row); otherwise consecutive tiles cover different channels and every tile flushes its own row.
+  float ssum[STATS ? NBW / 2 : 1][8], ssq[STATS ? NBW / 2 : 1][8];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int v = 0; v < NBW / 2; ++v)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ssum[v][e] = 0.f; ssq[v][e] = 0.f; }
+  }
+  auto stats_flush = [&](long prow) __attribute__((always_inline)) {
+    if constexpr (STATS) {
+#pragma unroll
+      for (int v = 0; v < NBW / 2; ++v)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssum[v][e] = halo_row_sum16(ssum[v][e]); ssq[v][e] = halo_row_sum16(ssq[v][e]); }
+      if (r15 == 15) {
+#pragma unroll
+        for (int v = 0; v < NBW / 2; ++v) {
+          float* ps = a.stats + prow + v * 32;
+          *reinterpret_cast<f32x4*>(ps) = f32x4{ssum[v][0], ssum[v][1], ssum[v][2], ssum[v][3]};
+          *reinterpret_cast<f32x4*>(ps + 4) = f32x4{ssum[v][4], ssum[v][5], ssum[v][6], ssum[v][7]};
+          *reinterpret_cast<f32x4*>(ps + a.Co) = f32x4{ssq[v][0], ssq[v][1], ssq[v][2], ssq[v][3]};
+          *reinterpret_cast<f32x4*>(ps + a.Co + 4) = f32x4{ssq[v][4], ssq[v][5], ssq[v][6], ssq[v][7]};
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < NBW / 2; ++v)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssum[v][e] = 0.f; ssq[v][e] = 0.f; }
+    }
+  };
   // the accumulators restart at the bias of the tile whose first channel is n0 (so the epilogue adds nothing)
   auto acc_init = [&](int n0) __attribute__((always_inline)) {
     const float* bl = reinterpret_cast<const float*>(smem + HALO_BIAS) + n0 + wc * NW + 8 * q;
@@ -238,7 +289,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
         const u32x4 pk = pack16<bf16_t>(ev);
         if constexpr (DBG != 4) __builtin_amdgcn_raw_buffer_store_b128(hbufvec_t{pk.x, pk.y, pk.z, pk.w}, cr, ok ? off : 0xFFFFFFF0u, 0, 0);
         else asm volatile("" ::"v"(pk));
+        if constexpr (STATS) {   // statistics of what was stored (the rounded values: what BatchNorm will normalise)
+          float rv[8];
+          unpack16<bf16_t>(pk, rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x_ = ok ? rv[e] : 0.f;
+            ssum[v][e] += x_;
+            ssq[v][e] = __builtin_fmaf(x_, x_, ssq[v][e]);
+          }
+        }
       }
+    }
+    if constexpr (STATS) {
+      if (!wg_stats) stats_flush(e_prow);
     }
   };
 
@@ -473,6 +537,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
 #undef HALO_PIN_S
   // the last tile (the epilogue parameters still describe it)
   epilogue();
+  if constexpr (STATS) {
+    if (wg_stats) stats_flush(e_prow);
+  }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SPG_DEV_KERNELS
@@ -487,21 +554,23 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
 }
 
 // returns SPG_OK, an error, or 1 when the problem is outside this kernel's domain (the caller falls back to the implicit GEMM)
+// stats != nullptr: also writes the BatchNorm partial statistics (conv3x3_halo_stats_rows() rows of 2 Co floats, every row written)
 int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bias, int B, int H, int W, int Ci, int Co, int ldc,
-                        int cus, int force_bn, hipStream_t s) {
+                        int cus, int force_bn, hipStream_t s, float* stats) {
   const int dbg = force_bn / 1000;
   force_bn %= 1000;
   if (Ci % 64 != 0 || Co % 64 != 0 || Co > 512 || ldc % 8 != 0 || H < 1 || W < 1) return 1;
   const long M = (long)B * H * W;
   const long xb = M * Ci * 2L, wb = (long)Co * 9 * Ci * 2L, cb = ((M - 1) * ldc + Co) * 2L;
   if (wb >= 0x7FFFFFF0L) return 1;
+  if (stats && (xb >= 0x7FFFFFF0L || cb >= 0xFFFFFFF0L)) return 1;
   if (xb >= 0x7FFFFFF0L || cb >= 0xFFFFFFF0L) {   // operands beyond one buffer descriptor's reach (batch 64 inference): images are independent, launch them in groups
     const long xi = (long)H * W * Ci * 2L, ci_ = (long)H * W * ldc * 2L;
     const long per = std::min(0x7FFFFFF0L / xi, 0xFFFFFFF0L / ci_);
     if (per < 1) return 1;
     for (long b0 = 0; b0 < B; b0 += per) {
       const int nb = (int)std::min(per, (long)B - b0);
-      const int rc = launch_conv3x3_halo((const char*)X + b0 * xi, Wp, (char*)C + b0 * ci_, bias, nb, H, W, Ci, Co, ldc, cus, force_bn + 1000 * dbg, s);
+      const int rc = launch_conv3x3_halo((const char*)X + b0 * xi, Wp, (char*)C + b0 * ci_, bias, nb, H, W, Ci, Co, ldc, cus, force_bn + 1000 * dbg, s, nullptr);
       if (rc != SPG_OK) return rc;     // (1 cannot happen here: the first group decides)
     }
     return SPG_OK;
@@ -515,12 +584,13 @@ int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bia
     return (double)t / (double)((t + cus - 1) / cus * cus);
   };
   if (bn == 128 && util(64) > 1.1 * util(128)) bn = 64;      // (measured: the 64-wide instance runs ~7 % behind at equal fill)
+  if (stats && Co == 128) bn = 128;                            // one n-tile: the statistics stay in registers across the workgroup's tiles
   if (force_bn == 128 || force_bn == 64) {
     if (Co % force_bn != 0) return 1;
     bn = force_bn;
   }
   HaloArgs a;
-  a.X = (const bf16_t*)X; a.Wp = (const bf16_t*)Wp; a.C = (bf16_t*)C; a.bias = bias;
+  a.X = (const bf16_t*)X; a.Wp = (const bf16_t*)Wp; a.C = (bf16_t*)C; a.bias = bias; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.ldc = ldc;
   a.tiles_x = tx; a.tiles_y = ty; a.tiles_n = Co / bn;
   const long nt = sp_tiles * a.tiles_n;
@@ -528,20 +598,20 @@ int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bia
   a.ntiles = (int)nt;
   a.xbytes = (unsigned)xb; a.wbytes = (unsigned)wb; a.cbytes = (unsigned)cb;
   const int grid = a.ntiles < cus ? a.ntiles : cus;
-#define SPG_HALO_LAUNCH(BN_, D_)                                                                                                    \
+#define SPG_HALO_LAUNCH(BN_, D_, S_)                                                                                                \
   do {                                                                                                                              \
     static bool attr_ = false;                                                                                                      \
     if (!attr_) {                                                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                HALO_LDS_BYTES);                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN_, D_, S_>),                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS_BYTES);                                        \
       attr_ = true;                                                                                                                 \
     }                                                                                                                               \
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, D_>), dim3(grid), dim3(512), HALO_LDS_BYTES, s, a);                               \
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, D_, S_>), dim3(grid), dim3(512), HALO_LDS_BYTES, s, a);                           \
   } while (0)
-#define SPG_HALO_LAUNCH_BN(D_)                   \
-  do {                                           \
-    if (bn == 128) SPG_HALO_LAUNCH(128, D_);     \
-    else SPG_HALO_LAUNCH(64, D_);                \
+#define SPG_HALO_LAUNCH_BN(D_)                                                              \
+  do {                                                                                      \
+    if (bn == 128) { if (stats) SPG_HALO_LAUNCH(128, D_, true); else SPG_HALO_LAUNCH(128, D_, false); } \
+    else { if (stats) SPG_HALO_LAUNCH(64, D_, true); else SPG_HALO_LAUNCH(64, D_, false); }  \
   } while (0)
 #ifdef SPG_DEV_KERNELS
   if (dbg == 1) SPG_HALO_LAUNCH_BN(1);
@@ -558,7 +628,44 @@ int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bia
   return check_launch("conv3x3_halo");
 }
 
+// rows of the partial-statistics matrix a STATS launch writes (0: the problem is outside the kernel's domain)
+long conv3x3_halo_stats_rows(int B, int H, int W, int Ci, int Co, int ldc, int cus) {
+  if (Ci % 64 != 0 || Co % 64 != 0 || Co > 512 || ldc % 8 != 0 || H < 1 || W < 1) return 0;
+  const long M = (long)B * H * W;
+  if ((long)Co * 9 * Ci * 2L >= 0x7FFFFFF0L) return 0;
+  if (M * Ci * 2L >= 0x7FFFFFF0L || ((M - 1) * ldc + Co) * 2L >= 0xFFFFFFF0L) return 0;   // (image groups: training batches stay below)
+  const long sp = (long)B * cdiv(W, HALO_TW) * cdiv(H, HALO_TH);
+  if (Co == 64 || Co == 128) return 4L * (sp < cus ? sp : cus);      // one n-tile: a row per (workgroup, wave row)
+  return sp * 4L;                                                    // a row per (pixel tile, wave row)
+}
+
 }  // namespace spg
+
+using namespace spg;
+// ---- C ABI: bf16 3x3 convolution + BatchNorm partial statistics in one launch (include/spegnet_hip.h)
+static int halo_cus(int cu_budget) {
+  static int hw = 0;
+  if (hw == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    hw = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return (cu_budget >= 8 && cu_budget < hw) ? cu_budget : hw;
+}
+extern "C" long spg_conv3x3_stats_rows(int dtype, int B, int H, int Wd, int Ci, int Co, int cu_budget) {
+  return dtype == SPG_BF16 ? conv3x3_halo_stats_rows(B, H, Wd, Ci, Co, Co, halo_cus(cu_budget)) : 0;
+}
+extern "C" int spg_conv3x3_fwd_stats(int dtype, const void* X, const void* Wp, void* C, const float* bias, float* stats_part,
+                                     long part_rows, int B, int H, int Wd, int Ci, int Co, int cu_budget, spg_stream_t stream) {
+  SPG_REQUIRE(dtype == SPG_BF16, "conv3x3_fwd_stats: bf16 only (dtype %d)", dtype);
+  const int cus = halo_cus(cu_budget);
+  const long rows = conv3x3_halo_stats_rows(B, H, Wd, Ci, Co, Co, cus);
+  SPG_REQUIRE(rows > 0, "conv3x3_fwd_stats: no instance for B=%d H=%d W=%d Ci=%d Co=%d (ask spg_conv3x3_stats_rows first)", B, H, Wd, Ci, Co);
+  SPG_REQUIRE(stats_part != nullptr && part_rows == rows, "conv3x3_fwd_stats: the partial matrix must have %ld rows of 2*Co floats, got %ld", rows, part_rows);
+  const int rc = launch_conv3x3_halo(X, Wp, C, bias, B, H, Wd, Ci, Co, Co, cus, 0, (hipStream_t)stream, stats_part);
+  if (rc == 1) { set_error("conv3x3_fwd_stats: problem outside the halo kernel's domain"); return SPG_ERR_UNSUPPORTED; }
+  return rc;
+}
 
 #ifdef SPG_DEV_KERNELS
 extern "C" int spg_dev_halo_stamps(unsigned long long* out) {   // 256 workgroups x 8 waves x 6 (SPG_CONV_HALO_DBG=5)

@@ -63,7 +63,7 @@ struct ConvGeom {
 };
 // conv_halo.hip: bf16 3x3 convolution with an LDS-resident input tile; returns 1 when the problem is outside its domain
 int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bias, int B, int H, int W, int Ci, int Co, int ldc,
-                        int cus, int force_bn, hipStream_t s);
+                        int cus, int force_bn, hipStream_t s, float* stats);
 
 // Branch-free operand loads: raw buffer loads with hardware bounds checking (out-of-range offsets return 0), so
 // hipcc keeps every load of a K-tile in flight behind a counted vmcnt instead of branching around each one
@@ -3288,7 +3288,7 @@ static int try_conv_halo(const void* X, const void* W, void* C, const NtEpi& epi
   static const int dbg = dev_env("SPG_CONV_HALO_DBG", 0);   // ablation instances of conv_halo.hip (1 no DMA, 2 no reads, 3 no MFMAs, 4 no stores)
   force = (mode == 1 ? 0 : mode) + 1000 * dbg;
 #endif
-  return launch_conv3x3_halo(X, W, C, epi.bias, g.B, g.H, g.W, g.Ci, N, ldc, cus, force, s);
+  return launch_conv3x3_halo(X, W, C, epi.bias, g.B, g.H, g.W, g.Ci, N, ldc, cus, force, s, nullptr);
 }
 
 // bf16 problems the 4-wave two-per-CU kernel has an instance for: 8-element-aligned rows, operands addressable by 32-bit offsets, no ReLU

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // Column reductions over [M, C] rows (channels fastest): sum (and optionally sum of squares, or sum of
 // dy'*(1, xhat) for BN backward).  A thread owns one 16-byte channel chunk and strides over rows.
 // ---------------------------------------------------------------------------------------------------
-enum { RED_SUM = 0, RED_SUM_SQ = 1, RED_BN_BWD = 2, RED_PROD = 3, RED_LN = 4 };
+enum { RED_SUM = 0, RED_SUM_SQ = 1, RED_BN_BWD = 2, RED_PROD = 3, RED_LN = 4,
+       RED_PRESUM = 5 };   // a = f32 partial rows [R][2C] written by a producer's epilogue (sum | sum of squares): only summed
 
 // Grid (row blocks, images, column slabs).  A slab is NCHS <= 16 consecutive 16-byte channel chunks; a block covers 256 / NCHS rows of
 // it at a time.  Block totals go to part[] (plain stores); the block that arrives last at its (image, slab) counter sums the row
@@ -126,6 +127,7 @@ struct BnFin {
   const float* gamma[4]; const float* beta[4]; float* rmean[4]; float* rvar[4]; long long* nbt[4]; float* ss; float* mi;
   float eps, momentum;
   int gc;       // channels per parameter group (== C for a single BatchNorm)
+  long rows;    // RED_PRESUM: the number of samples behind the partial rows (the reduction's own row count otherwise: 0)
 };
 constexpr int RED_SLAB_CHUNKS = 16;
 #ifndef SPG_RED_MAX_GX     // (tools/ builds may override: the last workgroup's fixed-order finish grows with the number of row blocks)
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
                                                         float* __restrict__ part, unsigned* __restrict__ counters, int accumulate,
                                                         BnFin fin) {
   constexpr int VEC = ST<T>::VEC;
-  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN);
+  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN || MODE == RED_PRESUM);
   constexpr int K = TWO ? 2 : 1;
   const int nch = C / VEC;
   const int rpar = 256 / nchs;  // rows handled in parallel by a block
@@ -180,6 +182,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
       } else if constexpr (MODE == RED_SUM_SQ) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { s0[e] += av[e]; s1[e] += av[e] * av[e]; }
+      } else if constexpr (MODE == RED_PRESUM) {   // row = [sums of C channels | sums of squares of C channels], lda = 2 C
+        float qv[VEC];
+        unpack16<T>(ld16(a + (base + r) * lda + C + ch * VEC), qv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s0[e] += av[e]; s1[e] += qv[e]; }
       } else if constexpr (MODE == RED_LN) {  // a = dy, b = x, p0 = mean[row], p1 = rstd[row]
         float xv[VEC];
         unpack16<T>(ld16(b + (base + r) * lda + ch * VEC), xv);
@@ -232,9 +239,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
     o0[cl] = accumulate ? o0[cl] + res[cl] : res[cl];
     if (TWO) o1[cl] = accumulate ? o1[cl] + res[SW + cl] : res[SW + cl];
   }
-  if constexpr (MODE == RED_SUM_SQ) {
+  if constexpr (MODE == RED_SUM_SQ || MODE == RED_PRESUM) {
     if (fin.gamma[0]) {         // BatchNorm finalize of this slab's channels, straight from the totals in LDS
-      const float Mf = (float)rows_total;
+      const long nrows = MODE == RED_PRESUM ? fin.rows : rows_total;
+      const float Mf = (float)nrows;
       for (int cl = threadIdx.x; cl < ncols; cl += 256) {
         const int c = slab * SW + cl;
         const int grp = c / fin.gc, cg = c - grp * fin.gc;
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
         const float var = fmaxf(res[SW + cl] / Mf - mu * mu, 0.f);
         if (fin.rmean[grp]) {
           fin.rmean[grp][cg] = (1.f - fin.momentum) * fin.rmean[grp][cg] + fin.momentum * mu;
-          const float unb = rows_total > 1 ? var * (Mf / (Mf - 1.f)) : var;
+          const float unb = nrows > 1 ? var * (Mf / (Mf - 1.f)) : var;
           fin.rvar[grp][cg] = (1.f - fin.momentum) * fin.rvar[grp][cg] + fin.momentum * unb;
         }
         const float is = rsqrtf(var + fin.eps);
@@ -257,13 +265,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
 }
 
 struct RedPlan { int nchs, nslabs, gx; long rpb; };
-static inline RedPlan red_plan(long rows, int nch, int nimg) {
+static inline RedPlan red_plan(long rows, int nch, int nimg, int rows_per_thread = SPG_RED_ROWS_PER_THREAD) {
   RedPlan p;
   p.nchs = nch < RED_SLAB_CHUNKS ? nch : RED_SLAB_CHUNKS;
   p.nslabs = cdiv(nch, p.nchs);
   const int rpar = 256 / p.nchs;
   const int ni = nimg > 0 ? nimg : 1;
-  long want = rows / ((long)rpar * SPG_RED_ROWS_PER_THREAD);   // >= 16 rows per thread: enough blocks to stream at HBM rate, few partials
+  long want = rows / ((long)rpar * rows_per_thread);   // >= 16 rows per thread: enough blocks to stream at HBM rate, few partials
   long cap = RED_MAX_BLOCKS / ((long)ni * p.nslabs);
   if (cap > RED_MAX_GX) cap = RED_MAX_GX;
   if (cap < 1) cap = 1;
@@ -299,9 +307,10 @@ static int launch_colreduce(const void* a, const void* b, const float* p0, const
     return SPG_ERR_BAD_ARG;
   }
   const long rows = img_rows > 0 ? img_rows : M;
-  const RedPlan p = red_plan(rows, C / VEC, nimg);
+  // (partial rows from a producer's epilogue are few -- 1-5 k rows: a short per-thread loop and more blocks, or two blocks would walk them)
+  const RedPlan p = MODE == RED_PRESUM ? red_plan(rows, C / VEC, nimg, 4) : red_plan(rows, C / VEC, nimg);
   const int ni = nimg > 0 ? nimg : 1;
-  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN);
+  constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN || MODE == RED_PRESUM);
   const long need = (long)p.gx * ni * p.nslabs * (TWO ? 2 : 1) * p.nchs * VEC;
   if (!ws.part || !ws.counters || ws.floats < need) {
     set_error("%s: reduction workspace of %ld floats (+ %d zeroed counters) required, got %ld", what, need, p.nslabs * ni, ws.floats);
@@ -600,6 +609,22 @@ extern "C" int spg_bn_stats_finalize(int dtype, const void* x, float* stats, con
   fin.ss = scale_shift; fin.mi = mean_invstd; fin.eps = eps; fin.momentum = momentum; fin.gc = C;
   return DISPATCH_T(dtype, (launch_colreduce<bf16_t, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats_finalize", nullptr, fin)),
                     (launch_colreduce<float, RED_SUM_SQ>(x, nullptr, nullptr, nullptr, stats, M, C, C, 0, 0, 0, ws, 0, s, "bn_stats_finalize", nullptr, fin)));
+}
+
+// the same from PARTIAL statistics: part f32 [R][2C] rows of (sums | sums of squares) over disjoint sample sets (the epilogue of
+// spg_conv3x3_fwd_stats writes them), M samples in all.  One launch: fixed-order sum of the rows + finalize; the conv output is not read.
+extern "C" int spg_bn_stats_finalize_part(const float* part, long R, float* stats, const float* gamma, const float* beta, float* running_mean,
+                                          float* running_var, long long* num_batches_tracked, float* scale_shift, float* mean_invstd, long M,
+                                          int C, float eps, float momentum, float* red_ws, long red_ws_floats, unsigned* red_counters_,
+                                          spg_stream_t stream) {
+  SPG_REQUIRE(part && gamma && beta && scale_shift && stats, "bn_stats_finalize_part: part, gamma, beta, stats and scale_shift are required");
+  SPG_REQUIRE(R > 0 && M > 0 && C % 4 == 0, "bn_stats_finalize_part: R=%ld M=%ld C=%d", R, M, C);
+  const RedWs ws{red_ws, red_ws_floats, red_counters_};
+  BnFin fin{};
+  fin.gamma[0] = gamma; fin.beta[0] = beta; fin.rmean[0] = running_mean; fin.rvar[0] = running_var; fin.nbt[0] = num_batches_tracked;
+  fin.ss = scale_shift; fin.mi = mean_invstd; fin.eps = eps; fin.momentum = momentum; fin.gc = C; fin.rows = M;
+  return launch_colreduce<float, RED_PRESUM>(part, nullptr, nullptr, nullptr, stats, R, C, 2 * C, 0, 0, 0, ws, 0, (hipStream_t)stream,
+                                             "bn_stats_finalize_part", nullptr, fin);
 }
 
 // the same for four BatchNorms of C/4 channels each over one [M, C] tensor (the e-ASPP branches stored branch-major): HOST arrays of 4 pointers

@@ -191,12 +191,20 @@ class Engine:
         return self._opt_jobs
 
     # ------------------------------------------------------------------------------------------------ BN
-    def bn_fwd(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool):
+    def _bn_train_stats(self, prefix: str, x: Tensor, C: int, part: Optional[Tensor]):
+        """batch statistics -> (scale_shift, mean_invstd) + running statistics: from the producing convolution's partial rows when it
+        wrote them (no pass over x), else by the reduction over x"""
+        P = self.P
+        args = (P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"], P[prefix + "running_var"], P[prefix + "num_batches_tracked"])
+        if part is not None:
+            return ops.bn_stats_finalize_part(part, x.numel() // C, C, *args)
+        return ops.bn_stats_finalize(x, C, *args)
+
+    def bn_fwd(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool, part: Optional[Tensor] = None):
         P = self.P
         M = x.numel() // C
         if training:
-            ss, mi = ops.bn_stats_finalize(x, C, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
-                                           P[prefix + "running_var"], P[prefix + "num_batches_tracked"])
+            ss, mi = self._bn_train_stats(prefix, x, C, part)
         else:
             ss, mi = ops.bn_finalize(None, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
                                      P[prefix + "running_var"], M, False)
@@ -207,13 +215,12 @@ class Engine:
             st.x, st.ss, st.mi, st.C, st.relu, st.prefix = x, ss, mi, C, relu, prefix
         return y, st
 
-    def bn_prepare(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool) -> BNState:
+    def bn_prepare(self, prefix: str, x: Tensor, C: int, relu: bool, training: bool, save: bool, part: Optional[Tensor] = None) -> BNState:
         """Statistics / scale-shift only: the apply is fused into whichever kernel consumes x (bn_apply_head, ped_gather)."""
         P = self.P
         M = x.numel() // C
         if training:
-            ss, mi = ops.bn_stats_finalize(x, C, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
-                                           P[prefix + "running_var"], P[prefix + "num_batches_tracked"])
+            ss, mi = self._bn_train_stats(prefix, x, C, part)
         else:
             ss, mi = ops.bn_finalize(None, P[prefix + "weight"], P[prefix + "bias"], P[prefix + "running_mean"],
                                      P[prefix + "running_var"], M, False)
@@ -460,6 +467,15 @@ class Engine:
     def conv3_fwd(self, name: str, x: Tensor, B, H, W, Ci, bias: bool):
         return ops.gemm_nt(x, self.W[name + ".weight"], bias=self.P[name + ".bias"] if bias else None, conv=(B, H, W, Ci))
 
+    def conv3_fwd_stats(self, name: str, x: Tensor, B, H, W, Ci, bias: bool, training: bool):
+        """conv3_fwd for a convolution that feeds a train-mode BatchNorm: (output, partial statistics or None).  With an instance of the
+        halo-tile kernel for the shape, the statistics come out of the convolution's own epilogue."""
+        w = self.W[name + ".weight"]
+        rows = ops.conv3x3_stats_rows(x, B, H, W, Ci, w.shape[0]) if training else 0
+        if rows <= 0:
+            return self.conv3_fwd(name, x, B, H, W, Ci, bias), None
+        return ops.conv3x3_fwd_stats(x, w, self.P[name + ".bias"] if bias else None, B, H, W, Ci, rows)
+
     def conv3_bwd(self, name: str, dy: Tensor, x: Tensor, B, H, W, Ci, Co, bias: bool, need_dx: bool = True):
         gw, gb = self.grad(name + ".weight"), (self.grad(name + ".bias") if bias else None)
 
@@ -521,8 +537,8 @@ class Engine:
         e0 = ops.gemm_nt(fu1, W["context.expand.0.weight"])
         context, c["bn_e"] = self.bn_fwd("context.expand.1.", e0, 256, True, training, save)
         # --- EFE: conv3x3 -> BN statistics -> [BN-apply + ReLU + 1x1 edge head] in one pass
-        ec = self.conv3_fwd("edge_detector.conv1", context, B, h, w, 256, bias=False)
-        c["bn_ef"] = st_ef = self.bn_prepare("edge_detector.bn1.", ec, 64, True, training, save)
+        ec, ec_part = self.conv3_fwd_stats("edge_detector.conv1", context, B, h, w, 256, False, training)
+        c["bn_ef"] = st_ef = self.bn_prepare("edge_detector.bn1.", ec, 64, True, training, save, part=ec_part)
         edge_f, edge = ops.bn_apply_head(ec, st_ef.ss, P["edge_detector.edge_conv.weight"].view(64), P["edge_detector.edge_conv.bias"], 64)
         # --- PED.  Per stage: ONE gather builds the conv input cat[up2(relu(bn2(previous raw conv output))), up(edge_features)] (the
         # previous stage's BN-apply is folded into the gather, its activated output is never stored); conv1 -> BN -> ReLU -> conv2 ->
@@ -534,10 +550,10 @@ class Engine:
             Cc = Cin + ec_ch
             pc = ops.ped_gather(x, x_ss, B, Hc, Wc, Cin, edge_f if ec_ch else None, h, w, ec_ch)
             pre = f"decoder.decoder_blocks.{i}."
-            a0 = self.conv3_fwd(pre + "conv1", pc, B, H2, W2, Cc, bias=True)
-            a1, st1 = self.bn_fwd(pre + "bn1.", a0, Co, True, training, save)
-            b0 = self.conv3_fwd(pre + "conv2", a1, B, H2, W2, Co, bias=True)
-            st2 = self.bn_prepare(pre + "bn2.", b0, Co, True, training, save)
+            a0, a0_part = self.conv3_fwd_stats(pre + "conv1", pc, B, H2, W2, Cc, True, training)
+            a1, st1 = self.bn_fwd(pre + "bn1.", a0, Co, True, training, save, part=a0_part)
+            b0, b0_part = self.conv3_fwd_stats(pre + "conv2", a1, B, H2, W2, Co, True, training)
+            st2 = self.bn_prepare(pre + "bn2.", b0, Co, True, training, save, part=b0_part)
             _, pred = ops.bn_apply_head(b0, st2.ss, P[f"decoder.pred_heads.{i}.weight"].view(Co), P[f"decoder.pred_heads.{i}.bias"], Co,
                                         write_y=False)
             preds.append(pred.view(B, 1, H2, W2))

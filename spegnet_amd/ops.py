@@ -2,7 +2,7 @@
 HIP kernels on torch's current stream; tensors only provide device memory.  No CPU path exists."""
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -492,6 +492,40 @@ def bn_stats_finalize(x: Tensor, C: int, gamma: Tensor, beta: Tensor, rmean: Opt
                   _p(ss), _p(mi), M, C, eps, momentum, _p(ws), n, cnt, _stream())
     return ss, mi
 
+
+
+def conv3x3_stats_rows(x: Tensor, B: int, H: int, W: int, Ci: int, Co: int) -> int:
+    """rows of the partial-statistics matrix conv3x3_fwd_stats writes; 0 = no fused instance for this problem (fp32 parity mode, channel
+    counts that are no multiples of 64): the caller then runs gemm_nt(conv=...) and bn_stats_finalize."""
+    return int(_lib.load().spg_conv3x3_stats_rows(dcode(x), B, H, W, Ci, Co, cu_budget_now()))
+
+
+def conv3x3_fwd_stats(x: Tensor, w: Tensor, bias: Optional[Tensor], B: int, H: int, W: int, Ci: int, rows: int) -> Tuple[Tensor, Tensor]:
+    """3x3 convolution (w packed [Co, 9*Ci]) + per-tile BatchNorm partial statistics in ONE launch.  Returns (out [B*H*W, Co], part f32
+    [rows, 2*Co])."""
+    Co = w.shape[0]
+    M = B * H * W
+    out = torch.empty((M, Co), dtype=x.dtype, device=x.device)
+    part = torch.empty((rows, 2 * Co), dtype=torch.float32, device=x.device)
+    with _prof("gemm_nt<bf16,conv3x3>", "mfma", 2.0 * M * Co * 9 * Ci):
+        _lib.call("spg_conv3x3_fwd_stats", dcode(x), _p(_c(x)), _p(_c(w)), _p(out), _p(bias), _p(part), rows, B, H, W, Ci, Co,
+                  cu_budget_now(), _stream())
+    return out, part
+
+
+def bn_stats_finalize_part(part: Tensor, M: int, C: int, gamma: Tensor, beta: Tensor, rmean: Optional[Tensor], rvar: Optional[Tensor],
+                           nbt: Optional[Tensor], eps: float = 1e-5, momentum: float = 0.1):
+    """bn_stats_finalize from the partial rows a producer's epilogue wrote (sum | sum of squares): one launch over [R, 2C] floats instead
+    of a pass over the [M, C] tensor.  Returns (scale_shift, mean_invstd)."""
+    R = part.shape[0]
+    assert part.dtype == torch.float32 and part.shape[1] == 2 * C and part.is_contiguous()
+    buf = torch.empty(6 * C, dtype=torch.float32, device=part.device)
+    stats, ss, mi = buf[:2 * C], buf[2 * C:4 * C], buf[4 * C:]
+    ws, n, cnt = _red(part, C, 0)
+    with _prof("bn_stats_finalize (from conv partials)", "hbm", part.numel() * 4):
+        _lib.call("spg_bn_stats_finalize_part", _p(part), R, _p(stats), _p(f32(gamma)), _p(f32(beta)), _p(rmean), _p(rvar), _p(nbt),
+                  _p(ss), _p(mi), M, C, eps, momentum, _p(ws), n, cnt, _stream())
+    return ss, mi
 
 def bn_finalize(stats: Optional[Tensor], gamma: Tensor, beta: Tensor, rmean: Optional[Tensor], rvar: Optional[Tensor], M: int,
                 training: bool, eps: float = 1e-5, momentum: float = 0.1):

@@ -832,3 +832,36 @@ def test_fused_codloss_matches_torch_formula(dt, case):
     if dt == torch.float32:
         o = O.cod_loss([p.cpu() for p in preds], edge.cpu(), [m for m in masks.cpu()], [e for e in edges.cpu()], **O.LOSS_DEFAULT_YAML)
         assert abs(float(out["loss"]) - float(o["loss"])) < 2e-5 * max(1.0, abs(float(o["loss"])))
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 9, 33, 64, 64), (3, 17, 31, 128, 320), (2, 48, 48, 256, 64), (8, 96, 96, 64, 128)])
+def test_conv3x3_fwd_stats_matches_conv_then_bn_stats(ops, B, H, W, Ci, Co):
+    """The fused launch (halo-tile convolution whose epilogue writes per-tile BatchNorm partial sums) + bn_stats_finalize_part against the
+    unfused pair: the convolution output must be bit-identical to gemm_nt(conv=...), and scale/shift, mean/invstd and the running statistics
+    must equal those of bn_stats_finalize over that output (both reduce the same rounded values in fp32; only the summation order differs).
+    Ragged tiles (H, W no multiples of 8 / 32) check that masked pixels stay out of the sums; Co = 320 the five 64-wide n-tiles."""
+    dt = torch.bfloat16
+    x = rnd(B, H, W, Ci, seed=1).to(dt)
+    w = rnd(Co, 9 * Ci, seed=2, scale=(9 * Ci) ** -0.5).to(dt)
+    bias = rnd(Co, seed=3)
+    rows = ops.conv3x3_stats_rows(x, B, H, W, Ci, Co)
+    sp = B * ((H + 7) // 8) * ((W + 31) // 32)
+    assert rows == (4 * min(sp, 256) if Co in (64, 128) else 4 * sp)
+    out, part = ops.conv3x3_fwd_stats(x, w, bias, B, H, W, Ci, rows)
+    ref = ops.gemm_nt(x, w, bias=bias, conv=(B, H, W, Ci))
+    assert torch.equal(out, ref)
+    M = B * H * W
+    def fresh():
+        return (rnd(Co, seed=4).abs() + 0.5, rnd(Co, seed=5), torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda"),
+                torch.zeros((), dtype=torch.int64, device="cuda"))
+    g1, b1, rm1, rv1, n1 = fresh()
+    g2, b2, rm2, rv2, n2 = fresh()
+    ss1, mi1 = ops.bn_stats_finalize_part(part, M, Co, g1, b1, rm1, rv1, n1)
+    ss2, mi2 = ops.bn_stats_finalize(ref, Co, g2, b2, rm2, rv2, n2)
+    for a_, b_, nm in ((ss1, ss2, "scale_shift"), (mi1, mi2, "mean_invstd"), (rm1, rm2, "running_mean"), (rv1, rv2, "running_var")):
+        check(a_, b_, 1e-4, nm)
+    assert int(n1) == int(n2) == 1
+    # and against torch on the rounded output
+    xf = ref.float()
+    check(mi1[:Co], xf.mean(0), 1e-4, "mean")
+    check(mi1[Co:], (xf.var(0, unbiased=False) + 1e-5).rsqrt(), 1e-4, "invstd")
