@@ -553,6 +553,330 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloArgs a) {
   (void)st_sum0; (void)st_sum1; (void)st_sum2; (void)st_sum3; (void)st_n;
 }
 
+// =====================================================================================================================
+// Weight gradient of the 3x3 convolution on the same LDS-resident tiles:  dW[co][tap][ci] += sum_px dY[px][co] * X[px + tap][ci]
+// (reference: autograd of nn.Conv2d, models/object_detection.py:115-123, 193-199).  A workgroup owns ONE 64 (co) x 9 x 64 (ci) block
+// of dW and a contiguous range of 8 x 32 pixel tiles; its accumulators (72 VGPRs per lane) live across the whole range, so there is no
+// per-tile epilogue at all: one partial block per workgroup goes to a slab at the end and a small kernel sums the slabs in a fixed
+// order (deterministic: no float atomics, unlike the implicit-GEMM wgrad it replaces).  Per tile the workgroup stages dY [256 px][64 co]
+// (32 KiB) and the X halo [340 px][64 ci] (43 KiB) ONCE for all nine taps -- the implicit GEMM re-gathers X per tap.
+//   * contraction = pixels: a k32 step is one tile row of 32 pixels (k-step j <-> tile row j); tap (dy, dx) reads halo rows
+//     (j + dy + 1) * 34 + dx + 1 + (0..31).  Both operands have k along LDS rows, so fragments come from ds_read_b64_tr_b16 (two per
+//     fragment); the chunk swizzle key (x & 7) ^ (((x >> 3) & 1) << 2) of a pixel's column x makes those reads conflict-free.
+//   * MFMA roles: A = X (rows ci), B = dY (cols co)  =>  D[ci][co]: a lane holds 4 consecutive ci of one co: 16-byte slab stores.
+//   * waves: 2 (co halves of 32) x 4 (ci blocks of 16); a wave multiplies 2 co-blocks x 9 taps per k32 step: 11 fragments for 18 MFMAs.
+//   * two wave groups one barrier apart, phases of two k-steps (36 MFMAs), as in the forward kernel; two tile buffers: the ten pieces per
+//     wave of tile t + 1 are issued in phases 0 and 1 of tile t and retired (vmcnt(0)) in its phase 3, two phases after the last issue.
+// =====================================================================================================================
+typedef __attribute__((ext_vector_type(4))) short hs16x4_t;
+typedef __attribute__((ext_vector_type(8))) short hs16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2_t;
+constexpr int WG_DY_BYTES = 256 * 128;                       // dY tile image
+constexpr int WG_BUF = WG_DY_BYTES + HALO_PIECES * 1024;     // + halo image: 76800 B
+constexpr int WG_LDS_BYTES = 2 * WG_BUF;
+constexpr int WG_SLAB_FLOATS = 64 * 9 * 64;
+
+struct WgradArgs {
+  const bf16_t* dY; const bf16_t* X; float* slabs; float* bslabs;
+  int B, H, W, Ci, Co;
+  int tiles_x, tiles_y, T, nci, P;      // spatial tiles in all, ci chunks, pixel-range splits per (co tile, ci chunk)
+  unsigned ybytes, xbytes;
+};
+
+__device__ __forceinline__ int wg_key(int x) { return (x & 7) ^ (((x >> 3) & 1) << 2); }
+__device__ __forceinline__ bf16x8_t wg_frag(const char* base, unsigned o0, unsigned o1) {
+  const hs16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4_t*)(base + o0));
+  const hs16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4_t*)(base + o1));
+  const hs16x8_t v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int DBG = 0>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wco = wave & 1, wci = wave >> 1;           // this wave's co half (2 blocks of 16) and ci block
+  const int q = lane >> 4, ra = (lane & 15) >> 2, rb = lane & 3;
+  const int H = a.H, W = a.W, Ci = a.Ci, Co = a.Co;
+  const int wg = blockIdx.x;
+  const int combo = wg / a.P, split = wg - combo * a.P;
+  const int co0 = (combo / a.nci) * 64, ci0 = (combo % a.nci) * 64;
+  const int t0 = (int)((long)split * a.T / a.P), t1 = (int)((long)(split + 1) * a.T / a.P);
+  const int ntiles = t1 - t0;
+  const hrsrc_words_t yr = halo_rsrc_words(a.dY, a.ybytes), xr = halo_rsrc_words(a.X, a.xbytes);
+  const unsigned smem_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- fragment read offsets (buffer 0; the buffer toggle is added per tile)
+  unsigned xa[3][2], ya[2][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int hx = d + 8 * q + ra + 4 * r;
+      xa[d][r] = (unsigned)(WG_DY_BYTES + hx * 128 + (((2 * wci + (rb >> 1)) ^ wg_key(hx)) << 4) + (rb & 1) * 8);
+    }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int x = 8 * q + ra + 4 * r;
+      ya[cb][r] = (unsigned)(x * 128 + (((2 * (2 * wco + cb) + (rb >> 1)) ^ wg_key(x)) << 4) + (rb & 1) * 8);
+    }
+
+  // ---- the prefetch stream's tile (one ahead of the multiplication) and the ten piece offsets prepared for it
+  int pf_x, pf_y, pf_i, pf_left;        // tile digits of the tile the NEXT issue fills, tiles left to prefetch
+  {
+    int r = t0;
+    pf_x = r % a.tiles_x; r /= a.tiles_x;
+    pf_y = r % a.tiles_y; pf_i = r / a.tiles_y;
+  }
+  pf_left = ntiles;
+  auto pf_advance = [&]() __attribute__((always_inline)) {
+    --pf_left;
+    if (++pf_x == a.tiles_x) { pf_x = 0; if (++pf_y == a.tiles_y) { pf_y = 0; ++pf_i; } }
+  };
+  unsigned po[10];
+  // piece s (0..3: dY pieces 8 s + wave; 4..9: halo pieces 8 (s - 4) + wave) of the prefetch stream's tile
+  auto piece_off = [&](int s) __attribute__((always_inline)) -> unsigned {
+    const int l3 = lane >> 3;
+    if (s < 4) {
+      const int pc = s * 8 + wave;                       // px = 8 pc + l3: tile row pc >> 2, column (pc & 3) * 8 + l3
+      const int cx = (pc & 3) * 8 + l3;
+      const int y = pf_y * HALO_TH + (pc >> 2), x = pf_x * HALO_TW + cx;
+      const bool ok = pf_left > 0 && y < H && x < W;
+      const unsigned off = (unsigned)((((pf_i * H + y) * W + x) * Co + co0) * 2) + (unsigned)((((lane & 7) ^ wg_key(cx))) << 4);
+      return ok ? off : HALO_DEAD;
+    } else {
+      const int pc = (s - 4) * 8 + wave;
+      const int p = pc * 8 + l3;
+      const int hy = (p * 241) >> 13, hx = p - hy * HALO_PITCH;
+      const int y = pf_y * HALO_TH - 1 + hy, x = pf_x * HALO_TW - 1 + hx;
+      const bool ok = pf_left > 0 && p < HALO_ROWS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      const unsigned off = (unsigned)((((pf_i * H + y) * W + x) * Ci + ci0) * 2) + (unsigned)((((lane & 7) ^ wg_key(hx))) << 4);
+      return ok ? off : HALO_DEAD;
+    }
+  };
+  auto piece_issue = [&](int s, int buf) __attribute__((always_inline)) {
+    if (s < 4) {
+      halo_dma16(yr, smem_base + (unsigned)(buf * WG_BUF + (s * 8 + wave) * 1024), po[s]);
+    } else {
+      const int pc = (s - 4) * 8 + wave;
+      if (pc < HALO_PIECES) halo_dma16(xr, smem_base + (unsigned)(buf * WG_BUF + WG_DY_BYTES + pc * 1024), po[s]);
+    }
+  };
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  float bsum[2] = {0.f, 0.f};
+  const hbf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+  const bool do_bias = a.bslabs != nullptr && ci0 == 0 && wci == 0;
+
+  // ---- prologue: tile t0 into buffer 0; tile t0 + 1's offsets prepared
+#pragma unroll
+  for (int s = 0; s < 10; ++s) po[s] = piece_off(s);
+#pragma unroll
+  for (int s = 0; s < 10; ++s) piece_issue(s, 0);
+  pf_advance();
+#pragma unroll
+  for (int s = 0; s < 10; ++s) po[s] = piece_off(s);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier interval behind group 0
+
+  bf16x8_t fx[2][9], fy[2][2];
+  int buf = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    auto phase = [&](auto PH_) __attribute__((always_inline)) {
+      constexpr int ph = decltype(PH_)::value;
+      // ================= issue segment: 44 transpose reads (two k-steps), the next tile's pieces (phases 0 and 1)
+      if constexpr (DBG != 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          constexpr int dummy = 0; (void)dummy;
+          const int j = 2 * ph + ks;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) fy[ks][cb] = wg_frag(smem + j * 4096, ya[cb][0], ya[cb][1]);
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) fx[ks][tp] = wg_frag(smem + (j + tp / 3) * (HALO_PITCH * 128), xa[tp % 3][0], xa[tp % 3][1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DBG != 1) {
+        if constexpr (ph == 0) {
+#pragma unroll
+          for (int s = 0; s < 5; ++s) piece_issue(s, buf ^ 1);
+        }
+        if constexpr (ph == 1) {
+#pragma unroll
+          for (int s = 5; s < 10; ++s) piece_issue(s, buf ^ 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ph == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (this wave's pieces; the barrier publishes everyone's)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ================= MFMA segment; phases 2 and 3 prepare the piece offsets of the tile after next in its gaps
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < 36; ++m) {
+        const int ks = m / 18, r = m % 18, tp = r >> 1, cb = r & 1;
+        if constexpr (DBG != 3) acc[tp][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[ks][tp], fy[ks][cb], acc[tp][cb], 0, 0, 0);
+        else asm volatile("" ::"v"(fx[ks][tp]), "v"(fy[ks][cb]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_bias && m < 16) {   // column sums of dY (the bias gradient) from the fragments in registers: one element pair per gap
+          const int ks_ = m >> 3, cb_ = (m >> 2) & 1, e = m & 3;
+          const bf16x8_t v = fy[ks_][cb_];
+          const hbf16x2_t pr = {v[2 * e], v[2 * e + 1]};
+          bsum[cb_] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum[cb_], false);
+        }
+        if constexpr (ph == 2) {
+          if (m == 16) { asm volatile("" : "+s"(pf_left)); pf_advance(); asm volatile("" : "+s"(pf_left)); }
+          if (m >= 18 && m < 28 && (m & 1) == 0) { const int s_ = (m - 18) >> 1; po[s_] = piece_off(s_); asm volatile("" : "+v"(po[s_])); }
+        }
+        if constexpr (ph == 3) {
+          if (m >= 16 && m < 26 && (m & 1) == 0) { const int s_ = 5 + ((m - 16) >> 1); po[s_] = piece_off(s_); asm volatile("" : "+v"(po[s_])); }
+          if (m == 28) {   // the next tile is multiplied from the other buffer
+            const unsigned d = buf ? (unsigned)-WG_BUF : (unsigned)WG_BUF;
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) { xa[dd][0] += d; xa[dd][1] += d; asm volatile("" : "+v"(xa[dd][0])); asm volatile("" : "+v"(xa[dd][1])); }
+#pragma unroll
+            for (int cb2 = 0; cb2 < 2; ++cb2) { ya[cb2][0] += d; ya[cb2][1] += d; asm volatile("" : "+v"(ya[cb2][0])); asm volatile("" : "+v"(ya[cb2][1])); }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+    buf ^= 1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- the workgroup's partial block: slab[wg][co][tap][ci]
+  float* sl = a.slabs + (long)wg * WG_SLAB_FLOATS;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int co = (2 * wco + cb) * 16 + (lane & 15), ci = wci * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(sl + ((co * 9 + tp) * 64 + ci)) = acc[tp][cb];
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float b = bsum[cb];
+      b += __shfl_xor(b, 16, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (q == 0) a.bslabs[(long)wg * 64 + (2 * wco + cb) * 16 + (lane & 15)] = b;
+    }
+  }
+}
+
+// dW[co0 + co][tap][ci0 + ci] += sum over the P splits of a (co tile, ci chunk) in a FIXED order; dbias likewise from the ci chunk 0 slabs.
+// A block owns 16 float4 of the 64 x 9 x 64 block; its 16 lanes-groups each sum every sixteenth split (up to four loads in flight per
+// lane) and the sixteen partial sums are combined in a fixed tree: with P = 256 splits one thread per output walked 256 dependent-latency
+// loads (55 us for 38 MB); 576 blocks x 256 threads stream them.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bslabs,
+                                                                   float* __restrict__ dW, float* __restrict__ dbias, int Ci, int nci, int P) {
+  __shared__ f32x4 red[16][16];
+  const int combo = blockIdx.y;
+  const int co0 = (combo / nci) * 64, ci0 = (combo % nci) * 64;
+  const int o = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int v = blockIdx.x * 16 + o;                     // float4 index inside the 64 x 9 x 64 block
+  const float* base = slabs + (long)combo * P * WG_SLAB_FLOATS + v * 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int p = pl;
+  for (; p + 48 < P; p += 64) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(base + (long)p * WG_SLAB_FLOATS);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(base + (long)(p + 16) * WG_SLAB_FLOATS);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(base + (long)(p + 32) * WG_SLAB_FLOATS);
+    const f32x4 a3 = *reinterpret_cast<const f32x4*>(base + (long)(p + 48) * WG_SLAB_FLOATS);
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  for (; p < P; p += 16) s0 += *reinterpret_cast<const f32x4*>(base + (long)p * WG_SLAB_FLOATS);
+  red[pl][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pl == 0) {
+    f32x4 t[4];
+#pragma unroll
+    for (int g_ = 0; g_ < 4; ++g_) t[g_] = (red[4 * g_][o] + red[4 * g_ + 1][o]) + (red[4 * g_ + 2][o] + red[4 * g_ + 3][o]);
+    const f32x4 tt = (t[0] + t[1]) + (t[2] + t[3]);
+    const int ci = (v & 15) * 4, tp = (v >> 4) % 9, co = (v >> 4) / 9;
+    float* d = dW + ((long)(co0 + co) * 9 + tp) * Ci + ci0 + ci;
+    *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + tt;
+  }
+  if (dbias && bslabs && ci0 == 0 && blockIdx.x == 0) {   // (a serial walk over P = 256 splits took 65 us: four lanes per channel, four loads in flight)
+    __shared__ float bred[4][64];
+    const int c = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const float* bb = bslabs + (long)combo * P * 64 + c;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    int q_ = bl;
+    for (; q_ + 12 < P; q_ += 16) {
+      b0 += bb[(long)q_ * 64]; b1 += bb[(long)(q_ + 4) * 64]; b2 += bb[(long)(q_ + 8) * 64]; b3 += bb[(long)(q_ + 12) * 64];
+    }
+    for (; q_ < P; q_ += 4) b0 += bb[(long)q_ * 64];
+    bred[bl][c] = (b0 + b1) + (b2 + b3);
+    __syncthreads();
+    if (bl == 0) dbias[co0 + c] += (bred[0][c] + bred[1][c]) + (bred[2][c] + bred[3][c]);
+  }
+}
+
+// workspace floats of launch_conv3x3_wgrad_halo (0: the problem is outside its domain)
+long conv3x3_wgrad_halo_ws_floats(int B, int H, int W, int Ci, int Co, int cus) {
+  if (Ci % 64 != 0 || Co % 64 != 0 || H < 1 || W < 1) return 0;
+  const long M = (long)B * H * W;
+  if (M * Ci * 2L >= 0x7FFFFFF0L || M * Co * 2L >= 0x7FFFFFF0L) return 0;
+  const int combos = (Co / 64) * (Ci / 64);
+  if (combos > cus) return 0;
+  const long T = (long)B * cdiv(W, HALO_TW) * cdiv(H, HALO_TH);
+  long P = cus / combos;
+  if (P > T / 4) P = T / 4;              // at least four tiles per workgroup (one or two are all prologue, slab write and reduce: EFE at 48 x 48 measured 54 vs 30 us)
+  if (P < 1) return 0;
+  if (T >= 64 && combos * P < cus / 2) return 0;   // fewer than half the CUs would work (EFE at 48 x 48: 35 vs 29 us for the implicit GEMM)
+  return (long)combos * P * (WG_SLAB_FLOATS + 64);
+}
+
+// dW f32 [Co][9][Ci] += conv-wgrad(dY, X); dbias [Co] += column sums of dY (may be null).  Returns 1 when outside the kernel's domain.
+int launch_conv3x3_wgrad_halo(const void* dY, const void* X, float* dW, float* dbias, float* ws, long ws_floats, int B, int H, int W, int Ci,
+                              int Co, int cus, hipStream_t s) {
+  const long need = conv3x3_wgrad_halo_ws_floats(B, H, W, Ci, Co, cus);
+  if (need <= 0 || !ws || ws_floats < need) return 1;
+  WgradArgs a;
+  a.dY = (const bf16_t*)dY; a.X = (const bf16_t*)X;
+  a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  a.tiles_x = cdiv(W, HALO_TW); a.tiles_y = cdiv(H, HALO_TH);
+  a.T = B * a.tiles_x * a.tiles_y;
+  a.nci = Ci / 64;
+  const int combos = (Co / 64) * a.nci;
+  int P = cus / combos;
+  if (P > a.T / 4) P = a.T / 4;
+  a.P = P;
+  a.slabs = ws;
+  a.bslabs = dbias ? ws + (long)combos * P * WG_SLAB_FLOATS : nullptr;
+  const long M = (long)B * H * W;
+  a.ybytes = (unsigned)(M * Co * 2L); a.xbytes = (unsigned)(M * Ci * 2L);
+  static bool attr_ = false;
+  if (!attr_) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_halo_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES);
+    attr_ = true;
+  }
+  hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<0>), dim3(combos * P), dim3(512), WG_LDS_BYTES, s, a);
+  int rc = check_launch("conv3x3_wgrad_halo");
+  if (rc) return rc;
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(WG_SLAB_FLOATS / 4 / 16, combos), dim3(256), 0, s, (const float*)a.slabs,
+                     (const float*)a.bslabs, dW, dbias, Ci, a.nci, P);
+  return check_launch("conv3x3_wgrad_halo(reduce)");
+}
+
 // returns SPG_OK, an error, or 1 when the problem is outside this kernel's domain (the caller falls back to the implicit GEMM)
 // stats != nullptr: also writes the BatchNorm partial statistics (conv3x3_halo_stats_rows() rows of 2 Co floats, every row written)
 int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bias, int B, int H, int W, int Ci, int Co, int ldc,
@@ -664,6 +988,22 @@ extern "C" int spg_conv3x3_fwd_stats(int dtype, const void* X, const void* Wp, v
   SPG_REQUIRE(stats_part != nullptr && part_rows == rows, "conv3x3_fwd_stats: the partial matrix must have %ld rows of 2*Co floats, got %ld", rows, part_rows);
   const int rc = launch_conv3x3_halo(X, Wp, C, bias, B, H, Wd, Ci, Co, Co, cus, 0, (hipStream_t)stream, stats_part);
   if (rc == 1) { set_error("conv3x3_fwd_stats: problem outside the halo kernel's domain"); return SPG_ERR_UNSUPPORTED; }
+  return rc;
+}
+
+// ---- C ABI: bf16 3x3 convolution weight gradient on LDS-resident tiles (include/spegnet_hip.h)
+extern "C" long spg_conv3x3_wgrad_workspace_bytes(int dtype, int B, int H, int Wd, int Ci, int Co, int cu_budget) {
+  return dtype == SPG_BF16 ? 4L * conv3x3_wgrad_halo_ws_floats(B, H, Wd, Ci, Co, halo_cus(cu_budget)) : 0;
+}
+extern "C" int spg_conv3x3_wgrad(int dtype, const void* dY, const void* X, float* dW, float* dbias, void* workspace, long workspace_bytes,
+                                 int B, int H, int Wd, int Ci, int Co, int cu_budget, spg_stream_t stream) {
+  SPG_REQUIRE(dtype == SPG_BF16, "conv3x3_wgrad: bf16 only (dtype %d)", dtype);
+  const int cus = halo_cus(cu_budget);
+  const long need = 4L * conv3x3_wgrad_halo_ws_floats(B, H, Wd, Ci, Co, cus);
+  SPG_REQUIRE(need > 0, "conv3x3_wgrad: no instance for B=%d H=%d W=%d Ci=%d Co=%d (ask spg_conv3x3_wgrad_workspace_bytes first)", B, H, Wd, Ci, Co);
+  SPG_REQUIRE(workspace && workspace_bytes >= need, "conv3x3_wgrad: workspace of %ld bytes needed (got %ld)", need, workspace_bytes);
+  const int rc = launch_conv3x3_wgrad_halo(dY, X, dW, dbias, (float*)workspace, workspace_bytes / 4, B, H, Wd, Ci, Co, cus, (hipStream_t)stream);
+  if (rc == 1) { set_error("conv3x3_wgrad: problem outside the kernel's domain"); return SPG_ERR_UNSUPPORTED; }
   return rc;
 }
 

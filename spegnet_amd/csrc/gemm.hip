@@ -3125,6 +3125,296 @@ __global__ __launch_bounds__(256) void tnw_reduce_kernel(TnwGroup g, const float
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn_wide_pp_kernel: the macro-tile grouped wgrad kernel above with the two-group schedule of conv_halo.hip.  Waves 0-3 and 4-7 run
+// the same program ONE barrier apart: while one group issues its 32-MFMA cluster, the other issues the next step's 32 transpose reads
+// and its 6 LDS-DMA pieces, so the matrix pipe never waits for a wave's own loads (the kernel above reads, fills and multiplies in
+// every wave at once: its fill pipeline alone took as long as the whole step).  Step = 64 rows of M; stage = three [64][128] sub-tiles
+// (48 KiB) as above, 3 stages: step s multiplies slot s % 3 while the pieces of step s + 2 go to slot (s + 2) % 3, the slot read one
+// phase earlier (every wave's reads have returned -- lgkmcnt(0) -- before the barrier that precedes the issue).  vmcnt(6) after the
+// issue retires step s + 1's pieces (this wave's; the barrier publishes everyone's).  The cursor / address arithmetic of the next
+// step sits in the gaps of the MFMA cluster, pinned by empty volatile asm statements (conv_halo.hip).  A finished tile leaves in the
+// NEXT step's issue segment (dW read-modify-write for whole tiles, slab stores for partial ones): schedule, slabs and reduce as above.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_tn_wide_pp_kernel(TnwGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  using F = TnFrag<T>;
+  constexpr int MSTEP = 64, STAGES = 3, SUB_B = 16384, STAGE_B = 3 * SUB_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int G = (int)gridDim.x;
+  const int c = xcd_remap(blockIdx.x, G);
+  const int S = g.S;
+  const int WS = g.W * S;
+  const int rb = (int)((long)c * g.RS / G), re = (int)((long)(c + 1) * g.RS / G);
+  const int total = WS + (re - rb);
+  if (total <= 0) return;
+  const int gt_first = WS > 0 ? c * g.W : g.W * G + rb / S;
+  const int m_first = WS > 0 ? 0 : rb % S;
+  const int gt_rem = g.W * G + rb / S, m_rem = rb % S;
+  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
+
+  // ---- DMA issue stream (two steps ahead of the multiplication): a wave moves pieces {wave, wave + 8} of each of the three sub-tiles
+  const int lrow = lane >> 4, lpc = lane & 15;
+  const int prow0 = wave * 4 + lrow;
+  const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;
+  int is_job = -1, is_gt = gt_first, is_tile, is_mstep = m_first, is_ls = 0, is_slot = 0, is_ndy = 1;
+  bool is_live = true;
+  bool sin[3] = {false, false, false};           // the sub-tile's 8 columns of this lane are inside the matrix
+  unsigned soff[3] = {0u, 0u, 0u}, sstride[3] = {0u, 0u, 0u}, s32[3] = {0u, 0u, 0u};
+  rsrc_words_t yr, xr;
+  auto is_enter_tile = [&]() __attribute__((always_inline)) {
+    int j;
+    tnw_locate_tile(g, is_gt, j, is_tile);
+    const TnwJob& jb = g.job[j];
+    if (j != is_job) {
+      is_job = j;
+      yr = make_rsrc_words(jb.dY, (unsigned)((long)g.M * jb.ldy * 2));
+      xr = make_rsrc_words(jb.X, (unsigned)((long)g.M * jb.ldx * 2));
+      is_ndy = jb.wide_n ? 2 : 1;
+    }
+    const int tk = is_tile % jb.tiles_k, tn = is_tile / jb.tiles_k;
+    const int n0 = tn * (jb.wide_n ? 256 : 128), k0 = tk * (jb.wide_n ? 128 : 256);
+    const long m0 = (long)is_mstep * MSTEP + prow0;
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) {
+      const bool isy = sb < is_ndy;
+      const int col = (isy ? n0 + 128 * sb : k0 + 128 * (sb - is_ndy)) + fcol;
+      const int ld = isy ? jb.ldy : jb.ldx;
+      soff[sb] = (unsigned)((m0 * ld + col) * 2);
+      sstride[sb] = (unsigned)(MSTEP * ld * 2);
+      s32[sb] = (unsigned)(32 * ld * 2);
+      sin[sb] = col < (isy ? jb.N : jb.K);
+    }
+  };
+  is_enter_tile();
+  unsigned dof[3][2];          // prepared source offsets of the six pieces of the stream's current step
+  unsigned d_slot = 0;         // ... and the stage they go to (byte offset)
+  int d_ndy = 1;
+  rsrc_words_t d_yr, d_xr;
+  auto dma_prepare = [&]() __attribute__((always_inline)) {   // rows past M fall outside the descriptors: hardware zero fill
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) {
+      dof[sb][0] = (is_live && sin[sb]) ? soff[sb] : OOB;
+      dof[sb][1] = (is_live && sin[sb]) ? soff[sb] + s32[sb] : OOB;
+    }
+    d_slot = (unsigned)(is_slot * STAGE_B);
+    d_ndy = is_ndy; d_yr = yr; d_xr = xr;
+  };
+  auto dma_issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned st = smem_base + d_slot + sb * SUB_B + (h * 8 + wave) * 1024;
+        if (sb < d_ndy) dma16_asm(d_yr, st, dof[sb][h]); else dma16_asm(d_xr, st, dof[sb][h]);
+      }
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) soff[sb] += sstride[sb];
+    ++is_ls;
+    const bool tile_end = is_mstep + 1 == S;
+    if (is_ls >= total) is_live = false;
+    else if (is_ls == WS) { is_gt = gt_rem; is_mstep = m_rem; is_enter_tile(); }
+    else if (tile_end) { is_gt = is_gt + 1; is_mstep = 0; is_enter_tile(); }
+    else is_mstep = is_mstep + 1;
+  };
+
+  // ---- fragments: a = dY (n) blocks, b = X (k) blocks of this wave's 64 x 64 tile; one byte offset per fragment
+  int oa[4], ob[4];
+  int wn = 0, wk = 0;
+  auto set_wave_layout = [&](int wide_n) __attribute__((always_inline)) {
+    wn = wide_n ? (wave & 3) : (wave & 1);
+    wk = wide_n ? (wave >> 2) : (wave >> 1);
+    const int ndy = wide_n ? 2 : 1;
+    const int ncol = 64 * wn, kcol = 64 * wk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int o0, o1;
+      F::offsets(0, (ncol & 127) + i * 16, lane, o0, o1);
+      oa[i] = (ncol >> 7) * SUB_B + o0;
+      F::offsets(0, (kcol & 127) + i * 16, lane, o0, o1);
+      ob[i] = (ndy + (kcol >> 7)) * SUB_B + o0;
+    }
+  };
+  typename F::Frag fa[2][4], fb[2][4];
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+  const int r15 = lane & 15, q = lane >> 4;
+
+  // ---- compute cursor (the step being multiplied) and the finished tile waiting for its stores
+  int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;
+  int cj, ctile;
+  tnw_locate_tile(g, cgt, cj, ctile);
+  set_wave_layout(g.job[cj].wide_n);
+  bool ep_pending = false, ep_whole = false, ep_bias = false;
+  int ep_j = 0, ep_tile = 0, ep_slot = 0, ep_wn = 0, ep_wk = 0;
+  auto flush = [&]() __attribute__((always_inline)) {   // the finished (part of a) tile leaves: accumulators restart at zero
+    const TnwJob& jb = g.job[ep_j];
+    const int tk = ep_tile % jb.tiles_k, tn = ep_tile / jb.tiles_k;
+    const int TNn = jb.wide_n ? 256 : 128, TNk = jb.wide_n ? 128 : 256;
+    const int n0 = tn * TNn + ep_wn * 64, k0 = tk * TNk + ep_wk * 64;
+    if (ep_whole) {
+      const __amdgpu_buffer_rsrc_t wr = make_rsrc(jb.dW, (unsigned)((long)jb.N * jb.ldw * 4));
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {       // one n block at a time: 4 loads in flight, 16 VGPRs
+        u32x4 old[4];
+        unsigned o[4];
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+          const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
+          o[ki] = (n < jb.N && k < jb.K) ? (unsigned)(((long)n * jb.ldw + k) * 4) : OOB;
+          old[ki] = bload16(wr, o[ki]);
+        }
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+          const f32x4 v = acc[ni][ki] + f32x4{__uint_as_float(old[ki].x), __uint_as_float(old[ki].y), __uint_as_float(old[ki].z),
+                                              __uint_as_float(old[ki].w)};
+          bstore16(wr, o[ki], u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
+          acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    } else {
+      const unsigned base = (unsigned)(((long)c * 2 + ep_slot) * TNW_SLOT_FLOATS * 4);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+          const int nl = ep_wn * 64 + ni * 16 + r15, kl = ep_wk * 64 + ki * 16 + q * 4;
+          bstore16(sr, base + (unsigned)((nl * TNk + kl) * 4), u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
+                                                                     __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
+          acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if (ep_bias) {
+      const bool two = jb.wide_n != 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 0 || two) {
+          float b = bsum[h];
+          b += __shfl_xor(b, 16, 64);
+          b += __shfl_xor(b, 32, 64);
+          const int n = n0 + (two ? 2 * ep_wk + h : ep_wk) * 16 + r15;
+          if (q == 0 && n < jb.N) atomicAdd(jb.dbias + n, b);
+        }
+      }
+    }
+    bsum[0] = 0.f; bsum[1] = 0.f;
+    ep_pending = false;
+  };
+
+  // ---- prologue: two groups in flight, the third step's pieces prepared
+  for (int i = 0; i < STAGES - 1; ++i) {
+    dma_prepare();
+    dma_issue();
+    issue_advance();
+  }
+  dma_prepare();
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __syncthreads();
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier interval behind group 0
+
+  int rd_slot = 0;
+  for (int gc = 0; gc < total; ++gc) {
+    const TnwJob& jb = g.job[cj];
+    const bool bias_tile = jb.dbias != nullptr && (ctile % jb.tiles_k) == 0;
+    // ================= issue segment: the step's 32 transpose reads, the 6 pieces of the step after next, a finished tile's stores
+    if (ep_pending) flush();
+    {
+      const char* rst = smem + rd_slot * STAGE_B;
+      if constexpr (DBG != 3) {
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fb[sx][r] = F::load_at(rst, ob[r] + sx * 8192, ob[r] + sx * 8192 + 1024);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fa[sx][r] = F::load_at(rst, oa[r] + sx * 8192, oa[r] + sx * 8192 + 1024);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    dma_issue();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= MFMA segment; the cursors and the next pieces' addresses move in its gaps
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int ms = i >> 4, r = i & 15, ni = r >> 2, ki = r & 3;
+      if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(fb[ms][ki], fa[ms][ni], acc[ni][ki]);     // D[k][n]
+      else asm volatile("" :: "v"(fb[ms][ki]), "v"(fa[ms][ni]));
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 2) {   // the stream moves one step on
+        asm volatile("" : "+s"(is_ls));
+        issue_advance();
+        asm volatile("" : "+s"(is_ls));
+      }
+      if (i == 6) {
+        dma_prepare();
+#pragma unroll
+        for (int sb = 0; sb < 3; ++sb) { asm volatile("" : "+v"(dof[sb][0])); asm volatile("" : "+v"(dof[sb][1])); }
+      }
+      if (i >= 8 && i < 24 && bias_tile) {   // column sums of dY from the fragments being multiplied: one fragment element pair per gap
+        const bool two = jb.wide_n != 0;
+        const int idx = i - 8, ms_ = idx >> 3, h = (idx >> 2) & 1, e = idx & 3;
+        const int blk = two ? 2 * wk + h : wk;
+        if (h == 0 || two) {
+          const typename F::Frag v = blk == 0 ? fa[ms_][0] : (blk == 1 ? fa[ms_][1] : (blk == 2 ? fa[ms_][2] : fa[ms_][3]));
+          const bf16x2_t pr = {v[2 * e], v[2 * e + 1]};
+          bsum[h] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum[h], false);
+        }
+      }
+      if (i == 26) {   // the compute cursor moves on; a finished tile is handed to the next issue segment
+        asm volatile("" : "+s"(cls));
+        const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
+        const bool range_end = cls + 1 == total;
+        if (tile_end || range_end) {
+          ep_pending = true;
+          ep_whole = seg0 == 0 && tile_end;
+          ep_slot = seg0 != 0 ? 0 : 1;
+          ep_j = cj; ep_tile = ctile; ep_wn = wn; ep_wk = wk; ep_bias = bias_tile;
+        }
+        const int nls = cls + 1;
+        const bool jump = nls == WS && nls < total;
+        const bool moved = (jump || tile_end) && !range_end;
+        cgt = jump ? gt_rem : (tile_end ? cgt + 1 : cgt);
+        cm = jump ? m_rem : (tile_end ? 0 : cm + 1);
+        seg0 = jump ? m_rem : (tile_end ? 0 : seg0);
+        cls = nls;
+        rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
+        if (moved) {
+          const int pj = cj;
+          tnw_locate_tile(g, cgt, cj, ctile);
+          if (g.job[cj].wide_n != g.job[pj].wide_n) set_wave_layout(g.job[cj].wide_n);   // the next step reads with the new wave layout
+        }
+        asm volatile("" : "+s"(cls));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (ep_pending) flush();
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 #endif  // SPG_DEV_KERNELS (wide grouped wgrad kernel)
 
 // ------------------------------------------------------------------------------------------------
@@ -3845,7 +4135,19 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
       hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
       attrw = true;
     }
-    if (dbgw == 2) hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
+    static const int widemode = dev_env("SPG_TN_GROUP_WIDE", 0);
+    if (widemode == 2) {
+      static bool attrp = false;
+      if (!attrp) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_pp_kernel<bf16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_pp_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_pp_kernel<bf16_t, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
+        attrp = true;
+      }
+      if (dbgw == 2) hipLaunchKernelGGL((gemm_tn_wide_pp_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
+      else if (dbgw == 3) hipLaunchKernelGGL((gemm_tn_wide_pp_kernel<bf16_t, 3>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
+      else hipLaunchKernelGGL((gemm_tn_wide_pp_kernel<bf16_t, 0>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
+    } else if (dbgw == 2) hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
     else hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 0>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
     int rc = check_launch("gemm_tn_group(wide)");
     if (reduce_desc_out) { TnReduceDesc d; memset(&d, 0, sizeof(d)); memcpy(reduce_desc_out, &d, sizeof(d)); }   // reduced right here

@@ -184,6 +184,15 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
         ldw = K
         _c(dw)
     assert ldw % 4 == 0 or ldw == K, ldw
+    if conv is not None and x.dtype == torch.bfloat16 and ldw == K:
+        # bf16 3x3 convolutions: the LDS-resident-tile kernel (csrc/conv_halo.hip) when it has an instance for the shape
+        hb = _lib.load().spg_conv3x3_wgrad_workspace_bytes(dcode(x), B, H, W, Ci, N, cu_budget_now())
+        if hb > 0:
+            hws = torch.empty(hb, dtype=torch.uint8, device=x.device)
+            with _prof("gemm_tn<bf16,conv3x3> (+reduce)", "mfma", 2.0 * M * N * K):
+                _lib.call("spg_conv3x3_wgrad", dcode(x), _p(_c(dy)), _p(_c(x)), dw.data_ptr(), _p(dbias), _p(hws), hb, B, H, W, Ci, N,
+                          cu_budget_now(), _stream())
+            return
     wsb = _lib.load().spg_gemm_tn_workspace_bytes(dcode(x), M, N, K)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
     tag = "bf16" if x.dtype == torch.bfloat16 else "f32"

@@ -865,3 +865,31 @@ def test_conv3x3_fwd_stats_matches_conv_then_bn_stats(ops, B, H, W, Ci, Co):
     xf = ref.float()
     check(mi1[:Co], xf.mean(0), 1e-4, "mean")
     check(mi1[Co:], (xf.var(0, unbiased=False) + 1e-5).rsqrt(), 1e-4, "invstd")
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 9, 33, 64, 64), (3, 17, 31, 128, 320), (2, 48, 48, 256, 64), (8, 96, 96, 64, 128), (4, 200, 96, 64, 64)])
+def test_conv3x3_wgrad_halo_matches_torch(ops, B, H, W, Ci, Co):
+    """bf16 3x3 weight gradient on LDS-resident tiles (spg_conv3x3_wgrad: per-workgroup partial blocks + fixed-order reduce) against
+    torch's conv2d weight gradient in fp32 on the same bf16-rounded operands; the fused bias gradient against the column sums.
+    Ragged tiles, several (co tile, ci chunk) blocks, more pixel tiles than workgroups, and accumulation into a non-zero dW.
+    Two runs must agree bit for bit (no float atomics)."""
+    dt = torch.bfloat16
+    x = rnd(B, Ci, H, W, seed=1).to(dt).float()
+    dy = rnd(B, Co, H, W, seed=4).to(dt).float()
+    w = torch.zeros(Co, Ci, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dt)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(dt)
+    assert ops._lib.load().spg_conv3x3_wgrad_workspace_bytes(1, B, H, W, Ci, Co, 0) > 0
+    outs = []
+    for rep in range(2):
+        dwp = torch.full((Co, 9 * Ci), 0.5, device="cuda")
+        dbc = torch.full((Co,), -1.0, device="cuda")
+        ops.gemm_tn(dyn, xn, dwp, conv=(B, H, W, Ci), dbias=dbc)
+        outs.append((dwp, dbc))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dwp, dbc = outs[0]
+    dwt = torch.zeros(Co, Ci, 3, 3, device="cuda")
+    ops.unpack_conv3x3_grad(dwp - 0.5, dwt)
+    check(dwt, w.grad, 2e-3, "conv wgrad (halo)")
+    check(dbc + 1.0, dyn.float().sum((0, 1, 2)), 1e-4, "conv fused bias grad (halo)")

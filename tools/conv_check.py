@@ -75,6 +75,31 @@ def main():
         print(line, flush=True)
     if tot_t:
         print(f"sum of timed shapes: {tot_t*1e3:.3f} ms, {tot_f/tot_t/1e12:.0f} TF")
+    if "wgrad" in sys.argv:
+        from spegnet_amd import _lib
+        WG = [(8, 48, 48, 256, 64, "EFE"), (8, 96, 96, 320, 256, "s1 conv1"), (8, 96, 96, 256, 256, "s1 conv2"), (8, 192, 192, 320, 128, "s2 conv1"),
+              (8, 192, 192, 128, 128, "s2 conv2"), (8, 384, 384, 128, 64, "s3 conv1"), (8, 384, 384, 64, 64, "s3 conv2")]
+        tn, to, tf = 0.0, 0.0, 0.0
+        for B, H, W_, Ci, Co, tag in WG:
+            x = torch.randn(B, H, W_, Ci, device="cuda", generator=g).to(dt)
+            dy = torch.randn(B, H, W_, Co, device="cuda", generator=g).to(dt)
+            M, K = B * H * W_, 9 * Ci
+            dw_new, dw_old = torch.zeros(Co, K, device="cuda"), torch.zeros(Co, K, device="cuda")
+            db = torch.zeros(Co, device="cuda")
+            ops.gemm_tn(dy, x, dw_new, conv=(B, H, W_, Ci), dbias=db)
+            wsb = _lib.load().spg_gemm_tn_workspace_bytes(1, M, Co, K)
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+            old = lambda: _lib.call("spg_gemm_tn", 1, dy.data_ptr(), x.data_ptr(), dw_old.data_ptr(), None, ws.data_ptr(), wsb, M, Co, K, Co, Ci, K,
+                                    1, B, H, W_, Ci, 0, torch.cuda.current_stream().cuda_stream)
+            old()
+            torch.cuda.synchronize()
+            e = float((dw_new - dw_old).abs().max() / dw_old.abs().max())
+            t_new = timeit(lambda: ops.gemm_tn(dy, x, dw_new, conv=(B, H, W_, Ci), dbias=db))
+            t_old = timeit(old)
+            fl = 2.0 * M * Co * K
+            tn += t_new; to += t_old; tf += fl
+            print(f"wgrad {tag:9s} B{B} {H}x{W_} {Ci}->{Co} new vs old rel diff {e:.1e} | halo {t_new*1e6:8.1f}us {fl/t_new/1e12:5.0f} TF | implicit GEMM {t_old*1e6:8.1f}us {fl/t_old/1e12:5.0f} TF", flush=True)
+        print(f"wgrad sum: halo {tn*1e3:.3f} ms ({tf/tn/1e12:.0f} TF), implicit GEMM {to*1e3:.3f} ms ({tf/to/1e12:.0f} TF)")
     print("worst", worst)
     assert worst < 2.5e-2, worst
 
