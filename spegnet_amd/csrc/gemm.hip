@@ -64,6 +64,13 @@ struct ConvGeom {
 // conv_halo.hip: bf16 3x3 convolution with an LDS-resident input tile; returns 1 when the problem is outside its domain
 int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bias, int B, int H, int W, int Ci, int Co, int ldc,
                         int cus, int force_bn, hipStream_t s, float* stats);
+#ifdef SPG_DEV_KERNELS
+// tn_block.hip (dev builds): grouped weight gradients with 256 x 192 blocks per workgroup (every N, K a multiple of 192); returns 1 when not applicable
+int launch_tn_block_group(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
+                          const int* K, const int* ldy, const int* ldx, const int* ldw, void* workspace, long workspace_bytes, int cus,
+                          hipStream_t s);
+long tn_block_workspace_bytes(int cus);
+#endif
 
 // Branch-free operand loads: raw buffer loads with hardware bounds checking (out-of-range offsets return 0), so
 // hipcc keeps every load of a K-tile in flight behind a counted vmcnt instead of branching around each one
@@ -4081,7 +4088,10 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
 }
 
 #ifdef SPG_DEV_KERNELS
-extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus() * 2 * TNW_SLOT_FLOATS * (long)sizeof(float); }   // covers both kernels
+extern "C" long spg_gemm_tn_group_workspace_bytes(void) {   // covers every kernel of the family
+  const long a_ = (long)num_cus() * 2 * TNW_SLOT_FLOATS * (long)sizeof(float), b_ = tn_block_workspace_bytes(num_cus());
+  return a_ > b_ ? a_ : b_;
+}
 #else
 extern "C" long spg_gemm_tn_group_workspace_bytes(void) { return (long)num_cus() * 2 * TN_SLOT_FLOATS * (long)sizeof(float); }
 #endif
@@ -4093,6 +4103,20 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   SPG_REQUIRE(dtype == SPG_BF16, "gemm_tn_group: bf16 only (dtype %d)", dtype);
   SPG_REQUIRE(njobs >= 1 && njobs <= TN_GROUP_MAX, "gemm_tn_group: 1..%d problems, got %d", TN_GROUP_MAX, njobs);
   SPG_REQUIRE(M > 0, "gemm_tn_group: empty M");
+#ifdef SPG_DEV_KERNELS
+  // opt-in (SPG_TN_BLOCK=1): one 256 x 192 block of dW per workgroup (tn_block.hip) for problem sets whose every N and K is a multiple of 192.
+  // MEASURED: its main kernel takes 52.4 us on a stage-3 block against 65 for the tile kernel, but its partial blocks (49 MB of slabs)
+  // need their own reduce launch per trunk block (14.5 us) where the tile kernel's boundary reduces are deferred and batched: the
+  // train step is 23.40 ms with it and 23.39 ms without (same box).  Kept out of the product library.
+  if (dev_env("SPG_TN_BLOCK", 0) != 0 && dev_env("SPG_TN_GROUP_WIDE", 0) == 0) {
+    const int rcb = launch_tn_block_group(njobs, dY, X, dW, dbias, M, N, K, ldy, ldx, ldw, workspace, workspace_bytes, num_cus(cu_budget),
+                                          (hipStream_t)stream);
+    if (rcb != 1) {
+      if (reduce_desc_out) { TnReduceDesc d; memset(&d, 0, sizeof(d)); memcpy(reduce_desc_out, &d, sizeof(d)); }   // reduced right here
+      return rcb;
+    }
+  }
+#endif
 #ifdef SPG_DEV_KERNELS
   // opt-in (SPG_TN_GROUP_WIDE=1): measured no faster than the 128 x 128 grouped kernel on the stage-3 / stage-4 blocks (97.1 vs 96.5,
   // 96.7 vs 92.6 us), better only at stage 1 (139 vs 157 us) -- see the kernel's header and DESIGN.md 3.1

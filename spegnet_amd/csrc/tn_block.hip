@@ -1,0 +1,351 @@
+// Grouped weight-gradient GEMM for the wide trunk stages:  dW[N,K] += dY[M,N]^T X[M,K]  (+ dbias[N] += column sums of dY) for the
+// four Linear layers of a Hiera block at once (reference: autograd of the nn.Linear layers of sam2's MultiScaleBlock, reached through
+// models/feature_encoding.py:236), when every N and K is a multiple of 192 (stage 3: 576 / 1728 / 2304, stage 4: 1152 / 3456 / 4608).
+//
+// Why a second kernel beside gemm_tn_group4_kernel (gemm.hip): that one is bound by operand re-reads -- every 128 x 128 tile streams its
+// own dY and X panels (573 MB through L2 per stage-3 block, 2.8x the algorithmic bytes, profiles/round2_bench_kernel_stats.md) -- and by
+// its per-workgroup partial tiles.  Here, with the structure of the convolution weight gradient in conv_halo.hip:
+//   * a workgroup owns ONE 256 x 192 block of some dW (the 192 side along the layer's 576-multiple dimension: 84 blocks for a stage-3
+//     block against 243 tiles, 3.7 % padding) and a contiguous range of M; its 96 accumulator registers per lane live across the whole
+//     range, one partial block per workgroup goes to a slab at the end and a small kernel adds the slabs in a fixed order
+//     (deterministic).  Panel traffic per block drops to 0.58x.
+//   * K (= M here) advances in 32-row slices: seven [32][64] bf16 sub-tiles (4 dY + 3 X or 3 + 4), 28 KiB, in a 5-slot ring (three slices
+//     in flight behind the one being read); fragments by ds_read_b64_tr_b16 from 128-byte rows with the conflict-free column key of
+//     conv_halo.hip; MFMA roles A = X (rows k), B = dY (cols n): D[k][n], a lane holds 4 consecutive k of one n.
+//   * two wave groups one barrier apart: while one issues its 24-MFMA cluster the other issues the next slice's 20 transpose reads and
+//     its share of the 28 LDS-DMA pieces; all per-slice address arithmetic sits in the gaps of the MFMA cluster.
+// STATUS: a measured experiment, compiled into the dev library only (python spegnet_amd/build.py --dev, SPG_TN_BLOCK=1).  Correct
+// (tests/test_kernels_gpu.py::test_gemm_tn_group passes through it) and its main kernel is 20 % faster than the tile kernel on a stage-3
+// block (52.4 vs 65 us), but the 49 MB of per-workgroup partial blocks cost a 14.5 us reduce launch per trunk block that the tile kernel's
+// deferred, batched boundary reduce does not pay: the train step does not move (23.40 vs 23.39 ms on one box).  What it would take:
+// the first M split adding straight into dW and a batched reduce across blocks.
+#include <algorithm>
+#include <type_traits>
+#include "common.h"
+
+#ifdef SPG_DEV_KERNELS
+namespace spg {
+
+typedef __attribute__((ext_vector_type(4))) unsigned tbrsrc_t;
+typedef __attribute__((ext_vector_type(4))) short tbs16x4_t;
+typedef __attribute__((ext_vector_type(8))) short tbs16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 tbbf16x2_t;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned tbbufvec_t;
+
+__device__ __forceinline__ tbrsrc_t tb_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  tbrsrc_t r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void tb_dma16(tbrsrc_t rsrc, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ int tb_key(int x) { return (x & 7) ^ (((x >> 3) & 1) << 2); }
+__device__ __forceinline__ bf16x8_t tb_frag(const char* base, unsigned o0, unsigned o1) {
+  const tbs16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tbs16x4_t*)(base + o0));
+  const tbs16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tbs16x4_t*)(base + o1));
+  const tbs16x8_t v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+constexpr int TB_MAX_JOBS = 8;
+constexpr int TB_SUB = 32 * 128;                 // one [32][64] bf16 sub-tile
+constexpr int TB_SLOT = 7 * TB_SUB;              // one 32-row slice of a block's operands
+constexpr int TB_NSLOT = 5;
+constexpr int TB_LDS_BYTES = TB_NSLOT * TB_SLOT;
+constexpr int TB_SLAB_FLOATS = 256 * 192;
+constexpr unsigned TB_DEAD = 0x80000000u;
+
+struct TbJob {
+  const bf16_t* dY; const bf16_t* X; float* dW; float* dbias;
+  int N, K, ldy, ldx, ldw;
+  int wide_n;                // 1: block = 256 (n) x 192 (k); 0: 192 (n) x 256 (k)
+  int tiles_b, tiles, tile0; // tiles along the 192 side, tiles of this job, first block id
+};
+struct TbGroup {
+  TbJob job[TB_MAX_JOBS];
+  int njobs, M, T, NB, S;    // T = 32-row slices of M, NB blocks in all, S splits of M per block
+};
+
+template <bool WIDE_N>
+__device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int ta, int tb, int split, char* smem, float* __restrict__ slab,
+                                        float* __restrict__ bslab) {
+  constexpr int KA = WIDE_N ? 6 : 4;           // k blocks (16) per wave
+  constexpr int NBk = WIDE_N ? 4 : 6;          // n blocks per wave
+  constexpr int NYS = WIDE_N ? 4 : 3;          // dY sub-tiles of a slice (X: 7 - NYS)
+  constexpr int NM = KA * NBk;                 // 24 MFMAs per slice
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wk = WIDE_N ? (wave & 1) : (wave & 3), wn = WIDE_N ? (wave >> 1) : (wave >> 2);
+  const int q = lane >> 4, ra = (lane & 15) >> 2, rb = lane & 3;
+  const int n0 = (WIDE_N ? ta * 256 : tb * 192), k0 = (WIDE_N ? tb * 192 : ta * 256);
+  const int s0 = (int)((long)split * g.T / g.S), s1 = (int)((long)(split + 1) * g.T / g.S);
+  const int nsl = s1 - s0;
+  const tbrsrc_t yr = tb_rsrc(jb.dY, (unsigned)(((long)(g.M - 1) * jb.ldy + jb.N) * 2)), xr = tb_rsrc(jb.X, (unsigned)(((long)(g.M - 1) * jb.ldx + jb.K) * 2));
+  const unsigned smem_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- fragment read offsets in slot 0: block-local column c lives in sub-tile c / 64 (dY sub-tiles first), 16-column group (c % 64) / 16
+  unsigned xa[KA][2], ya[NBk][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = 8 * q + ra + 4 * r;
+#pragma unroll
+    for (int kb = 0; kb < KA; ++kb) {
+      const int col = wk * (KA * 16) + kb * 16;
+      xa[kb][r] = (unsigned)((NYS + (col >> 6)) * TB_SUB + row * 128 + (((2 * ((col & 63) >> 4) + (rb >> 1)) ^ tb_key(row)) << 4) + (rb & 1) * 8);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NBk; ++nb) {
+      const int col = wn * (NBk * 16) + nb * 16;
+      ya[nb][r] = (unsigned)((col >> 6) * TB_SUB + row * 128 + (((2 * ((col & 63) >> 4) + (rb >> 1)) ^ tb_key(row)) << 4) + (rb & 1) * 8);
+    }
+  }
+  // ---- LDS-DMA: the 28 pieces of a slice (7 sub-tiles x 4 pieces of 8 rows) are dealt pc = wave, wave + 8, ...: 4 pieces for waves 0-3, 3 for 4-7
+  // piece pc: sub-tile pc >> 2, rows 8 (pc & 3) + lane / 8; a lane fetches logical chunk (lane & 7) ^ key(row)
+  const int npc = wave < 4 ? 4 : 3;
+  unsigned pbase[4];          // source offset of piece i for slice 0 of M (row part + column part), TB_DEAD when the columns are outside
+  unsigned pstride[4];        // bytes per slice (32 rows)
+  unsigned pdst[4];           // LDS offset inside a slot
+  tbrsrc_t prs[4];            // ... and the descriptor it reads through (dY or X)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pc = wave + 8 * i;
+    const int st = pc >> 2, row = 8 * (pc & 3) + (lane >> 3);
+    const int chunk = (lane & 7) ^ tb_key(row);
+    const bool isy = st < NYS;
+    const int col = (isy ? n0 + 64 * st : k0 + 64 * (st - NYS)) + chunk * 8;
+    const int ld = isy ? jb.ldy : jb.ldx;
+    const bool inside = pc < 28 && col < (isy ? jb.N : jb.K);
+    pbase[i] = inside ? (unsigned)((((long)s0 * 32 + row) * ld + col) * 2) : TB_DEAD;
+    pstride[i] = inside ? (unsigned)(32 * ld * 2) : 0u;
+    pdst[i] = (unsigned)(st * TB_SUB + (pc & 3) * 1024);
+    prs[i] = isy ? yr : xr;
+  }
+  // (rows past M: beyond the descriptors' extent -> zero fill; slices past the range: never issued as live pieces)
+  int is_slice = 0;            // slices issued so far
+  unsigned is_slot = 0;        // ring slot (byte offset) the next issue fills
+  auto issue = [&]() __attribute__((always_inline)) {
+    const bool live = is_slice < nsl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < npc) {
+        const unsigned off = live ? pbase[i] : TB_DEAD;
+        tb_dma16(prs[i], smem_base + is_slot + pdst[i], off);
+      }
+    }
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    ++is_slice;
+    is_slot = is_slot + TB_SLOT == (unsigned)TB_LDS_BYTES ? 0u : is_slot + TB_SLOT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pbase[i] += pstride[i];
+  };
+
+  f32x4 acc[KA][NBk];
+#pragma unroll
+  for (int i = 0; i < KA; ++i)
+#pragma unroll
+    for (int j = 0; j < NBk; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[NBk];
+#pragma unroll
+  for (int j = 0; j < NBk; ++j) bsum[j] = 0.f;
+  const tbbf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+  const bool do_bias = bslab != nullptr && wk == 0;
+
+  // ---- prologue: three slices in flight, the first landed
+  for (int i = 0; i < 3; ++i) { issue(); issue_advance(); }
+  if (wave < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __syncthreads();
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier interval behind group 0
+
+  bf16x8_t fx[KA], fy[NBk];
+  unsigned rd = 0;             // ring slot being read (tracked inside xa / ya: they are advanced in place)
+  for (int sl = 0; sl < nsl; ++sl) {
+    // ================= issue segment: 20 transpose reads, this wave's pieces of slice sl + 3
+#pragma unroll
+    for (int nb = 0; nb < NBk; ++nb) fy[nb] = tb_frag(smem, ya[nb][0], ya[nb][1]);
+#pragma unroll
+    for (int kb = 0; kb < KA; ++kb) fx[kb] = tb_frag(smem, xa[kb][0], xa[kb][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    issue();
+    __builtin_amdgcn_sched_barrier(0);
+    // slice sl + 1 has landed (this wave's pieces: two younger slices may stay in flight); this wave's reads have returned
+    if (wave < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= MFMA segment; the ring / stream bookkeeping sits in its gaps
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int kb = m / NBk, nb = m % NBk;
+      acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[kb], fy[nb], acc[kb][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m == 0) { asm volatile("" : "+s"(is_slice)); issue_advance(); asm volatile("" : "+s"(is_slice)); }
+      if (m == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pbase[i]));
+      }
+      if (m == 2) { rd = rd + TB_SLOT == (unsigned)TB_LDS_BYTES ? 0u : rd + TB_SLOT; asm volatile("" : "+s"(rd)); }
+      if (m >= 3 && m < 3 + KA) {   // the fragment offsets follow the ring
+        const int kb_ = m - 3;
+        const unsigned d = rd == 0u ? (unsigned)-(TB_LDS_BYTES - TB_SLOT) : (unsigned)TB_SLOT;
+        xa[kb_][0] += d; xa[kb_][1] += d;
+        asm volatile("" : "+v"(xa[kb_][0])); asm volatile("" : "+v"(xa[kb_][1]));
+      }
+      if (m >= 3 + KA && m < 3 + KA + NBk) {
+        const int nb_ = m - 3 - KA;
+        const unsigned d = rd == 0u ? (unsigned)-(TB_LDS_BYTES - TB_SLOT) : (unsigned)TB_SLOT;
+        ya[nb_][0] += d; ya[nb_][1] += d;
+        asm volatile("" : "+v"(ya[nb_][0])); asm volatile("" : "+v"(ya[nb_][1]));
+      }
+      if (do_bias && m >= 13 && m < 13 + NBk) {   // column sums of dY from the fragments in registers
+        const int nb_ = m - 13;
+        const bf16x8_t v = fy[nb_];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const tbbf16x2_t pr = {v[2 * e], v[2 * e + 1]};
+          bsum[nb_] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum[nb_], false);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- the workgroup's partial block: slab[n local][k local] (rows of 192 or 256 floats: the reduce kernel knows the orientation)
+  constexpr int KE = WIDE_N ? 192 : 256;
+#pragma unroll
+  for (int kb = 0; kb < KA; ++kb)
+#pragma unroll
+    for (int nb = 0; nb < NBk; ++nb) {
+      const int n = wn * (NBk * 16) + nb * 16 + (lane & 15), k = wk * (KA * 16) + kb * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(slab + n * KE + k) = acc[kb][nb];
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int nb = 0; nb < NBk; ++nb) {
+      float b = bsum[nb];
+      b += __shfl_xor(b, 16, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (q == 0) bslab[wn * (NBk * 16) + nb * 16 + (lane & 15)] = b;
+    }
+  }
+}
+
+__device__ __forceinline__ void tb_locate(const TbGroup& g, int blk, int& j, int& local) {
+  j = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.njobs; ++i) if (blk >= g.job[i].tile0) j = i;
+  local = blk - g.job[j].tile0;
+}
+
+__global__ __launch_bounds__(512) void tn_block_kernel(TbGroup g, float* __restrict__ slabs, float* __restrict__ bslabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // workgroups that share an XCD (blockIdx % 8: one L2) get a contiguous range of ids, and ids run block-fastest inside a split: the
+  // ~32 workgroups of an XCD then walk the SAME rows of M through blocks that share dY / X panels (a layer's 9 x 3 blocks read 12 panels,
+  // not 54), so most of their fill is served by that L2 instead of once per block from beyond it
+  int wid;
+  {
+    const int nwg = (int)gridDim.x, bid = blockIdx.x;
+    const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, i = bid >> 3;
+    wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + i;
+  }
+  const int split = wid / g.NB, blk = wid - split * g.NB;
+  const int wgid = blk * g.S + split;          // slab index: the reduce kernel walks a block's splits
+  int j, local;
+  tb_locate(g, blk, j, local);
+  const TbJob& jb = g.job[j];
+  const int ta = local / jb.tiles_b, tb = local - ta * jb.tiles_b;
+  float* slab = slabs + (long)wgid * TB_SLAB_FLOATS;
+  // the bias gradient: by the blocks at the first k position of their n range
+  const bool bias_blk = jb.dbias != nullptr && (jb.wide_n ? tb == 0 : ta == 0);
+  float* bslab = bias_blk ? bslabs + (long)wgid * 256 : nullptr;
+  if (jb.wide_n) tb_body<true>(g, jb, ta, tb, split, smem, slab, bslab);
+  else tb_body<false>(g, jb, ta, tb, split, smem, slab, bslab);
+}
+
+// dW[n0 + n][k0 + k] += sum over the S splits of block blk (split order); dbias likewise
+__global__ __launch_bounds__(256) void tn_block_reduce_kernel(TbGroup g, const float* __restrict__ slabs, const float* __restrict__ bslabs) {
+  const int blk = blockIdx.y;
+  int j, local;
+  tb_locate(g, blk, j, local);
+  const TbJob& jb = g.job[j];
+  const int ta = local / jb.tiles_b, tb = local - ta * jb.tiles_b;
+  const int n0 = jb.wide_n ? ta * 256 : tb * 192, k0 = jb.wide_n ? tb * 192 : ta * 256;
+  const int KE = jb.wide_n ? 192 : 256, NE = jb.wide_n ? 256 : 192;
+  const int v = blockIdx.x * 256 + threadIdx.x;          // float4 index inside the block
+  if (v < TB_SLAB_FLOATS / 4) {
+    const int kq = KE / 4;
+    const int n = v / kq, k = (v - n * kq) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* base = slabs + (long)blk * g.S * TB_SLAB_FLOATS + v * 4;
+    for (int p = 0; p < g.S; ++p) s += *reinterpret_cast<const f32x4*>(base + (long)p * TB_SLAB_FLOATS);
+    if (n0 + n < jb.N && k0 + k < jb.K && n < NE) {
+      float* d = jb.dW + (long)(n0 + n) * jb.ldw + k0 + k;
+      *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
+    }
+  }
+  if (jb.dbias && (jb.wide_n ? tb == 0 : ta == 0) && blockIdx.x == 0 && threadIdx.x < NE) {
+    float b = 0.f;
+    for (int p = 0; p < g.S; ++p) b += bslabs[((long)blk * g.S + p) * 256 + threadIdx.x];
+    if (n0 + threadIdx.x < jb.N) jb.dbias[n0 + threadIdx.x] += b;
+  }
+}
+
+// bytes of workspace the block kernel needs for `cus` workgroups (an upper bound for every problem set it accepts)
+long tn_block_workspace_bytes(int cus) { return (long)cus * (TB_SLAB_FLOATS + 256) * 4L; }
+
+// returns SPG_OK / an error, or 1 when the problem set is outside this kernel's domain (the caller uses gemm_tn_group4_kernel)
+int launch_tn_block_group(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
+                          const int* K, const int* ldy, const int* ldx, const int* ldw, void* workspace, long workspace_bytes, int cus,
+                          hipStream_t s) {
+  if (njobs < 1 || njobs > TB_MAX_JOBS || M < 256) return 1;
+  TbGroup g;
+  long nb = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (N[i] % 192 != 0 || K[i] % 192 != 0 || ldy[i] % 8 != 0 || ldx[i] % 8 != 0 || ldw[i] % 4 != 0) return 1;
+    if ((long)M * ldy[i] * 2 >= 0x7FFFFFF0L || (long)M * ldx[i] * 2 >= 0x7FFFFFF0L) return 1;
+    TbJob& jb = g.job[i];
+    jb.dY = (const bf16_t*)dY[i]; jb.X = (const bf16_t*)X[i]; jb.dW = dW[i]; jb.dbias = dbias ? dbias[i] : nullptr;
+    jb.N = N[i]; jb.K = K[i]; jb.ldy = ldy[i]; jb.ldx = ldx[i]; jb.ldw = ldw[i];
+    const long tn_ = (long)cdiv(N[i], 256) * (K[i] / 192), tk_ = (long)(N[i] / 192) * cdiv(K[i], 256);
+    jb.wide_n = tn_ <= tk_ ? 1 : 0;            // the orientation with fewer (less padded) blocks
+    jb.tiles_b = jb.wide_n ? K[i] / 192 : N[i] / 192;
+    jb.tiles = (int)(jb.wide_n ? tn_ : tk_);
+    jb.tile0 = (int)nb;
+    nb += jb.tiles;
+  }
+  for (int i = njobs; i < TB_MAX_JOBS; ++i) g.job[i] = g.job[njobs - 1];
+  if (nb > cus) return 1;                       // (stage 4 at batch 8: 330 blocks of 18 slices pairs -- the tile kernel balances those better)
+  const int T = cdiv(M, 32);
+  int S = (int)(cus / nb);
+  if (S > T / 16) S = T / 16;                   // at least 16 slices per workgroup
+  if (S < 1) return 1;
+  g.njobs = njobs; g.M = M; g.T = T; g.NB = (int)nb; g.S = S;
+  const long need = nb * S * (long)(TB_SLAB_FLOATS + 256) * 4L;
+  if (!workspace || workspace_bytes < need) return 1;
+  float* slabs = (float*)workspace;
+  float* bslabs = slabs + nb * S * (long)TB_SLAB_FLOATS;
+  static bool attr_ = false;
+  if (!attr_) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES);
+    attr_ = true;
+  }
+  hipLaunchKernelGGL(tn_block_kernel, dim3((unsigned)(nb * S)), dim3(512), TB_LDS_BYTES, s, g, slabs, bslabs);
+  int rc = check_launch("tn_block");
+  if (rc) return rc;
+  hipLaunchKernelGGL(tn_block_reduce_kernel, dim3(TB_SLAB_FLOATS / 4 / 256, (unsigned)nb), dim3(256), 0, s, g, (const float*)slabs, (const float*)bslabs);
+  return check_launch("tn_block(reduce)");
+}
+
+}  // namespace spg
+#endif  // SPG_DEV_KERNELS
