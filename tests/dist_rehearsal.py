@@ -1,7 +1,7 @@
 """Two-rank rehearsal of the multi-GPU train step on ONE GPU (gloo backend; RCCL needs one GPU per rank).  Launched by
 tests/test_distributed_gpu.py as two child processes BEFORE the parent touches the GPU.
 
-Each rank trains the tiny SPEGNet on ITS OWN batch with the segmented hipGraph step (forward + loss + backward captured in segments, the
+Each rank trains the tiny SPEGNet (fp32 compute) -- or, with `large`, the full Hiera-L block table in bf16 compute at 64 px -- on ITS OWN batch with the segmented hipGraph step (forward + loss + backward captured in segments, the
 all-reduce of finished gradient ranges between them on a side stream, bf16 payload or fp32) and, for comparison, rank 0 recomputes what
 data parallelism must produce: the gradients of both batches from two single-rank eager passes, averaged, one clip + AdamW step.
 Prints one JSON line per rank."""
@@ -18,6 +18,7 @@ import torch  # noqa: E402
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "graph"          # graph | eager
     payload = sys.argv[2] if len(sys.argv) > 2 else "fp32"         # fp32 | bf16
+    variant = sys.argv[3] if len(sys.argv) > 3 else "tiny"         # tiny (fp32 compute, 128 px) | large (bf16 compute, Hiera-L block table, 64 px)
     from oracle import spegnet_oracle as O
     from spegnet_amd.engine.arena import Arena
     from spegnet_amd.engine.distributed import GradSync, init_process_group_from_env
@@ -27,11 +28,12 @@ def main():
     import torch.distributed as dist
     rank, world, local = init_process_group_from_env("cuda")
     torch.cuda.set_device(0)
-    cfg = O.HIERA_TINY_TEST
+    large = variant == "large"
+    cfg = O.HIERA_L if large else O.HIERA_TINY_TEST
     sd = O.init_state_dict(seed=3, cfg=cfg)
 
     def fresh():
-        m = SPEGNet({"encoder": {"variant": "test_tiny"}, "compute_dtype": "fp32"})
+        m = SPEGNet({"encoder": {"variant": "large" if large else "test_tiny"}, "compute_dtype": "bf16" if large else "fp32"})
         m.load_state_dict(sd)
         m = m.cuda().train()
         ar = Arena(m)
@@ -39,14 +41,14 @@ def main():
         ar.set_hyper(1e-3, 1e-2, 0.5)
         return m, ar
 
-    batches = [O.synthetic_batch(4, 128, seed=80 + r) for r in range(world)]
+    batches = [O.synthetic_batch(2, 64, seed=80 + r) if large else O.synthetic_batch(4, 128, seed=80 + r) for r in range(world)]
     dev = lambda b: (b[0].cuda(), torch.stack(b[1]).cuda(), torch.stack(b[2]).cuda())
     m, ar = fresh()
     sync = GradSync(ar.g, ar.unit_ends, compress_bf16=(payload == "bf16"))
     step = TrainStep(m, CODLoss().cuda(), ar, grad_clip=1.0, sync=sync, capture=(mode == "graph"))
     out = step(*dev(batches[rank]))
     torch.cuda.synchronize()
-    res = {"rank": rank, "mode": mode, "payload": payload, "loss": float(out["loss"]), "gnorm": float(ar.gnorm_sq.sqrt()),
+    res = {"rank": rank, "mode": mode, "payload": payload, "variant": variant, "loss": float(out["loss"]), "gnorm": float(ar.gnorm_sq.sqrt()),
            "segments": len(step.segments) if step.segments else 0}
     # every rank must hold the same parameters after the step
     p = ar.p.detach().clone()

@@ -21,13 +21,13 @@ def _free_port():
     return p
 
 
-def _run(mode, payload, world=2):
+def _run(mode, payload, world=2, variant="tiny"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SPG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_rehearsal.py"), mode, payload], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_rehearsal.py"), mode, payload, variant], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -60,3 +60,16 @@ def test_two_rank_step_equals_averaged_single_rank_gradients(mode, payload):
     assert r0["frac_updates_differ"] < tol, res
     # (arena.gnorm_sq is the norm of the SUMMED gradient; the 1/world scale is applied inside the optimizer kernel)
     assert abs(r0["gnorm"] / 2 - r0["gnorm_ref"]) < (2e-3 if payload == "fp32" else 2e-2) * r0["gnorm_ref"], res
+
+
+def test_two_rank_step_bf16_compute_hiera_large_block_table():
+    """The same rehearsal on the shipping configuration's code path: bf16 compute, the 48-block Hiera-L table (stage widths 144..1152,
+    global-attention blocks, all four pooling transitions), 64 px inputs, bf16 wire payload -- the segment boundaries and bucket ends are
+    the ones bench.py --gpus N uses."""
+    res = _run("graph", "bf16", variant="large")
+    assert all(v["ranks_agree"] for v in res.values()), res
+    r0 = res[0]
+    assert r0["segments"] >= 4, r0
+    assert r0["loss"] == r0["loss"]
+    assert r0["frac_updates_differ"] < 0.10, res
+    assert abs(r0["gnorm"] / 2 - r0["gnorm_ref"]) < 3e-2 * r0["gnorm_ref"], res
