@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspegnet_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "conv_halo.hip", "tn_block.hip", "attention.hip", "norm.hip", "elem.hip", "head.hip", "easpp.hip", "loss.hip", "optim.hip"]
+SOURCES = ["core.hip", "gemm.hip", "conv_halo.hip", "nt_wide.hip", "tn_block.hip", "attention.hip", "norm.hip", "elem.hip", "head.hip", "easpp.hip", "loss.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-inline-asm", "-munsafe-fp-atomics"]
 
 

@@ -65,6 +65,9 @@ struct ConvGeom {
 int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bias, int B, int H, int W, int Ci, int Co, int ldc,
                         int cus, int force_bn, hipStream_t s, float* stats);
 #ifdef SPG_DEV_KERNELS
+// nt_wide.hip (dev builds): dense bf16 NT GEMM on 192-column tiles of variable height (act = PIPE_ACT_* code); returns 1 when the problem is outside its domain
+int launch_nt_wide(const void* X, const void* W, void* C, const float* bias, const void* Hh, void* C2, int act, int M, int N, int K, int ldx,
+                   int ldc, int cus, int dbg, hipStream_t s);
 // tn_block.hip (dev builds): grouped weight gradients with 256 x 192 blocks per workgroup (every N, K a multiple of 192); returns 1 when not applicable
 int launch_tn_block_group(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
                           const int* K, const int* ldy, const int* ldx, const int* ldw, void* workspace, long workspace_bytes, int cus,
@@ -3588,6 +3591,30 @@ static int try_conv_halo(const void* X, const void* W, void* C, const NtEpi& epi
   return launch_conv3x3_halo(X, W, C, epi.bias, g.B, g.H, g.W, g.Ci, N, ldc, cus, force, s, nullptr);
 }
 
+// Dev builds, SPG_NT_WIDE=1: dense bf16 problems with a wide output and no residual go to the 192-column variable-height kernel
+// (nt_wide.hip) when its plan fills the CUs; 1 = not taken.  A measured experiment (no gain in the step), not a product path.
+static int try_nt_wide(const void* X, const void* W, void* C, const NtEpi& epi, int M, int N, int K, int ldx, int ldc, int conv, int cus,
+                       hipStream_t s) {
+#ifdef SPG_DEV_KERNELS
+  static const int mode = dev_env("SPG_NT_WIDE", 0);
+  if (mode == 0) return 1;
+  if (conv || epi.residual || epi.act == SPG_ACT_RELU) return 1;
+  int pact;
+  if (epi.gelu_h) {
+    if (epi.act != SPG_ACT_MUL_H) return 1;
+    pact = 4;   // PIPE_ACT_MULH
+  } else {
+    pact = epi.act == SPG_ACT_GELU ? 1 : (epi.act == SPG_ACT_GELU_SAVE_GRAD ? 3 : (epi.act == SPG_ACT_NONE ? 0 : -1));
+    if (pact < 0) return 1;
+  }
+  static const int dbg = dev_env("SPG_NT_WIDE_DBG", 0);   // 5: in-kernel stamps (tools/ntw_stamps.py)
+  return launch_nt_wide(X, W, C, epi.bias, epi.gelu_h, epi.C2, pact, M, N, K, ldx, ldc, cus, dbg, s);
+#else
+  (void)X; (void)W; (void)C; (void)epi; (void)M; (void)N; (void)K; (void)ldx; (void)ldc; (void)conv; (void)cus; (void)s;
+  return 1;
+#endif
+}
+
 // bf16 problems the 4-wave two-per-CU kernel has an instance for: 8-element-aligned rows, operands addressable by 32-bit offsets, no ReLU
 // (NT_V3_NA = not applicable, the caller falls through to the older kernels)
 constexpr int NT_V3_NA = -1000;
@@ -3690,6 +3717,8 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
   if constexpr (sizeof(T) == 2) {
     const int rch = try_conv_halo(X, W, C, epi, N, ldc, conv, g, num_cus(cu_budget), s);
     if (rch != 1) return rch;
+    const int rcw = try_nt_wide(X, W, C, epi, M, N, K, ldx, ldc, conv, num_cus(cu_budget), s);
+    if (rcw != 1) return rcw;
     const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s, cu_budget);
     if (rc3 != NT_V3_NA) return rc3;
   }
@@ -3877,6 +3906,8 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
     {
       const int rch = try_conv_halo(X, W, C, epi, N, ldc, conv, g, cus, s);
       if (rch != 1) return rch;
+      const int rcw = try_nt_wide(X, W, C, epi, M, N, K, ldx, ldc, conv, cus, s);
+      if (rcw != 1) return rcw;
       const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s, cu_budget);
       if (rc3 != NT_V3_NA) return rc3;
     }
