@@ -716,6 +716,35 @@ def test_easpp_middle_branch_batched(ops, dt):
         check(dbet[i], gb_t[2 * i + 1].grad, t, f"d branch BN beta {i}")
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,h,w,C", [(3, 48, 48, 32), (2, 56, 56, 16), (2, 72, 64, 16), (2, 9, 7, 64)])
+def test_dwconv4_forward_dgrad_wgrad_match_torch(ops, dt, B, h, w, C):
+    """The four dilated depth-wise 3x3 convolutions with the reference's rates (feature_integration.py:397-404), their input gradient
+    (+ the GAP adjoint) and weight gradients on the 48 x 48 context map of a 384 px input and on larger / ragged maps, against torch's
+    grouped convolution from the same rounded inputs."""
+    rates = (1, 6, 12, 18)
+    x = rnd(B, h, w, C, seed=3).to(dt)
+    wd = [rnd(C, 9, seed=50 + i) * 0.3 for i in range(4)]
+    dy = rnd(B * h * w, 4 * C, seed=7).to(dt)
+    gadd = rnd(B, C, seed=8)
+    xt = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wt = [t.clone().requires_grad_(True) for t in wd]
+    ref = torch.cat([F.conv2d(xt, wt[i].view(C, 1, 3, 3), padding=d, dilation=d, groups=C) for i, d in enumerate(rates)], 1)
+    (ref.permute(0, 2, 3, 1).reshape(B * h * w, 4 * C) * dy.float()).sum().backward()
+    dcat = ops.dwconv4(x, wd, rates, B, h, w, C)
+    check(dcat.float(), ref.detach().permute(0, 2, 3, 1).reshape(B * h * w, 4 * C), tol(dt, 1e-5, 1e-2), "dwconv4")
+    dwd = [torch.zeros(C, 9, device="cuda") for _ in range(4)]
+    ops.dwconv4_wgrad(dy, x, rates, dwd, B, h, w, C)
+    dx = ops.dwconv4_dgrad(dy, wd, rates, gadd, B, h, w, C)
+    want_dx = xt.grad.permute(0, 2, 3, 1) + gadd.view(B, 1, 1, C)
+    check(dx.float().view(B, h, w, C), want_dx, tol(dt, 1e-5, 1e-2), "dwconv4 dgrad")
+    for i in range(4):
+        check(dwd[i], wt[i].grad, tol(dt, 1e-4, 1e-3), f"dwconv4 wgrad {i}")
+    dwd2 = [torch.zeros(C, 9, device="cuda") for _ in range(4)]
+    ops.dwconv4_wgrad(dy, x, rates, dwd2, B, h, w, C)
+    assert all(torch.equal(a, b) for a, b in zip(dwd, dwd2)), "deterministic weight gradient"
+
+
 def test_pack_cols2_and_add_cols_batch(ops):
     """the position-embedding operand [pos_embed | pos_embed_window | 0] and the column-slice gradient adds (models/engine.py trunk)"""
     a, b = rnd(144, 49, seed=1), rnd(144, 64, seed=2)
