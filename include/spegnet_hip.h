@@ -35,7 +35,7 @@ enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
 
 /* ABI revision: bumped with every change of an exported signature.  Bindings must compare spg_version() with the SPG_ABI_VERSION they
  * were written against and refuse to run on a mismatch (spegnet_amd/_lib.py does).  300 = round 3. */
-#define SPG_ABI_VERSION 303
+#define SPG_ABI_VERSION 304
 int spg_version(void);
 const char* spg_last_error(void);
 
@@ -75,6 +75,18 @@ int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, const void* c
 long spg_gemm_tn_group_desc_bytes(void);
 int spg_gemm_tn_group_reduce_batch(int n, const void* const* descs, const void* const* workspaces, spg_stream_t stream);
 long spg_gemm_tn_group_workspace_bytes(void);
+/* The weight gradients of SEVERAL trunk blocks in one launch (up to 16 dense bf16 problems sharing M, every N and K a multiple of 192):
+ * each workgroup owns one whole 256 x 192 block of some dW over all of M and adds it straight into dW / dbias -- no partial sums, no
+ * workspace, no second kernel, deterministic.  The problem set may make at most spg_num_cus(cu_budget) blocks;
+ * spg_gemm_tn_blocks_count (host-only, -1 = outside the domain) tells the caller how many a set makes, so that it can defer the
+ * wgrads of consecutive trunk blocks until they just fill the chip (stage 3 of Hiera-L: 84 blocks per trunk block, three trunk blocks
+ * per launch).  Same reference op as spg_gemm_tn_group: autograd of the nn.Linear layers of sam2's MultiScaleBlock
+ * (models/feature_encoding.py:236).  The caller keeps every dY / X alive until the launch.                                           */
+int spg_gemm_tn_blocks(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias,
+                       int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, int cu_budget,
+                       spg_stream_t stream);
+long spg_gemm_tn_blocks_count(int njobs, int M, const int* N, const int* K);
+int spg_num_cus(int cu_budget);   /* CUs the persistent grids are sized for under this budget (0 = all) */
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
  * spg_pack_matrix: dst[r][c] = src[r][c] (transpose=0) or dst[c][r] = src[r][c] (transpose=1), src f32 [R,C].
  * spg_pack_conv3x3: torch [Co,Ci,3,3] f32 -> fwd pack [Co][tap][Ci] and dgrad pack [Ci][tap'][Co] (tap' flipped).

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPG_LIBRARY") or os.path.join(_HERE, "libspegnet_hip.so")
 
 SPG_F32, SPG_BF16 = 0, 1
-ABI_VERSION = 303   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
+ABI_VERSION = 304   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 ACT_GELU_SAVE_GRAD, ACT_MUL_H = 3, 4   # bf16: C2 = gelu'(pre) saved by the forward GEMM | C = acc * gelu_h in the backward GEMM
 
@@ -26,6 +26,7 @@ SIGNATURES = {
     "spg_gemm_tn": "ipppppliiiiiiiiiiiip",
     "spg_gemm_tn_group": "ii" "pppp" "i" "ppppp" "plp" "i" "p",
     "spg_gemm_tn_group_reduce_batch": "ippp",
+    "spg_gemm_tn_blocks": "ii" "pppp" "i" "ppppp" "i" "p",
     "spg_pack_matrix": "ippiiip",
     "spg_pack_batch": "ipiip",
     "spg_pack_conv3x3": "ipppiip",
@@ -97,6 +98,8 @@ QUERIES = {
     "spg_conv3x3_wgrad_workspace_bytes": ("l", "iiiiiii"),
     "spg_gemm_tn_group_workspace_bytes": ("l", ""),
     "spg_gemm_tn_group_desc_bytes": ("l", ""),
+    "spg_gemm_tn_blocks_count": ("l", "iipp"),
+    "spg_num_cus": ("i", "i"),
     "spg_reduce_workspace_floats": ("l", "iii"),
     "spg_reduce_counters": ("i", "iii"),
     "spg_layernorm_param_grads_batch_workspace_floats": ("l", "ip"),

@@ -14,16 +14,18 @@
 //     conv_halo.hip; MFMA roles A = X (rows k), B = dY (cols n): D[k][n], a lane holds 4 consecutive k of one n.
 //   * two wave groups one barrier apart: while one issues its 24-MFMA cluster the other issues the next slice's 20 transpose reads and
 //     its share of the 28 LDS-DMA pieces; all per-slice address arithmetic sits in the gaps of the MFMA cluster.
-// STATUS: a measured experiment, compiled into the dev library only (python spegnet_amd/build.py --dev, SPG_TN_BLOCK=1).  Correct
-// (tests/test_kernels_gpu.py::test_gemm_tn_group passes through it) and its main kernel is 20 % faster than the tile kernel on a stage-3
-// block (52.4 vs 65 us), but the 49 MB of per-workgroup partial blocks cost a 14.5 us reduce launch per trunk block that the tile kernel's
-// deferred, batched boundary reduce does not pay: the train step does not move (23.40 vs 23.39 ms on one box).  What it would take:
-// the first M split adding straight into dW and a batched reduce across blocks.
+// Two ways to fill the chip with such blocks:
+//   * DIRECT (product, spg_gemm_tn_blocks): the wgrads of SEVERAL consecutive trunk blocks (stage 3: three of them = 252 blocks for 256 CUs)
+//     go out as one launch in which every workgroup owns a whole block over ALL of M and adds its accumulators straight into dW / dbias:
+//     no partial blocks, no slabs, no reduce launch, deterministic (one owner per gradient element).  The caller (models/engine.py) keeps
+//     the dY / X operands of the deferred trunk blocks alive until the launch.
+//   * split M (dev library only, SPG_TN_BLOCK=1: one trunk block per launch, S = 3 ranges of M per block, partial blocks through slabs
+//     + a reduce launch).  Measured in round 3: main kernel 52.4 us against 65 for the tile kernel, but the 49 MB of partial blocks cost a
+//     14.5 us reduce per trunk block: step unchanged (23.40 vs 23.39 ms), which is what the DIRECT form removes.
 #include <algorithm>
 #include <type_traits>
 #include "common.h"
 
-#ifdef SPG_DEV_KERNELS
 namespace spg {
 
 typedef __attribute__((ext_vector_type(4))) unsigned tbrsrc_t;
@@ -52,7 +54,7 @@ __device__ __forceinline__ bf16x8_t tb_frag(const char* base, unsigned o0, unsig
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-constexpr int TB_MAX_JOBS = 8;
+constexpr int TB_MAX_JOBS = 16;
 constexpr int TB_SUB = 32 * 128;                 // one [32][64] bf16 sub-tile
 constexpr int TB_SLOT = 7 * TB_SUB;              // one 32-row slice of a block's operands
 constexpr int TB_NSLOT = 5;
@@ -71,9 +73,10 @@ struct TbGroup {
   int njobs, M, T, NB, S;    // T = 32-row slices of M, NB blocks in all, S splits of M per block
 };
 
-template <bool WIDE_N>
+// DIRECT: the workgroup owns the block over all of M (S == 1) and adds into dW / dbias itself; otherwise its partial block goes to `slab`
+template <bool WIDE_N, bool DIRECT>
 __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int ta, int tb, int split, char* smem, float* __restrict__ slab,
-                                        float* __restrict__ bslab) {
+                                        float* __restrict__ bslab, bool bias_blk) {
   constexpr int KA = WIDE_N ? 6 : 4;           // k blocks (16) per wave
   constexpr int NBk = WIDE_N ? 4 : 6;          // n blocks per wave
   constexpr int NYS = WIDE_N ? 4 : 3;          // dY sub-tiles of a slice (X: 7 - NYS)
@@ -155,7 +158,7 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
 #pragma unroll
   for (int j = 0; j < NBk; ++j) bsum[j] = 0.f;
   const tbbf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
-  const bool do_bias = bslab != nullptr && wk == 0;
+  const bool do_bias = (DIRECT ? bias_blk : bslab != nullptr) && wk == 0;
 
   // ---- prologue: three slices in flight, the first landed
   for (int i = 0; i < 3; ++i) { issue(); issue_advance(); }
@@ -221,22 +224,46 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // ---- the workgroup's partial block: slab[n local][k local] (rows of 192 or 256 floats: the reduce kernel knows the orientation)
   constexpr int KE = WIDE_N ? 192 : 256;
+  if constexpr (DIRECT) {
+    // ---- the block is complete: dW[n0 + n][k0 + k .. k + 3] += acc (a lane holds 4 consecutive k of one n; the padded part of the 256 side is skipped)
 #pragma unroll
-  for (int kb = 0; kb < KA; ++kb)
+    for (int kb = 0; kb < KA; ++kb)
 #pragma unroll
-    for (int nb = 0; nb < NBk; ++nb) {
-      const int n = wn * (NBk * 16) + nb * 16 + (lane & 15), k = wk * (KA * 16) + kb * 16 + 4 * q;
-      *reinterpret_cast<f32x4*>(slab + n * KE + k) = acc[kb][nb];
+      for (int nb = 0; nb < NBk; ++nb) {
+        const int n = n0 + wn * (NBk * 16) + nb * 16 + (lane & 15), k = k0 + wk * (KA * 16) + kb * 16 + 4 * q;
+        if (n < jb.N && k < jb.K) {
+          float* d = jb.dW + (long)n * jb.ldw + k;
+          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + acc[kb][nb];
+        }
+      }
+    if (do_bias) {
+#pragma unroll
+      for (int nb = 0; nb < NBk; ++nb) {
+        float b = bsum[nb];
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        const int n = n0 + wn * (NBk * 16) + nb * 16 + (lane & 15);
+        if (q == 0 && n < jb.N) jb.dbias[n] += b;
+      }
     }
-  if (do_bias) {
+  } else {
+    // ---- the workgroup's partial block: slab[n local][k local] (rows of 192 or 256 floats: the reduce kernel knows the orientation)
 #pragma unroll
-    for (int nb = 0; nb < NBk; ++nb) {
-      float b = bsum[nb];
-      b += __shfl_xor(b, 16, 64);
-      b += __shfl_xor(b, 32, 64);
-      if (q == 0) bslab[wn * (NBk * 16) + nb * 16 + (lane & 15)] = b;
+    for (int kb = 0; kb < KA; ++kb)
+#pragma unroll
+      for (int nb = 0; nb < NBk; ++nb) {
+        const int n = wn * (NBk * 16) + nb * 16 + (lane & 15), k = wk * (KA * 16) + kb * 16 + 4 * q;
+        *reinterpret_cast<f32x4*>(slab + n * KE + k) = acc[kb][nb];
+      }
+    if (do_bias) {
+#pragma unroll
+      for (int nb = 0; nb < NBk; ++nb) {
+        float b = bsum[nb];
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (q == 0) bslab[wn * (NBk * 16) + nb * 16 + (lane & 15)] = b;
+      }
     }
   }
 }
@@ -248,17 +275,32 @@ __device__ __forceinline__ void tb_locate(const TbGroup& g, int blk, int& j, int
   local = blk - g.job[j].tile0;
 }
 
+__device__ __forceinline__ int tb_xcd_order(int bid, int nwg) {
+  const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, i = bid >> 3;
+  return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + i;
+}
+
+// DIRECT launch: grid = number of blocks (<= CUs), one whole block per workgroup
+__global__ __launch_bounds__(512) void tn_block_direct_kernel(TbGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // workgroups that share an XCD (blockIdx % 8: one L2) get a contiguous range of block ids: the ~32 workgroups of an XCD walk the SAME
+  // rows of M through blocks of one or two layers, which share dY / X panels, so most of their fill is served by that L2
+  const int blk = tb_xcd_order((int)blockIdx.x, (int)gridDim.x);
+  int j, local;
+  tb_locate(g, blk, j, local);
+  const TbJob& jb = g.job[j];
+  const int ta = local / jb.tiles_b, tb = local - ta * jb.tiles_b;
+  const bool bias_blk = jb.dbias != nullptr && (jb.wide_n ? tb == 0 : ta == 0);   // the blocks at the first k position of their n range
+  if (jb.wide_n) tb_body<true, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
+  else tb_body<false, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
+}
+
+#ifdef SPG_DEV_KERNELS
 __global__ __launch_bounds__(512) void tn_block_kernel(TbGroup g, float* __restrict__ slabs, float* __restrict__ bslabs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // workgroups that share an XCD (blockIdx % 8: one L2) get a contiguous range of ids, and ids run block-fastest inside a split: the
-  // ~32 workgroups of an XCD then walk the SAME rows of M through blocks that share dY / X panels (a layer's 9 x 3 blocks read 12 panels,
-  // not 54), so most of their fill is served by that L2 instead of once per block from beyond it
-  int wid;
-  {
-    const int nwg = (int)gridDim.x, bid = blockIdx.x;
-    const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, i = bid >> 3;
-    wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + i;
-  }
+  // ids run block-fastest inside a split: the ~32 workgroups of an XCD walk the SAME rows of M through blocks that share dY / X panels
+  // (a layer's 9 x 3 blocks read 12 panels, not 54)
+  const int wid = tb_xcd_order((int)blockIdx.x, (int)gridDim.x);
   const int split = wid / g.NB, blk = wid - split * g.NB;
   const int wgid = blk * g.S + split;          // slab index: the reduce kernel walks a block's splits
   int j, local;
@@ -269,8 +311,8 @@ __global__ __launch_bounds__(512) void tn_block_kernel(TbGroup g, float* __restr
   // the bias gradient: by the blocks at the first k position of their n range
   const bool bias_blk = jb.dbias != nullptr && (jb.wide_n ? tb == 0 : ta == 0);
   float* bslab = bias_blk ? bslabs + (long)wgid * 256 : nullptr;
-  if (jb.wide_n) tb_body<true>(g, jb, ta, tb, split, smem, slab, bslab);
-  else tb_body<false>(g, jb, ta, tb, split, smem, slab, bslab);
+  if (jb.wide_n) tb_body<true, false>(g, jb, ta, tb, split, smem, slab, bslab, bias_blk);
+  else tb_body<false, false>(g, jb, ta, tb, split, smem, slab, bslab, bias_blk);
 }
 
 // dW[n0 + n][k0 + k] += sum over the S splits of block blk (split order); dbias likewise
@@ -303,20 +345,20 @@ __global__ __launch_bounds__(256) void tn_block_reduce_kernel(TbGroup g, const f
 
 // bytes of workspace the block kernel needs for `cus` workgroups (an upper bound for every problem set it accepts)
 long tn_block_workspace_bytes(int cus) { return (long)cus * (TB_SLAB_FLOATS + 256) * 4L; }
+#endif  // SPG_DEV_KERNELS
 
-// returns SPG_OK / an error, or 1 when the problem set is outside this kernel's domain (the caller uses gemm_tn_group4_kernel)
-int launch_tn_block_group(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
-                          const int* K, const int* ldy, const int* ldx, const int* ldw, void* workspace, long workspace_bytes, int cus,
-                          hipStream_t s) {
-  if (njobs < 1 || njobs > TB_MAX_JOBS || M < 256) return 1;
-  TbGroup g;
+// fills g.job[] and returns the number of 256 x 192 blocks, or -1 when a problem is outside the kernel's domain
+static long tb_plan(TbGroup& g, int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
+                    const int* K, const int* ldy, const int* ldx, const int* ldw) {
+  if (njobs < 1 || njobs > TB_MAX_JOBS || M < 256) return -1;
   long nb = 0;
   for (int i = 0; i < njobs; ++i) {
-    if (N[i] % 192 != 0 || K[i] % 192 != 0 || ldy[i] % 8 != 0 || ldx[i] % 8 != 0 || ldw[i] % 4 != 0) return 1;
-    if ((long)M * ldy[i] * 2 >= 0x7FFFFFF0L || (long)M * ldx[i] * 2 >= 0x7FFFFFF0L) return 1;
+    if (N[i] <= 0 || K[i] <= 0 || N[i] % 192 != 0 || K[i] % 192 != 0) return -1;
+    if (ldy && (ldy[i] % 8 != 0 || ldx[i] % 8 != 0 || ldw[i] % 4 != 0 || ldy[i] < N[i] || ldx[i] < K[i] || ldw[i] < K[i])) return -1;
+    if (ldy && ((long)M * ldy[i] * 2 >= 0x7FFFFFF0L || (long)M * ldx[i] * 2 >= 0x7FFFFFF0L)) return -1;
     TbJob& jb = g.job[i];
-    jb.dY = (const bf16_t*)dY[i]; jb.X = (const bf16_t*)X[i]; jb.dW = dW[i]; jb.dbias = dbias ? dbias[i] : nullptr;
-    jb.N = N[i]; jb.K = K[i]; jb.ldy = ldy[i]; jb.ldx = ldx[i]; jb.ldw = ldw[i];
+    jb.dY = dY ? (const bf16_t*)dY[i] : nullptr; jb.X = X ? (const bf16_t*)X[i] : nullptr; jb.dW = dW ? dW[i] : nullptr; jb.dbias = dbias ? dbias[i] : nullptr;
+    jb.N = N[i]; jb.K = K[i]; jb.ldy = ldy ? ldy[i] : N[i]; jb.ldx = ldx ? ldx[i] : K[i]; jb.ldw = ldw ? ldw[i] : K[i];
     const long tn_ = (long)cdiv(N[i], 256) * (K[i] / 192), tk_ = (long)(N[i] / 192) * cdiv(K[i], 256);
     jb.wide_n = tn_ <= tk_ ? 1 : 0;            // the orientation with fewer (less padded) blocks
     jb.tiles_b = jb.wide_n ? K[i] / 192 : N[i] / 192;
@@ -325,7 +367,39 @@ int launch_tn_block_group(int njobs, const void* const* dY, const void* const* X
     nb += jb.tiles;
   }
   for (int i = njobs; i < TB_MAX_JOBS; ++i) g.job[i] = g.job[njobs - 1];
-  if (nb > cus) return 1;                       // (stage 4 at batch 8: 330 blocks of 18 slices pairs -- the tile kernel balances those better)
+  return nb;
+}
+
+// number of 256 x 192 blocks the problems make (-1: outside the domain): the caller sizes its groups so that they just fill the CUs
+long tn_blocks_count(int njobs, int M, const int* N, const int* K) {
+  TbGroup g;
+  return tb_plan(g, njobs, nullptr, nullptr, nullptr, nullptr, M, N, K, nullptr, nullptr, nullptr);
+}
+
+// DIRECT form; returns SPG_OK / an error, or 1 when the problem set is outside the domain or makes more blocks than `cus`
+int launch_tn_blocks_direct(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
+                            const int* K, const int* ldy, const int* ldx, const int* ldw, int cus, hipStream_t s) {
+  TbGroup g;
+  const long nb = tb_plan(g, njobs, dY, X, dW, dbias, M, N, K, ldy, ldx, ldw);
+  if (nb < 1 || nb > cus) return 1;
+  g.njobs = njobs; g.M = M; g.T = cdiv(M, 32); g.NB = (int)nb; g.S = 1;
+  static bool attr_ = false;
+  if (!attr_) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn_block_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES);
+    attr_ = true;
+  }
+  hipLaunchKernelGGL(tn_block_direct_kernel, dim3((unsigned)nb), dim3(512), TB_LDS_BYTES, s, g);
+  return check_launch("tn_blocks(direct)");
+}
+
+#ifdef SPG_DEV_KERNELS
+// split-M form: returns SPG_OK / an error, or 1 when the problem set is outside this kernel's domain (the caller uses gemm_tn_group4_kernel)
+int launch_tn_block_group(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
+                          const int* K, const int* ldy, const int* ldx, const int* ldw, void* workspace, long workspace_bytes, int cus,
+                          hipStream_t s) {
+  TbGroup g;
+  const long nb = tb_plan(g, njobs, dY, X, dW, dbias, M, N, K, ldy, ldx, ldw);
+  if (nb < 1 || nb > cus) return 1;             // (stage 4 at batch 8: 330 blocks of 18 slices pairs -- the tile kernel balances those better)
   const int T = cdiv(M, 32);
   int S = (int)(cus / nb);
   if (S > T / 16) S = T / 16;                   // at least 16 slices per workgroup
@@ -346,6 +420,6 @@ int launch_tn_block_group(int njobs, const void* const* dY, const void* const* X
   hipLaunchKernelGGL(tn_block_reduce_kernel, dim3(TB_SLAB_FLOATS / 4 / 256, (unsigned)nb), dim3(256), 0, s, g, (const float*)slabs, (const float*)bslabs);
   return check_launch("tn_block(reduce)");
 }
+#endif  // SPG_DEV_KERNELS
 
 }  // namespace spg
-#endif  // SPG_DEV_KERNELS

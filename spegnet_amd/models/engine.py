@@ -50,6 +50,12 @@ class Engine:
         self.wgrad_async = False
         self.group_wgrads = True    # trunk blocks: one grouped wgrad launch per block (False: per-layer launches, for A/B runs)
         self._wg_jobs = None
+        # Whole-block wgrads (ops.gemm_tn_blocks): the weight gradients of CONSECUTIVE trunk blocks are held back until their 256 x 192
+        # blocks of dW just fill the CUs (Hiera-L stage 3: 84 per trunk block, three trunk blocks = 252 for 256 CUs) and go out as one
+        # launch in which every workgroup owns a whole block over all of M -- no partial sums, no reduce.  Their dY / X operands stay
+        # referenced by the pending list until then.  Not used while a per-unit gradient callback needs finished ranges mid-backward.
+        self.block_wgrads = os.environ.get("SPG_BLOCK_WGRADS", "1") != "0"
+        self._wg_pending = []       # [(jobs of one trunk block, its block count)]
         self.batch_ln_params = True  # trunk: LayerNorm dgamma / dbeta in batched launches
         self._ln_jobs = []
         self._tn_defer = []
@@ -267,8 +273,40 @@ class Engine:
         if self._ln_jobs:
             jobs, self._ln_jobs = self._ln_jobs, []
             ops.layernorm_param_grads_batch(jobs)
+        self.flush_block_wgrads()
         if self._tn_defer:
             ops.gemm_tn_group_reduce(self._tn_defer)
+
+    # ------------------------------------------------------------------------------------------------ deferred whole-block wgrads
+    def _issue_block_wgrads(self, jobs, defer_ok: bool = True) -> None:
+        ops.gemm_tn_group(jobs, self._tn_defer if (self.unit_cb is None and defer_ok) else None)
+
+    def queue_block_wgrads(self, jobs) -> None:
+        """One trunk block's wgrad jobs: launched now (grouped tile kernel) or held until the pending trunk blocks fill the CUs."""
+        cnt = ops.tn_blocks_count(jobs) if (self.block_wgrads and self.unit_cb is None and not self.wgrad_async) else -1
+        cus = ops.num_cus()
+        M = jobs[0][0].shape[0]
+        if cnt < 1 or cnt > cus or 2 * cnt < cus // 3 or M < 2048:     # outside the kernel's domain, or too small for whole-M owners to pay
+            self.flush_block_wgrads()
+            self._issue_block_wgrads(jobs)
+            return
+        pend = self._wg_pending
+        if pend and (pend[0][0][0][0].shape[0] != M or sum(c for _, c in pend) + cnt > cus or sum(len(j) for j, _ in pend) + len(jobs) > ops.TN_BLOCKS_MAX):
+            self.flush_block_wgrads()
+        pend.append((jobs, cnt))
+        if sum(c for _, c in pend) + cnt > cus:        # another trunk block of this size would not fit: go now, release the operands
+            self.flush_block_wgrads()
+
+    def flush_block_wgrads(self) -> None:
+        pend, self._wg_pending = self._wg_pending, []
+        if not pend:
+            return
+        total = sum(c for _, c in pend)
+        if 4 * total >= 3 * ops.num_cus():             # >= 3/4 of the CUs own a block
+            ops.gemm_tn_blocks([j for jobs, _ in pend for j in jobs])
+        else:
+            for jobs, _ in pend:
+                self._issue_block_wgrads(jobs)
 
     # ------------------------------------------------------------------------------------------------ linear helpers
     def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
@@ -409,7 +447,7 @@ class Engine:
             jobs, self._wg_jobs = self._wg_jobs, None
             # the groups' small slab reduces are deferred as well (flush_ln_params folds them, 6 per launch) unless a per-unit
             # gradient callback needs finished ranges mid-backward
-            ops.gemm_tn_group(jobs, self._tn_defer if self.unit_cb is None else None)
+            self.queue_block_wgrads(jobs)
         dx = self.ln_bwd(dln1, c["x"], P[p + "norm1.weight"], c["mean1"], c["rstd1"], G(p + "norm1.weight"),
                          G(p + "norm1.bias"), dres=dres)
         return dx.view(B, H, Wd, dim)

@@ -267,6 +267,45 @@ def gemm_tn_group(jobs, defer: Optional[list] = None) -> None:
                 defer.append((desc, ws))
 
 
+TN_BLOCKS_MAX = 16
+
+
+def tn_blocks_count(jobs) -> int:
+    """Number of 256 x 192 blocks of dW the jobs (same tuples as gemm_tn_group) make in spg_gemm_tn_blocks, or -1 when they are
+    outside that kernel's domain (bf16, dense, one common M >= 256, every N and K a multiple of 192, at most 16 problems)."""
+    import ctypes
+    if not jobs or len(jobs) > TN_BLOCKS_MAX:
+        return -1
+    M = jobs[0][0].numel() // jobs[0][0].shape[-1]
+    for dy, x, dw, db in jobs:
+        N, K = dy.shape[-1], x.shape[-1]
+        if not (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
+                and dw.dtype == torch.float32 and dw.numel() == N * K and dy.numel() // N == M and x.numel() // K == M):
+            return -1
+    I = ctypes.c_int * len(jobs)
+    return int(_lib.load().spg_gemm_tn_blocks_count(len(jobs), M, I(*[j[0].shape[-1] for j in jobs]), I(*[j[1].shape[-1] for j in jobs])))
+
+
+def num_cus() -> int:
+    """CUs the persistent grids are sized for under the calling thread's CU budget."""
+    return int(_lib.load().spg_num_cus(cu_budget_now()))
+
+
+def gemm_tn_blocks(jobs) -> None:
+    """The weight gradients of several trunk blocks in ONE launch: every workgroup owns a whole 256 x 192 block of some dw over all of M and
+    adds it straight into dw / dbias (no slabs, no reduce kernel, deterministic).  jobs as in gemm_tn_group; tn_blocks_count(jobs) must be
+    in 1..num_cus()."""
+    import ctypes
+    n = len(jobs)
+    M = jobs[0][0].numel() // jobs[0][0].shape[-1]
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    Ns, Ks = I(*[j[0].shape[-1] for j in jobs]), I(*[j[1].shape[-1] for j in jobs])
+    with _prof("gemm_tn_blocks<bf16> (wgrads of several trunk blocks, whole 256x192 blocks)", "mfma",
+               sum(2.0 * M * j[0].shape[-1] * j[1].shape[-1] for j in jobs)):
+        _lib.call("spg_gemm_tn_blocks", SPG_BF16, n, P(*[_p(j[0]) for j in jobs]), P(*[_p(j[1]) for j in jobs]), P(*[_p(j[2]) for j in jobs]),
+                  P(*[_p(j[3]) for j in jobs]), M, Ns, Ks, Ns, Ks, Ks, cu_budget_now(), _stream())
+
+
 def gemm_tn_group_reduce(deferred: list) -> None:
     """Folds the slabs of deferred grouped launches into their gradients, 6 launches per kernel; empties the list."""
     import ctypes

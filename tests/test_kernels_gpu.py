@@ -160,6 +160,37 @@ def test_gemm_tn_group(ops, shapes, defer):
             check(db, rb, tol(dt, 2e-5, 1e-4), f"group dbias {shp}")
 
 
+@pytest.mark.parametrize("M,trunk_blocks", [(4608, 3), (2304, 2), (300, 1)])
+def test_gemm_tn_blocks(ops, M, trunk_blocks):
+    """Whole-block wgrads of several trunk blocks in one launch (spg_gemm_tn_blocks): every dW / dbias equals the per-problem fp32
+    reference, accumulating on top of what is there; both block orientations, the padded part of the 256 side (576 = 2.25 x 256), rows of M
+    past the last 32-row slice (M = 300), problems without a bias; two launches of the same inputs are bit-identical (one owner per element)."""
+    dt = torch.bfloat16
+    layer = [(1728, 576), (576, 576), (2304, 576), (576, 2304)]          # a stage-3 Hiera-L block: qkv, proj, fc1, fc2 as (N, K)
+    jobs, refs, first = [], [], []
+    for i, (N, K) in enumerate(layer * trunk_blocks):
+        dy, x = rnd(M, N, seed=10 + i).to(dt), rnd(M, K, seed=60 + i).to(dt)
+        dw0, db0 = rnd(N, K, seed=110 + i), rnd(N, seed=160 + i)
+        dw, db = dw0.clone(), (db0.clone() if i % 3 != 1 else None)
+        jobs.append((dy, x, dw, db))
+        first.append((dw0, db0))
+        refs.append((dw0 + dy.float().t() @ x.float(), (db0 + dy.float().sum(0)) if db is not None else None))
+    cnt = ops.tn_blocks_count(jobs)
+    assert cnt == 84 * trunk_blocks and cnt <= ops.num_cus()
+    assert ops.tn_blocks_count([(jobs[0][0], jobs[0][1][:, :288].contiguous(), torch.zeros(1728, 288, device="cuda"), None)]) == -1   # K % 192
+    ops.gemm_tn_blocks(jobs)
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (rw, rb) in zip(jobs, refs):
+        check(dw, rw, tol(dt, 2e-5, 1e-2), f"blocks dW {tuple(dw.shape)} M={M}")
+        if db is not None:
+            check(db, rb, tol(dt, 2e-5, 1e-4), f"blocks dbias {tuple(dw.shape)} M={M}")
+    again = [(dy, x, dw0.clone(), (db0.clone() if db is not None else None)) for (dy, x, dw, db), (dw0, db0) in zip(jobs, first)]
+    ops.gemm_tn_blocks(again)
+    torch.cuda.synchronize()
+    for a, b in zip(jobs, again):
+        assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3])), "gemm_tn_blocks is not bit-reproducible"
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_layernorm_param_grads_batch(ops, dt):
     """Batched dgamma / dbeta (one launch for many LayerNorms of different widths / row counts) == the per-layer layernorm_bwd."""
