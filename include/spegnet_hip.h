@@ -77,10 +77,10 @@ int spg_gemm_tn_group_reduce_batch(int n, const void* const* descs, const void* 
 long spg_gemm_tn_group_workspace_bytes(void);
 /* The weight gradients of SEVERAL trunk blocks in one launch (up to 16 dense bf16 problems sharing M, every N and K a multiple of 192):
  * each workgroup owns one whole 256 x 192 block of some dW over all of M and adds it straight into dW / dbias -- no partial sums, no
- * workspace, no second kernel, deterministic.  The problem set may make at most spg_num_cus(cu_budget) blocks;
- * spg_gemm_tn_blocks_count (host-only, -1 = outside the domain) tells the caller how many a set makes, so that it can defer the
- * wgrads of consecutive trunk blocks until they just fill the chip (stage 3 of Hiera-L: 84 blocks per trunk block, three trunk blocks
- * per launch).  Same reference op as spg_gemm_tn_group: autograd of the nn.Linear layers of sam2's MultiScaleBlock
+ * workspace, no second kernel, deterministic.  A set that makes more blocks than spg_num_cus(cu_budget) runs them in rounds (several
+ * blocks per workgroup); spg_gemm_tn_blocks_count (host-only, -1 = outside the domain) tells the caller how many a set makes, so that
+ * it can defer the wgrads of consecutive trunk blocks until their blocks fill whole rounds (stage 3 of Hiera-L: 84 blocks per trunk
+ * block, three trunk blocks = 252 per launch; stage 4: 330 per trunk block, three = 990 = 3.87 rounds of 256).  Same reference op as spg_gemm_tn_group: autograd of the nn.Linear layers of sam2's MultiScaleBlock
  * (models/feature_encoding.py:236).  The caller keeps every dY / X alive until the launch.                                           */
 int spg_gemm_tn_blocks(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias,
                        int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, int cu_budget,

@@ -28,13 +28,19 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "spegnet_hip.h")]
     objdir = os.path.join(HERE, "build")
+    # A/B builds of the PRODUCT sources (tools/ only): SPG_VARIANT_TAG=_x SPG_VARIANT_FLAGS="-DTB_VARIANT=1" -> libspegnet_hip_x.so
+    vtag, vflags = os.environ.get("SPG_VARIANT_TAG", ""), os.environ.get("SPG_VARIANT_FLAGS", "").split()
+    lib = LIB
+    if vtag:
+        objdir = os.path.join(objdir, "variant" + vtag)
+        lib = os.path.join(HERE, f"libspegnet_hip{vtag}.so")
     os.makedirs(objdir, exist_ok=True)
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         path = os.path.join(CSRC, src)
         if force or _stale(obj, [path] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+            cmd = [hipcc] + FLAGS + vflags + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -44,12 +50,12 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, srcs))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    return LIB
+    return lib
 
 
 def _build_dev(hipcc, verbose):

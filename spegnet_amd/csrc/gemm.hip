@@ -4316,7 +4316,7 @@ extern "C" int spg_gemm_tn_blocks(int dtype, int njobs, const void* const* dY, c
   SPG_REQUIRE(M > 0 && njobs >= 1, "gemm_tn_blocks: empty problem set");
   const int rc = launch_tn_blocks_direct(njobs, dY, X, dW, dbias, M, N, K, ldy, ldx, ldw, num_cus(cu_budget), (hipStream_t)stream);
   SPG_REQUIRE(rc != 1, "gemm_tn_blocks: outside the kernel's domain (1..16 problems, M >= 256, every N and K a multiple of 192, leading "
-                       "dimensions multiples of 8 (ldw: 4), at most %d blocks of 256 x 192: ask spg_gemm_tn_blocks_count first)", num_cus(cu_budget));
+                       "dimensions multiples of 8 (ldw: 4): ask spg_gemm_tn_blocks_count first)");
   return rc;
 }
 

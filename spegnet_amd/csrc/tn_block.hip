@@ -26,6 +26,13 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef TB_ABLATE
+#define TB_ABLATE 0    // timing experiments with wrong results (tools/ builds only): 1 no MFMAs, 2 no fragment reads, 3 no LDS-DMA in the loop, 4 no dW read / store
+#endif
+#ifndef TB_VARIANT
+#define TB_VARIANT 0   // where the LDS-DMA pieces of slice sl + 3 are issued: 0 issue segment, 1 inside the MFMA cluster, 2 split, 3 = 1 without s_setprio
+#endif
+
 namespace spg {
 
 typedef __attribute__((ext_vector_type(4))) unsigned tbrsrc_t;
@@ -132,15 +139,15 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
   // (rows past M: beyond the descriptors' extent -> zero fill; slices past the range: never issued as live pieces)
   int is_slice = 0;            // slices issued so far
   unsigned is_slot = 0;        // ring slot (byte offset) the next issue fills
-  auto issue = [&]() __attribute__((always_inline)) {
-    const bool live = is_slice < nsl;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < npc) {
-        const unsigned off = live ? pbase[i] : TB_DEAD;
-        tb_dma16(prs[i], smem_base + is_slot + pdst[i], off);
-      }
+  auto issue_piece = [&](int i) __attribute__((always_inline)) {
+    if (i < npc) {
+      const unsigned off = is_slice < nsl ? pbase[i] : TB_DEAD;
+      if (TB_ABLATE != 3 || is_slice < 3) tb_dma16(prs[i], smem_base + is_slot + pdst[i], off);
     }
+  };
+  auto issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_piece(i);
   };
   auto issue_advance = [&]() __attribute__((always_inline)) {
     ++is_slice;
@@ -170,27 +177,50 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
   unsigned rd = 0;             // ring slot being read (tracked inside xa / ya: they are advanced in place)
   for (int sl = 0; sl < nsl; ++sl) {
     // ================= issue segment: 20 transpose reads, this wave's pieces of slice sl + 3
+    if (TB_ABLATE != 2 || sl == 0) {
 #pragma unroll
-    for (int nb = 0; nb < NBk; ++nb) fy[nb] = tb_frag(smem, ya[nb][0], ya[nb][1]);
+      for (int nb = 0; nb < NBk; ++nb) fy[nb] = tb_frag(smem, ya[nb][0], ya[nb][1]);
 #pragma unroll
-    for (int kb = 0; kb < KA; ++kb) fx[kb] = tb_frag(smem, xa[kb][0], xa[kb][1]);
+      for (int kb = 0; kb < KA; ++kb) fx[kb] = tb_frag(smem, xa[kb][0], xa[kb][1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
+#if TB_VARIANT == 0
     issue();
     __builtin_amdgcn_sched_barrier(0);
     // slice sl + 1 has landed (this wave's pieces: two younger slices may stay in flight); this wave's reads have returned
     if (wave < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#elif TB_VARIANT == 2
+    issue_piece(0); issue_piece(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // outstanding and allowed to stay: pieces 0, 1 of slice sl + 3 and all of slice sl + 2
+    if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+#else
+    // the pieces of slice sl + 3 are issued inside the MFMA cluster below: here only slice sl + 2 may stay in flight
+    if (wave < 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ================= MFMA segment; the ring / stream bookkeeping sits in its gaps
+#if TB_VARIANT != 3
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       const int kb = m / NBk, nb = m % NBk;
-      acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[kb], fy[nb], acc[kb][nb], 0, 0, 0);
+      if (TB_ABLATE != 1 || sl == 0) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[kb], fy[nb], acc[kb][nb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (m == 0) { asm volatile("" : "+s"(is_slice)); issue_advance(); asm volatile("" : "+s"(is_slice)); }
-      if (m == 1) {
+#if TB_VARIANT == 0
+      constexpr int ADV = 0;
+#else
+      constexpr int ADV = 20;
+      if (TB_VARIANT != 2 && m == 1) issue_piece(0);
+      if (TB_VARIANT != 2 && m == 6) issue_piece(1);
+      if (m == 11) issue_piece(2);
+      if (m == 16) issue_piece(3);
+#endif
+      if (m == ADV) { asm volatile("" : "+s"(is_slice)); issue_advance(); asm volatile("" : "+s"(is_slice)); }
+      if (m == ADV + 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pbase[i]));
       }
@@ -232,7 +262,7 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
 #pragma unroll
       for (int nb = 0; nb < NBk; ++nb) {
         const int n = n0 + wn * (NBk * 16) + nb * 16 + (lane & 15), k = k0 + wk * (KA * 16) + kb * 16 + 4 * q;
-        if (n < jb.N && k < jb.K) {
+        if (n < jb.N && k < jb.K && (TB_ABLATE != 4 || acc[kb][nb][0] == 123.f)) {
           float* d = jb.dW + (long)n * jb.ldw + k;
           *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + acc[kb][nb];
         }
@@ -280,19 +310,23 @@ __device__ __forceinline__ int tb_xcd_order(int bid, int nwg) {
   return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + i;
 }
 
-// DIRECT launch: grid = number of blocks (<= CUs), one whole block per workgroup
+// DIRECT launch: grid = min(blocks, CUs); a workgroup takes blocks wid, wid + grid, ... (one each when the set was sized to the chip)
 __global__ __launch_bounds__(512) void tn_block_direct_kernel(TbGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // workgroups that share an XCD (blockIdx % 8: one L2) get a contiguous range of block ids: the ~32 workgroups of an XCD walk the SAME
   // rows of M through blocks of one or two layers, which share dY / X panels, so most of their fill is served by that L2
-  const int blk = tb_xcd_order((int)blockIdx.x, (int)gridDim.x);
-  int j, local;
-  tb_locate(g, blk, j, local);
-  const TbJob& jb = g.job[j];
-  const int ta = local / jb.tiles_b, tb = local - ta * jb.tiles_b;
-  const bool bias_blk = jb.dbias != nullptr && (jb.wide_n ? tb == 0 : ta == 0);   // the blocks at the first k position of their n range
-  if (jb.wide_n) tb_body<true, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
-  else tb_body<false, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
+  const int wid = tb_xcd_order((int)blockIdx.x, (int)gridDim.x);
+#pragma unroll 1
+  for (int blk = wid; blk < g.NB; blk += (int)gridDim.x) {
+    int j, local;
+    tb_locate(g, blk, j, local);
+    const TbJob& jb = g.job[j];
+    const int ta = local / jb.tiles_b, tb = local - ta * jb.tiles_b;
+    const bool bias_blk = jb.dbias != nullptr && (jb.wide_n ? tb == 0 : ta == 0);   // the blocks at the first k position of their n range
+    if (jb.wide_n) tb_body<true, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
+    else tb_body<false, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
+    __syncthreads();          // every wave has left the ring before the next block's prologue refills it
+  }
 }
 
 #ifdef SPG_DEV_KERNELS
@@ -376,19 +410,20 @@ long tn_blocks_count(int njobs, int M, const int* N, const int* K) {
   return tb_plan(g, njobs, nullptr, nullptr, nullptr, nullptr, M, N, K, nullptr, nullptr, nullptr);
 }
 
-// DIRECT form; returns SPG_OK / an error, or 1 when the problem set is outside the domain or makes more blocks than `cus`
+// DIRECT form; returns SPG_OK / an error, or 1 when the problem set is outside the domain.  More blocks than `cus`: several per workgroup,
+// one after the other (the caller sizes its sets so that the rounds are full: models/engine.py)
 int launch_tn_blocks_direct(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
                             const int* K, const int* ldy, const int* ldx, const int* ldw, int cus, hipStream_t s) {
   TbGroup g;
   const long nb = tb_plan(g, njobs, dY, X, dW, dbias, M, N, K, ldy, ldx, ldw);
-  if (nb < 1 || nb > cus) return 1;
+  if (nb < 1) return 1;
   g.njobs = njobs; g.M = M; g.T = cdiv(M, 32); g.NB = (int)nb; g.S = 1;
   static bool attr_ = false;
   if (!attr_) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn_block_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES);
     attr_ = true;
   }
-  hipLaunchKernelGGL(tn_block_direct_kernel, dim3((unsigned)nb), dim3(512), TB_LDS_BYTES, s, g);
+  hipLaunchKernelGGL(tn_block_direct_kernel, dim3((unsigned)(nb < cus ? nb : cus)), dim3(512), TB_LDS_BYTES, s, g);
   return check_launch("tn_blocks(direct)");
 }
 

@@ -281,28 +281,31 @@ class Engine:
     def _issue_block_wgrads(self, jobs, defer_ok: bool = True) -> None:
         ops.gemm_tn_group(jobs, self._tn_defer if (self.unit_cb is None and defer_ok) else None)
 
+    @staticmethod
+    def _round_fill(total: int, cus: int) -> float:
+        """Share of the (workgroup, round) slots that own a block when `total` blocks run on `cus` CUs."""
+        return total / float(-(-total // cus) * cus)
+
     def queue_block_wgrads(self, jobs) -> None:
-        """One trunk block's wgrad jobs: launched now (grouped tile kernel) or held until the pending trunk blocks fill the CUs."""
+        """One trunk block's wgrad jobs: launched now (grouped tile kernel) or held until the pending trunk blocks fill whole rounds of CUs."""
         cnt = ops.tn_blocks_count(jobs) if (self.block_wgrads and self.unit_cb is None and not self.wgrad_async) else -1
-        cus = ops.num_cus()
         M = jobs[0][0].shape[0]
-        if cnt < 1 or cnt > cus or 2 * cnt < cus // 3 or M < 2048:     # outside the kernel's domain, or too small for whole-M owners to pay
+        if cnt < 1 or M < 1024:                  # outside the kernel's domain, or too few rows for whole-M owners to pay
             self.flush_block_wgrads()
             self._issue_block_wgrads(jobs)
             return
         pend = self._wg_pending
-        if pend and (pend[0][0][0][0].shape[0] != M or sum(c for _, c in pend) + cnt > cus or sum(len(j) for j, _ in pend) + len(jobs) > ops.TN_BLOCKS_MAX):
+        if pend and (pend[0][0][0][0].shape[0] != M or sum(len(j) for j, _ in pend) + len(jobs) > ops.TN_BLOCKS_MAX):
             self.flush_block_wgrads()
         pend.append((jobs, cnt))
-        if sum(c for _, c in pend) + cnt > cus:        # another trunk block of this size would not fit: go now, release the operands
+        if self._round_fill(sum(c for _, c in pend), ops.num_cus()) >= 0.9:        # the rounds are full: go now, release the operands
             self.flush_block_wgrads()
 
     def flush_block_wgrads(self) -> None:
         pend, self._wg_pending = self._wg_pending, []
         if not pend:
             return
-        total = sum(c for _, c in pend)
-        if 4 * total >= 3 * ops.num_cus():             # >= 3/4 of the CUs own a block
+        if self._round_fill(sum(c for _, c in pend), ops.num_cus()) >= 0.75:
             ops.gemm_tn_blocks([j for jobs, _ in pend for j in jobs])
         else:
             for jobs, _ in pend:

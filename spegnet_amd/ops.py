@@ -293,8 +293,8 @@ def num_cus() -> int:
 
 def gemm_tn_blocks(jobs) -> None:
     """The weight gradients of several trunk blocks in ONE launch: every workgroup owns a whole 256 x 192 block of some dw over all of M and
-    adds it straight into dw / dbias (no slabs, no reduce kernel, deterministic).  jobs as in gemm_tn_group; tn_blocks_count(jobs) must be
-    in 1..num_cus()."""
+    adds it straight into dw / dbias (no slabs, no reduce kernel, deterministic).  jobs as in gemm_tn_group with tn_blocks_count(jobs) >= 1;
+    more blocks than num_cus() run in rounds."""
     import ctypes
     n = len(jobs)
     M = jobs[0][0].numel() // jobs[0][0].shape[-1]

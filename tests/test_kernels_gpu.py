@@ -160,11 +160,12 @@ def test_gemm_tn_group(ops, shapes, defer):
             check(db, rb, tol(dt, 2e-5, 1e-4), f"group dbias {shp}")
 
 
-@pytest.mark.parametrize("M,trunk_blocks", [(4608, 3), (2304, 2), (300, 1)])
+@pytest.mark.parametrize("M,trunk_blocks", [(4608, 3), (2304, 2), (300, 1), (1152, 4)])
 def test_gemm_tn_blocks(ops, M, trunk_blocks):
     """Whole-block wgrads of several trunk blocks in one launch (spg_gemm_tn_blocks): every dW / dbias equals the per-problem fp32
     reference, accumulating on top of what is there; both block orientations, the padded part of the 256 side (576 = 2.25 x 256), rows of M
-    past the last 32-row slice (M = 300), problems without a bias; two launches of the same inputs are bit-identical (one owner per element)."""
+    past the last 32-row slice (M = 300), problems without a bias, more blocks than CUs (4 x 84: a second round for some workgroups); two
+    launches of the same inputs are bit-identical (one owner per element)."""
     dt = torch.bfloat16
     layer = [(1728, 576), (576, 576), (2304, 576), (576, 2304)]          # a stage-3 Hiera-L block: qkv, proj, fc1, fc2 as (N, K)
     jobs, refs, first = [], [], []
@@ -176,7 +177,7 @@ def test_gemm_tn_blocks(ops, M, trunk_blocks):
         first.append((dw0, db0))
         refs.append((dw0 + dy.float().t() @ x.float(), (db0 + dy.float().sum(0)) if db is not None else None))
     cnt = ops.tn_blocks_count(jobs)
-    assert cnt == 84 * trunk_blocks and cnt <= ops.num_cus()
+    assert cnt == 84 * trunk_blocks
     assert ops.tn_blocks_count([(jobs[0][0], jobs[0][1][:, :288].contiguous(), torch.zeros(1728, 288, device="cuda"), None)]) == -1   # K % 192
     ops.gemm_tn_blocks(jobs)
     torch.cuda.synchronize()

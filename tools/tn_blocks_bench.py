@@ -9,6 +9,8 @@ from spegnet_amd import ops
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 4608
 NBLK = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 LAYER = [(1728, 576), (576, 576), (2304, 576), (576, 2304)]
+if len(sys.argv) > 3 and sys.argv[3] == "stage4":
+    LAYER = [(3456, 1152), (1152, 1152), (4608, 1152), (1152, 4608)]
 
 
 def graph_time(fn, reps=20, iters=10):
@@ -54,6 +56,6 @@ t_tile = graph_time(tiles)
 print(f"M={M} x{NBLK} trunk blocks: tile kernel + batched reduce {t_tile*1e6:7.1f} us ({fl/t_tile/1e12:4.0f} TF)", flush=True)
 cnt = ops.tn_blocks_count(flat)
 print("blocks:", cnt, "CUs:", ops.num_cus(), flush=True)
-if 1 <= cnt <= ops.num_cus():
+if cnt >= 1:
     t_blk = graph_time(lambda: ops.gemm_tn_blocks(flat))
     print(f"M={M} x{NBLK} trunk blocks: whole-block kernel           {t_blk*1e6:7.1f} us ({fl/t_blk/1e12:4.0f} TF)", flush=True)
