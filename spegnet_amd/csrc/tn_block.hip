@@ -256,17 +256,58 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   constexpr int KE = WIDE_N ? 192 : 256;
   if constexpr (DIRECT) {
-    // ---- the block is complete: dW[n0 + n][k0 + k .. k + 3] += acc (a lane holds 4 consecutive k of one n; the padded part of the 256 side is skipped)
+    // ---- the block is complete: dW[n0 + n][k0 + k] += acc.  A lane holds 4 consecutive k of one n, sixteen lanes sixteen different rows:
+    // stored from there, every wave instruction touches 16 half lines (measured: 25 of 148 us per stage-3 launch, 74 of 202 at stage 4).
+    // So the block goes through the (now idle) ring, half of its n rows at a time, and leaves as whole rows: consecutive lanes = consecutive
+    // 16-byte pieces of a dW row (768 / 1024 contiguous bytes per row).
+    constexpr int NE = WIDE_N ? 256 : 192;
+    constexpr int RS = KE + 4;                     // floats per staged row (+4: the sixteen rows of a fragment store start 4 banks apart)
+    constexpr int VR = KE / 4;                     // 16-byte pieces per row
+    constexpr int NV = (NE / 2) * VR / 512;        // pieces per thread and half (12)
+    static_assert((NE / 2) * RS * 4 <= TB_LDS_BYTES && (NE / 2) * VR % (512 * 6) == 0, "half a block fits the ring");
+    float* stage = reinterpret_cast<float*>(smem);
+    const int myhalf = WIDE_N ? (wn >> 1) : wn;
+    const int nloc = (WIDE_N ? (wn & 1) * (NBk * 16) : 0) + (lane & 15);    // this lane's row inside its half, for nb = 0
+    __syncthreads();                               // every wave's LDS-DMA has landed (vmcnt(0) above) and every fragment read is done
 #pragma unroll
-    for (int kb = 0; kb < KA; ++kb)
+    for (int h = 0; h < 2; ++h) {
+      if (myhalf == h) {
 #pragma unroll
-      for (int nb = 0; nb < NBk; ++nb) {
-        const int n = n0 + wn * (NBk * 16) + nb * 16 + (lane & 15), k = k0 + wk * (KA * 16) + kb * 16 + 4 * q;
-        if (n < jb.N && k < jb.K && (TB_ABLATE != 4 || acc[kb][nb][0] == 123.f)) {
-          float* d = jb.dW + (long)n * jb.ldw + k;
-          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + acc[kb][nb];
+        for (int kb = 0; kb < KA; ++kb)
+#pragma unroll
+          for (int nb = 0; nb < NBk; ++nb)
+            *reinterpret_cast<f32x4*>(stage + (nloc + nb * 16) * RS + wk * (KA * 16) + kb * 16 + 4 * q) = acc[kb][nb];
+      }
+      __syncthreads();
+      // six old values are requested before the first add (cold HBM lines: two latencies per half, not one per piece); only the loaded
+      // values stay in registers, addresses are formed again for the stores (the other half's accumulators are still live)
+      auto piece = [&](int it, int& row, int& c4) __attribute__((always_inline)) -> float* {
+        const int v = it * 512 + tid;
+        row = v / VR; c4 = v - row * VR;
+        const int n = n0 + h * (NE / 2) + row, k = k0 + c4 * 4;
+        return (n < jb.N && k < jb.K && TB_ABLATE != 4) ? jb.dW + (long)n * jb.ldw + k : nullptr;
+      };
+      constexpr int CH = 6;                        // pieces in flight per thread
+#pragma unroll 1
+      for (int c = 0; c < NV; c += CH) {
+        f32x4 old[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          int row, c4;
+          const float* d = piece(c + i, row, c4);
+          old[i] = d ? *reinterpret_cast<const f32x4*>(d) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          int row, c4;
+          float* d = piece(c + i, row, c4);
+          const f32x4 part = *reinterpret_cast<const f32x4*>(stage + row * RS + c4 * 4);
+          if (d) *reinterpret_cast<f32x4*>(d) = old[i] + part;
         }
       }
+      if (h == 0) __syncthreads();                 // the second half overwrites the staged rows
+    }
     if (do_bias) {
 #pragma unroll
       for (int nb = 0; nb < NBk; ++nb) {
