@@ -29,6 +29,9 @@
 #ifndef TB_ABLATE
 #define TB_ABLATE 0    // timing experiments with wrong results (tools/ builds only): 1 no MFMAs, 2 no fragment reads, 3 no LDS-DMA in the loop, 4 no dW read / store
 #endif
+#ifndef TB_MFMA32
+#define TB_MFMA32 0    // 1 (A/B builds, -DTB_MFMA32=1): the DIRECT kernel on 32 x 32 x 16 MFMAs (tb_body32) -- measured no faster, see there
+#endif
 #ifndef TB_VARIANT
 #define TB_VARIANT 0   // where the LDS-DMA pieces of slice sl + 3 are issued: 0 issue segment, 1 inside the MFMA cluster, 2 split, 3 = 1 without s_setprio
 #endif
@@ -339,6 +342,238 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
   }
 }
 
+#if TB_MFMA32
+// ---- the DIRECT body on 32 x 32 x 16 MFMAs: a measured experiment (A/B builds only) -------------------------------------------------
+// RESULT: bit-checked by tests/test_kernels_gpu.py::test_gemm_tn_blocks, and no faster -- 142.5 vs 139.5 us per three stage-3 trunk
+// blocks, 178.1 vs 177.3 at stage 4 (same box, tools/tn_blocks_bench.py): the partner's issue slots are not what bounds the interval.
+// Same block, ring, LDS-DMA stream and two-group schedule as tb_body; what changes is the matrix instruction.  Why: in the ping-pong one
+// group's issue segment (20 transpose reads, 3-4 LDS-DMA pieces, waits) runs beside the OTHER group's MFMA cluster on the same SIMD, and
+// a 16 x 16 x 32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles, a 32 x 32 x 16 one for 8 of its 32 (MI355X_MICROARCH.md, cycle
+// constants): the same FLOPs leave the partner 3/4 instead of 1/2 of the issue slots.  Ablations of the 16 x 16 body (tools builds,
+// TB_ABLATE) had shown no single pole -- no MFMAs -39 us, no LDS-DMA -26, no reads -10 of 139 -- i.e. an issue-bound interval.
+// Operands: A = X (32 k-columns x 16 rows of M), B = dY (16 rows of M x 32 n-columns); a lane holds column l % 32 and the 8 rows
+// 8 (l / 32) .. + 7 of a 16-row k-step, so a 16-lane group q reads rows 16 s + 8 (q >> 1) + 4 r .. + 3 of column group (q & 1) with two
+// ds_read_b64_tr_b16.  A 32-lane half of such a read touches 4 rows x 4 chunks; rows two apart share their banks, so the chunk key is
+// ((row >> 1) & 1) << 2 (quad of chunks flipped every two rows): 64 distinct banks per half.
+// D = 32 (k) x 32 (n): register i of a lane is k = 8 (i / 4) + 4 (l / 32) + i % 4 at n = l % 32.
+typedef __attribute__((ext_vector_type(16))) float tbf32x16;
+__device__ __forceinline__ int tb_key32(int row) { return ((row >> 1) & 1) << 2; }
+
+template <bool WIDE_N>
+__device__ __forceinline__ void tb_body32(const TbGroup& g, const TbJob& jb, int ta, int tb, char* smem, bool bias_blk) {
+  constexpr int KA = WIDE_N ? 3 : 2;           // k blocks (32) per wave
+  constexpr int NBk = WIDE_N ? 2 : 3;          // n blocks (32) per wave
+  constexpr int NYS = WIDE_N ? 4 : 3;          // dY sub-tiles of a slice (X: 7 - NYS)
+  constexpr int NM = 2 * KA * NBk;             // 12 MFMAs per slice (two 16-row k-steps)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wk = WIDE_N ? (wave & 1) : (wave & 3), wn = WIDE_N ? (wave >> 1) : (wave >> 2);
+  const int q = lane >> 4, ra = (lane & 15) >> 2, rb = lane & 3;
+  const int n0 = (WIDE_N ? ta * 256 : tb * 192), k0 = (WIDE_N ? tb * 192 : ta * 256);
+  const int nsl = g.T;
+  const tbrsrc_t yr = tb_rsrc(jb.dY, (unsigned)(((long)(g.M - 1) * jb.ldy + jb.N) * 2)), xr = tb_rsrc(jb.X, (unsigned)(((long)(g.M - 1) * jb.ldx + jb.K) * 2));
+  const unsigned smem_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- fragment read offsets in slot 0, [k-step][block][r]
+  unsigned xa[2][KA][2], ya[2][NBk][2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = 16 * st + 8 * (q >> 1) + ra + 4 * r;
+#pragma unroll
+      for (int kb = 0; kb < KA; ++kb) {
+        const int col = wk * (KA * 32) + kb * 32;
+        xa[st][kb][r] = (unsigned)((NYS + (col >> 6)) * TB_SUB + row * 128 + (((2 * (((col & 63) >> 4) + (q & 1)) + (rb >> 1)) ^ tb_key32(row)) << 4) + (rb & 1) * 8);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBk; ++nb) {
+        const int col = wn * (NBk * 32) + nb * 32;
+        ya[st][nb][r] = (unsigned)((col >> 6) * TB_SUB + row * 128 + (((2 * (((col & 63) >> 4) + (q & 1)) + (rb >> 1)) ^ tb_key32(row)) << 4) + (rb & 1) * 8);
+      }
+    }
+  // ---- LDS-DMA: as in tb_body (28 pieces of 8 rows x 128 B per slice), with this body's chunk key
+  const int npc = wave < 4 ? 4 : 3;
+  unsigned pbase[4], pstride[4], pdst[4];
+  tbrsrc_t prs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pc = wave + 8 * i;
+    const int st = pc >> 2, row = 8 * (pc & 3) + (lane >> 3);
+    const int chunk = (lane & 7) ^ tb_key32(row);
+    const bool isy = st < NYS;
+    const int col = (isy ? n0 + 64 * st : k0 + 64 * (st - NYS)) + chunk * 8;
+    const int ld = isy ? jb.ldy : jb.ldx;
+    const bool inside = pc < 28 && col < (isy ? jb.N : jb.K);
+    pbase[i] = inside ? (unsigned)(((long)row * ld + col) * 2) : TB_DEAD;
+    pstride[i] = inside ? (unsigned)(32 * ld * 2) : 0u;
+    pdst[i] = (unsigned)(st * TB_SUB + (pc & 3) * 1024);
+    prs[i] = isy ? yr : xr;
+  }
+  int is_slice = 0;
+  unsigned is_slot = 0;
+  auto issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < npc) {
+        const unsigned off = is_slice < nsl ? pbase[i] : TB_DEAD;
+        tb_dma16(prs[i], smem_base + is_slot + pdst[i], off);
+      }
+    }
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    ++is_slice;
+    is_slot = is_slot + TB_SLOT == (unsigned)TB_LDS_BYTES ? 0u : is_slot + TB_SLOT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pbase[i] += pstride[i];
+  };
+
+  tbf32x16 acc[KA][NBk];
+#pragma unroll
+  for (int i = 0; i < KA; ++i)
+#pragma unroll
+    for (int j = 0; j < NBk; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float bsum[NBk];
+#pragma unroll
+  for (int j = 0; j < NBk; ++j) bsum[j] = 0.f;
+  const tbbf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+  const bool do_bias = bias_blk && wk == 0;
+
+  // ---- prologue: three slices in flight, the first landed
+  for (int i = 0; i < 3; ++i) { issue(); issue_advance(); }
+  if (wave < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __syncthreads();
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier interval behind group 0
+
+  bf16x8_t fx[2][KA], fy[2][NBk];
+  unsigned rd = 0;
+  for (int sl = 0; sl < nsl; ++sl) {
+    // ================= issue segment: 20 transpose reads, this wave's pieces of slice sl + 3
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int nb = 0; nb < NBk; ++nb) fy[st][nb] = tb_frag(smem, ya[st][nb][0], ya[st][nb][1]);
+#pragma unroll
+      for (int kb = 0; kb < KA; ++kb) fx[st][kb] = tb_frag(smem, xa[st][kb][0], xa[st][kb][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue();
+    __builtin_amdgcn_sched_barrier(0);
+    // slice sl + 1 has landed (this wave's pieces: two younger slices may stay in flight); this wave's reads have returned
+    if (wave < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= MFMA segment; the ring / stream bookkeeping sits in its gaps
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int st = m / (KA * NBk), kb = (m % (KA * NBk)) / NBk, nb = m % NBk;
+      acc[kb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[st][kb], fy[st][nb], acc[kb][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m == 0) { asm volatile("" : "+s"(is_slice)); issue_advance(); asm volatile("" : "+s"(is_slice)); }
+      if (m == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pbase[i]));
+        rd = rd + TB_SLOT == (unsigned)TB_LDS_BYTES ? 0u : rd + TB_SLOT; asm volatile("" : "+s"(rd));
+      }
+      if (m >= 2 && m < 2 + 2 * KA) {          // the fragment offsets follow the ring: one (k-step, block) pair of offsets per gap
+        const int i_ = m - 2, st_ = i_ / KA, kb_ = i_ % KA;
+        const unsigned d = rd == 0u ? (unsigned)-(TB_LDS_BYTES - TB_SLOT) : (unsigned)TB_SLOT;
+        xa[st_][kb_][0] += d; xa[st_][kb_][1] += d;
+        asm volatile("" : "+v"(xa[st_][kb_][0])); asm volatile("" : "+v"(xa[st_][kb_][1]));
+      }
+      if (m >= NM - 2 * NBk && m < NM) {       // (2 KA + 2 NBk = 10 pairs in gaps 2 .. 11)
+        const int i_ = m - (NM - 2 * NBk), st_ = i_ / NBk, nb_ = i_ % NBk;
+        const unsigned d = rd == 0u ? (unsigned)-(TB_LDS_BYTES - TB_SLOT) : (unsigned)TB_SLOT;
+        ya[st_][nb_][0] += d; ya[st_][nb_][1] += d;
+        asm volatile("" : "+v"(ya[st_][nb_][0])); asm volatile("" : "+v"(ya[st_][nb_][1]));
+      }
+      if (do_bias && m >= 2 && m < 2 + 2 * NBk) {   // column sums of dY from the fragments in registers
+        const int i_ = m - 2, st_ = i_ / NBk, nb_ = i_ % NBk;
+        const bf16x8_t v = fy[st_][nb_];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const tbbf16x2_t pr = {v[2 * e], v[2 * e + 1]};
+          bsum[nb_] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum[nb_], false);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- the block leaves through the idle ring as whole dW rows (see tb_body), half of its n rows at a time
+  constexpr int KE = WIDE_N ? 192 : 256;
+  constexpr int NE = WIDE_N ? 256 : 192;
+  constexpr int RS = KE + 4;
+  constexpr int VR = KE / 4;
+  constexpr int NV = (NE / 2) * VR / 512;
+  static_assert((NE / 2) * RS * 4 <= TB_LDS_BYTES && (NE / 2) * VR % (512 * 6) == 0, "half a block fits the ring");
+  float* stage = reinterpret_cast<float*>(smem);
+  const int myhalf = WIDE_N ? (wn >> 1) : wn;
+  const int nloc = (WIDE_N ? (wn & 1) * (NBk * 32) : 0) + (lane & 31);    // this lane's row inside its half, for nb = 0
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (myhalf == h) {
+#pragma unroll
+      for (int kb = 0; kb < KA; ++kb)
+#pragma unroll
+        for (int nb = 0; nb < NBk; ++nb)
+#pragma unroll
+          for (int jq = 0; jq < 4; ++jq) {
+            const f32x4 v = {acc[kb][nb][4 * jq], acc[kb][nb][4 * jq + 1], acc[kb][nb][4 * jq + 2], acc[kb][nb][4 * jq + 3]};
+            *reinterpret_cast<f32x4*>(stage + (nloc + nb * 32) * RS + wk * (KA * 32) + kb * 32 + 8 * jq + 4 * (lane >> 5)) = v;
+          }
+    }
+    __syncthreads();
+    auto piece = [&](int it, int& row, int& c4) __attribute__((always_inline)) -> float* {
+      const int v = it * 512 + tid;
+      row = v / VR; c4 = v - row * VR;
+      const int n = n0 + h * (NE / 2) + row, k = k0 + c4 * 4;
+      return (n < jb.N && k < jb.K) ? jb.dW + (long)n * jb.ldw + k : nullptr;
+    };
+    constexpr int CH = 6;
+#pragma unroll 1
+    for (int c = 0; c < NV; c += CH) {
+      f32x4 old[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        int row, c4;
+        const float* d = piece(c + i, row, c4);
+        old[i] = d ? *reinterpret_cast<const f32x4*>(d) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        int row, c4;
+        float* d = piece(c + i, row, c4);
+        const f32x4 part = *reinterpret_cast<const f32x4*>(stage + row * RS + c4 * 4);
+        if (d) *reinterpret_cast<f32x4*>(d) = old[i] + part;
+      }
+    }
+    if (h == 0) __syncthreads();
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int nb = 0; nb < NBk; ++nb) {
+      float b = bsum[nb];
+      b += __shfl_xor(b, 32, 64);
+      const int n = n0 + wn * (NBk * 32) + nb * 32 + (lane & 31);
+      if (lane < 32 && n < jb.N) jb.dbias[n] += b;
+    }
+  }
+}
+#endif  // TB_MFMA32
+
 __device__ __forceinline__ void tb_locate(const TbGroup& g, int blk, int& j, int& local) {
   j = 0;
 #pragma unroll 1
@@ -364,8 +599,13 @@ __global__ __launch_bounds__(512) void tn_block_direct_kernel(TbGroup g) {
     const TbJob& jb = g.job[j];
     const int ta = local / jb.tiles_b, tb = local - ta * jb.tiles_b;
     const bool bias_blk = jb.dbias != nullptr && (jb.wide_n ? tb == 0 : ta == 0);   // the blocks at the first k position of their n range
+#if TB_MFMA32
+    if (jb.wide_n) tb_body32<true>(g, jb, ta, tb, smem, bias_blk);
+    else tb_body32<false>(g, jb, ta, tb, smem, bias_blk);
+#else
     if (jb.wide_n) tb_body<true, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
     else tb_body<false, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
+#endif
     __syncthreads();          // every wave has left the ring before the next block's prologue refills it
   }
 }
