@@ -288,7 +288,9 @@ class Engine:
 
     def queue_block_wgrads(self, jobs) -> None:
         """One trunk block's wgrad jobs: launched now (grouped tile kernel) or held until the pending trunk blocks fill whole rounds of CUs."""
-        cnt = ops.tn_blocks_count(jobs) if (self.block_wgrads and self.unit_cb is None and not self.wgrad_async) else -1
+        # (not under a CU budget -- graph segments that replay beside a collective: 84-block sets no longer fill whole rounds of 240 CUs)
+        use = self.block_wgrads and self.unit_cb is None and not self.wgrad_async and ops.cu_budget_now() == 0
+        cnt = ops.tn_blocks_count(jobs) if use else -1
         M = jobs[0][0].shape[0]
         if cnt < 1 or M < 1024:                  # outside the kernel's domain, or too few rows for whole-M owners to pay
             self.flush_block_wgrads()
