@@ -306,6 +306,45 @@ def test_trunk_backward_bf16_per_parameter_matches_fp32_oracle():
     assert last[len(last) // 2] < 0.03 and last[int(0.9 * len(last))] < 0.06 and last[-1] < 0.16, ("blocks 36-47", last[len(last) // 2], last[-1], lw)
 
 
+def test_deferred_block_wgrads_equal_per_block_wgrads():
+    """Hiera-L bf16 at 384 px, batch 2 (stage 3: M = 1152 rows, 84 blocks of dW per trunk block -> three trunk blocks per
+    spg_gemm_tn_blocks launch; stage 4 below the row threshold): the engine's deferred whole-block weight gradients (operands of up to
+    three trunk blocks held back, one launch) must give the gradients of the per-block tile kernel.  Same bf16 operands, fp32 accumulation
+    in a different order: every parameter within 2e-5 of the largest gradient of its tensor; activations-side outputs bit-identical."""
+    from spegnet_amd.utils.loss_functions import CODLoss
+    x, masks, edges = O.synthetic_batch(2, 384, seed=33)
+    xs, ms, es = x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda()
+    runs, launches = [], []
+    for deferred in (True, False):
+        m, sd, cfg = make_model("large", "bf16", train=True)
+        m.engine.block_wgrads = deferred
+        crit = CODLoss().cuda()
+        from spegnet_amd import ops
+        calls = []
+        orig = ops.gemm_tn_blocks
+        ops.gemm_tn_blocks = lambda jobs, _o=orig, _c=calls: (_c.append(len(jobs)), _o(jobs))[1]
+        try:
+            out, losses = _train_once(m, crit, xs, ms, es)
+        finally:
+            ops.gemm_tn_blocks = orig
+        launches.append(calls)
+        runs.append((float(losses["loss"].detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    assert launches[1] == [] and len(launches[0]) >= 10 and max(launches[0]) == 12, launches   # 35 uniform stage-3 blocks: 11 launches of 3 x 4 problems
+    (l0, g0), (l1, g1) = runs
+    assert l0 == l1
+    worst = ("", 0.0)
+    for k in g0:
+        scale = float(g1[k].abs().max())
+        if scale == 0.0:
+            assert float(g0[k].abs().max()) == 0.0, k
+            continue
+        e = float((g0[k].float() - g1[k].float()).abs().max()) / scale
+        if e > worst[1]:
+            worst = (k, e)
+    print("deferred vs per-block weight gradients: worst", worst)
+    assert worst[1] < 2e-5, worst
+
+
 def test_config2_train_step_matches_oracle():
     """BASELINE config #2 at full size: batch 8 @384x384, bf16, hipGraph-captured step (what bench.py times).  Loss and global gradient
     norm of the first step against the fp32 CPU oracle on the same batch and weights (the oracle step takes ~30 s of CPU)."""
