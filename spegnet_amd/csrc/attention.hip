@@ -555,6 +555,159 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(SUB ? 3 : 1,
 }
 
 // =====================================================================================================
+// backward in ONE pass for windows of at most 64 keys and 64 queries (Hiera-L at 384 px: stage 1, stage 2's packed 4 x 4 windows, the two
+// transition blocks in front of them, stage 4): one workgroup per (window, head) stages K, V, Q and dO ONCE as four row images, then every
+// wave runs the query-side program of attn_bwd_dq_kernel for its 16 queries and the key-side program of attn_bwd_dkv_kernel for its 16
+// keys, with the stationary fragments read from the images instead of global memory.  Same products in the same order as the two kernels
+// (bit-identical gradients); what goes away is the second launch and the second read of qkv / dO / lse and the delta round trip through
+// memory: at stage 1 the pair moved 275 MB per block for 170 MB of operands and results (42 + 66 us).
+// =====================================================================================================
+template <typename T, int HD, bool SUB = false>
+__global__ __launch_bounds__(AT) void attn_bwd_small_kernel(AttnP p) {
+  using A = AC<T, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kimg = smem;
+  char* vimg = kimg + A::ROW_BYTES;
+  char* qimg = vimg + A::ROW_BYTES;
+  char* doimg = qimg + A::ROW_BYTES;
+  const T** kptr = reinterpret_cast<const T**>(doimg + A::ROW_BYTES);
+  const T** qptrs = kptr + 64;
+  const T** doptrs = qptrs + 64;
+  float* kb = reinterpret_cast<float*>(doptrs + 64);
+  float* lse_s = kb + 64;
+  float* delta_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r15 = lane & 15, q = lane >> 4;
+  const int head = blockIdx.y;
+  const Win w = get_win(p, blockIdx.z);
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* qp = reinterpret_cast<const T*>(p.qp);
+  const int nkeys = w.nvalid + (w.npad > 0 ? 1 : 0);   // (launcher: <= 64, and nq <= 64)
+
+  zero_images<T, HD>(smem, 4 * A::ROW_BYTES);
+  if (tid < 64) {
+    const int c = tid;
+    const T* kp = nullptr;
+    float b = NEG_BIG;
+    if (c < w.nvalid) { kp = qkv + key_row(p, w, c) * 3 * p.C + p.C + head * HD; b = 0.f; }
+    else if (c == w.nvalid && w.npad > 0) { kp = reinterpret_cast<const T*>(p.bias) + p.C + head * HD; b = __logf((float)w.npad); }
+    kptr[tid] = kp; kb[tid] = b;
+  } else if (tid < 128) {
+    const int i = tid - 64;
+    const T* a = nullptr; const T* b = nullptr;
+    float ls = 1.0e30f;
+    if (i < w.nq) {
+      const long row = q_row(p, w, i);
+      a = qp ? qp + row * p.C + head * HD : qkv + row * 3 * p.C + head * HD;
+      b = reinterpret_cast<const T*>(p.dout) + row * p.C + head * HD;
+      ls = p.lse[row * p.heads + head];
+    }
+    qptrs[i] = a; doptrs[i] = b; lse_s[i] = ls;
+  }
+  __syncthreads();
+  stage_tile<T, HD>(kptr, 0, kimg);
+  stage_tile<T, HD>(kptr, p.C, vimg);
+  stage_tile<T, HD>(qptrs, 0, qimg);
+  stage_tile<T, HD>(doptrs, 0, doimg);
+  __syncthreads();
+
+  // ---------------- query side (this lane's query: qi) ----------------
+  const int qi = wave * 16 + r15;
+  const bool qvalid = qi < w.nq;
+  const long qrow = q_row(p, w, qvalid ? qi : 0);
+  {
+    typename A::Frag qf[A::KS], dof[A::KS];
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) {
+      qf[s] = load_row_frag_lds<T, HD>(qimg, qi, s, q);
+      dof[s] = load_row_frag_lds<T, HD>(doimg, qi, s, q);
+    }
+    const T* optr = qvalid ? reinterpret_cast<const T*>(p.out) + qrow * p.C + head * HD : nullptr;
+    float delta = 0.f;
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) delta = frag_dot(dof[s], load_row_frag_global<T, HD>(optr, s, q), delta);
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    if (q == 0) delta_s[qi] = qvalid ? delta : 0.f;
+    const float lse = qvalid ? lse_s[qi] : 0.f;
+    f32x4 dq[A::DB];
+#pragma unroll
+    for (int db = 0; db < A::DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 sacc[4], pacc[4];
+    mma_scores<T, HD>(kimg, qf, lane, sacc);
+    mma_scores<T, HD>(vimg, dof, lane, pacc);
+    float ds[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + nb * 16 + q * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pr = __expf(sacc[nb][r] * p.scale + b4[r] - lse);
+        if constexpr (SUB) { if (!same_sub(p, qi, nb * 16 + q * 4 + r)) pr = 0.f; }
+        ds[nb][r] = pr * (pacc[nb][r] - delta);
+      }
+    }
+    mma_over_tokens<T, HD>(kimg, ds, lane, dq);
+    if (qvalid) {
+      T* dst = p.qp ? reinterpret_cast<T*>(p.dqp) + qrow * p.C + head * HD
+                    : reinterpret_cast<T*>(p.dqkv) + qrow * 3 * p.C + head * HD;
+      store_rows_T<T, HD>(dst, dq, p.scale, lane);
+    }
+  }
+  __syncthreads();          // delta_s complete
+
+  // ---------------- key side (this lane's key: c) ----------------
+  if (wave * 16 < nkeys) {  // (wave-uniform: key blocks past the window's keys have nothing to do)
+    const int c = wave * 16 + r15;
+    const float kbias = kb[c];
+    typename A::Frag kf[A::KS], vf[A::KS];
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) {
+      kf[s] = load_row_frag_lds<T, HD>(kimg, c, s, q);
+      vf[s] = load_row_frag_lds<T, HD>(vimg, c, s, q);
+    }
+    f32x4 dk[A::DB], dv[A::DB];
+#pragma unroll
+    for (int db = 0; db < A::DB; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x4 sacc[4], pacc[4];
+    mma_scores<T, HD>(qimg, kf, lane, sacc);   // S[i][key]
+    mma_scores<T, HD>(doimg, vf, lane, pacc);  // dP[i][key]
+    float pr[4][4], ds[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + nb * 16 + q * 4);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + nb * 16 + q * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[nb][r] = __expf(sacc[nb][r] * p.scale + kbias - l4[r]);
+        if constexpr (SUB) { if (!same_sub(p, nb * 16 + q * 4 + r, c)) pr[nb][r] = 0.f; }
+        ds[nb][r] = pr[nb][r] * (pacc[nb][r] - d4[r]);
+      }
+    }
+    mma_over_tokens<T, HD>(doimg, pr, lane, dv);
+    mma_over_tokens<T, HD>(qimg, ds, lane, dk);
+    if (c < w.nvalid) {
+      const long krow = key_row(p, w, c);
+      T* dst = reinterpret_cast<T*>(p.dqkv) + krow * 3 * p.C + p.C + head * HD;
+      store_rows_T<T, HD>(dst, dk, p.scale, lane);
+      store_rows_T<T, HD>(dst + p.C, dv, 1.f, lane);
+    } else if (c == w.nvalid && w.npad > 0) {
+      float* db_ = p.dbias + p.C + head * HD;
+#pragma unroll
+      for (int db = 0; db < A::DB; ++db) {
+        const int d = db * 16 + q * 4;
+        if (d < HD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(db_ + d + r, dk[db][r] * p.scale);
+            atomicAdd(db_ + p.C + d + r, dv[db][r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================================
 // "resident window" variants (bf16, 64 < keys <= 320, queries <= 256: the stage-3 windows and block 44 of Hiera-L).
 // One workgroup of 8 waves per (window, head): the whole window's K and V (forward, dQ) or Q and dO (dK/dV) are staged ONCE
 // into LDS as row images, then every wave walks its own 16-row blocks over all tiles without any further barrier.  The
@@ -976,6 +1129,11 @@ __global__ __launch_bounds__(RES_THREADS) void attn_res_bwd_kernel(AttnP p, ResP
   else { res_unit(plk, p, plk.first[c] + u, widx, part, nparts); res_dkv_body<T, HD, true>(p, blockIdx.x, widx, part, nparts); }
 }
 
+#ifndef SPG_ATTN_SMALL_BWD   // (A/B builds: -DSPG_ATTN_SMALL_BWD=0 keeps the two-kernel backward for the small windows)
+#define SPG_ATTN_SMALL_BWD 1
+#endif
+static inline bool small_bwd_enabled() { return SPG_ATTN_SMALL_BWD != 0; }
+
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int HD>
 static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
@@ -1036,6 +1194,20 @@ static int launch_attn(int which, AttnP p, int maxq, int maxk, hipStream_t s) {
     if (sub) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<T, HD, false>), dim3(cdiv(maxq, 64), p.heads, nwin), dim3(AT), lds, s, p);
     return check_launch("attn_fwd");
+  }
+  // every window at most 64 keys (incl. the virtual pad key: a window of ws x wsx = 64 slots is either full or has fewer valid keys + 1)
+  // and 64 queries: one pass
+  if (small_bwd_enabled() && maxq <= 64 && (sub ? maxk - 1 : (p.ws * p.wsx <= 64 ? p.ws * p.wsx : maxk)) <= 64) {
+    const size_t lds = 4 * A::ROW_BYTES + 3 * 64 * 8 + 3 * 64 * 4;
+    static bool attr_small = false;
+    if (lds > 65536 && !attr_small) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel<T, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel<T, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_small = true;
+    }
+    if (sub) hipLaunchKernelGGL((attn_bwd_small_kernel<T, HD, true>), dim3(1, p.heads, nwin), dim3(AT), lds, s, p);
+    else hipLaunchKernelGGL((attn_bwd_small_kernel<T, HD, false>), dim3(1, p.heads, nwin), dim3(AT), lds, s, p);
+    return check_launch("attn_bwd(small)");
   }
   {
     const size_t lds = 2 * A::ROW_BYTES + 64 * 8 + 64 * 4;

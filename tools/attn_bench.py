@@ -11,6 +11,8 @@ CASES = [  # name, B, H, W, heads, hd, ws, pooled
     ("s1 win8 (x2)", 8, 96, 96, 2, 72, 8, False),
     ("s4 win8 (x3)", 8, 12, 12, 16, 72, 8, False),
     ("blk44 pooled", 8, 24, 24, 16, 72, 16, True),
+    ("blk2 win8 pooled", 8, 96, 96, 4, 72, 8, True),
+    ("blk8 win4 pooled", 8, 48, 48, 8, 72, 4, True),
 ]
 
 
