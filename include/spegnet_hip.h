@@ -35,7 +35,7 @@ enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
 
 /* ABI revision: bumped with every change of an exported signature.  Bindings must compare spg_version() with the SPG_ABI_VERSION they
  * were written against and refuse to run on a mismatch (spegnet_amd/_lib.py does).  300 = round 3. */
-#define SPG_ABI_VERSION 304
+#define SPG_ABI_VERSION 305
 int spg_version(void);
 const char* spg_last_error(void);
 
@@ -193,13 +193,14 @@ int spg_bn_stats_finalize(int dtype, const void* x, float* stats, const float* g
 long spg_conv3x3_stats_rows(int dtype, int B, int H, int Wd, int Ci, int Co, int cu_budget);
 int spg_conv3x3_fwd_stats(int dtype, const void* X, const void* Wp, void* C, const float* bias, float* stats_part, long part_rows,
                           int B, int H, int Wd, int Ci, int Co, int cu_budget, spg_stream_t stream);
-/* Weight gradient of the same convolution on the same LDS-resident tiles: dW f32 [Co][9*Ci] (the fwd pack's layout) += dY^T (*) X,
+/* Weight gradient of the same convolution on the same LDS-resident tiles: dW f32 += dY^T (*) X, in the fwd pack's layout [Co][9*Ci]
+ * (torch_layout = 0) or straight into the parameter's own gradient [Co][Ci][3][3] (torch_layout = 1: no packed scratch, no unpack launch);
  * dbias f32 [Co] += column sums of dY (may be NULL).  dY NHWC [B,H,W,Co], X NHWC [B,H,W,Ci], bf16.  Deterministic (per-workgroup
  * partial blocks in the caller's workspace, summed in a fixed order by a second launch).  workspace bytes from
  * spg_conv3x3_wgrad_workspace_bytes (0: no instance -- use spg_gemm_tn(conv3x3=1)).  Replaces autograd's conv2d weight gradient.      */
 long spg_conv3x3_wgrad_workspace_bytes(int dtype, int B, int H, int Wd, int Ci, int Co, int cu_budget);
 int spg_conv3x3_wgrad(int dtype, const void* dY, const void* X, float* dW, float* dbias, void* workspace, long workspace_bytes,
-                      int B, int H, int Wd, int Ci, int Co, int cu_budget, spg_stream_t stream);
+                      int B, int H, int Wd, int Ci, int Co, int torch_layout, int cu_budget, spg_stream_t stream);
 int spg_bn_stats_finalize_part(const float* part, long R, float* stats, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, long long* num_batches_tracked, float* scale_shift, float* mean_invstd, long M, int C,
                                float eps, float momentum, float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);

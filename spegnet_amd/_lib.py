@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPG_LIBRARY") or os.path.join(_HERE, "libspegnet_hip.so")
 
 SPG_F32, SPG_BF16 = 0, 1
-ABI_VERSION = 304   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
+ABI_VERSION = 305   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 ACT_GELU_SAVE_GRAD, ACT_MUL_H = 3, 4   # bf16: C2 = gelu'(pre) saved by the forward GEMM | C = acc * gelu_h in the backward GEMM
 
@@ -52,7 +52,7 @@ SIGNATURES = {
     "spg_bn_stats_finalize4": "ipp" "ppppppp" "liff" "plp" "p",
     "spg_bn_stats_finalize_part": "plp" "ppppppp" "liff" "plp" "p",
     "spg_conv3x3_fwd_stats": "ippppp" "l" "iiiiii" "p",
-    "spg_conv3x3_wgrad": "ipppp" "pl" "iiiiii" "p",
+    "spg_conv3x3_wgrad": "ipppp" "pl" "iiiiiii" "p",
     "spg_bn_finalize": "ppppppp" "liffip",
     "spg_bn_apply": "ippp" "liip",
     "spg_bn_bwd_reduce": "ippppp" "lii" "plp" "p",

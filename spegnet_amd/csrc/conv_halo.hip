@@ -786,7 +786,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(WgradArgs a) {
 // lane) and the sixteen partial sums are combined in a fixed tree: with P = 256 splits one thread per output walked 256 dependent-latency
 // loads (55 us for 38 MB); 576 blocks x 256 threads stream them.
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bslabs,
-                                                                   float* __restrict__ dW, float* __restrict__ dbias, int Ci, int nci, int P) {
+                                                                   float* __restrict__ dW, float* __restrict__ dbias, int Ci, int nci, int P,
+                                                                   int torch_layout) {
   __shared__ f32x4 red[16][16];
   const int combo = blockIdx.y;
   const int co0 = (combo / nci) * 64, ci0 = (combo % nci) * 64;
@@ -811,8 +812,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* 
     for (int g_ = 0; g_ < 4; ++g_) t[g_] = (red[4 * g_][o] + red[4 * g_ + 1][o]) + (red[4 * g_ + 2][o] + red[4 * g_ + 3][o]);
     const f32x4 tt = (t[0] + t[1]) + (t[2] + t[3]);
     const int ci = (v & 15) * 4, tp = (v >> 4) % 9, co = (v >> 4) / 9;
-    float* d = dW + ((long)(co0 + co) * 9 + tp) * Ci + ci0 + ci;
-    *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + tt;
+    if (torch_layout) {   // dW is the parameter's own gradient [Co][Ci][3][3]: no packed scratch, no unpack launch
+      float* d = dW + ((long)(co0 + co) * Ci + ci0 + ci) * 9 + tp;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[9 * e] += tt[e];
+    } else {
+      float* d = dW + ((long)(co0 + co) * 9 + tp) * Ci + ci0 + ci;
+      *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + tt;
+    }
   }
   if (dbias && bslabs && ci0 == 0 && blockIdx.x == 0) {   // (a serial walk over P = 256 splits took 65 us: four lanes per channel, four loads in flight)
     __shared__ float bred[4][64];
@@ -847,7 +854,7 @@ long conv3x3_wgrad_halo_ws_floats(int B, int H, int W, int Ci, int Co, int cus) 
 
 // dW f32 [Co][9][Ci] += conv-wgrad(dY, X); dbias [Co] += column sums of dY (may be null).  Returns 1 when outside the kernel's domain.
 int launch_conv3x3_wgrad_halo(const void* dY, const void* X, float* dW, float* dbias, float* ws, long ws_floats, int B, int H, int W, int Ci,
-                              int Co, int cus, hipStream_t s) {
+                              int Co, int cus, hipStream_t s, int torch_layout) {
   const long need = conv3x3_wgrad_halo_ws_floats(B, H, W, Ci, Co, cus);
   if (need <= 0 || !ws || ws_floats < need) return 1;
   WgradArgs a;
@@ -873,7 +880,7 @@ int launch_conv3x3_wgrad_halo(const void* dY, const void* X, float* dW, float* d
   int rc = check_launch("conv3x3_wgrad_halo");
   if (rc) return rc;
   hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(WG_SLAB_FLOATS / 4 / 16, combos), dim3(256), 0, s, (const float*)a.slabs,
-                     (const float*)a.bslabs, dW, dbias, Ci, a.nci, P);
+                     (const float*)a.bslabs, dW, dbias, Ci, a.nci, P, torch_layout);
   return check_launch("conv3x3_wgrad_halo(reduce)");
 }
 
@@ -996,13 +1003,14 @@ extern "C" long spg_conv3x3_wgrad_workspace_bytes(int dtype, int B, int H, int W
   return dtype == SPG_BF16 ? 4L * conv3x3_wgrad_halo_ws_floats(B, H, Wd, Ci, Co, halo_cus(cu_budget)) : 0;
 }
 extern "C" int spg_conv3x3_wgrad(int dtype, const void* dY, const void* X, float* dW, float* dbias, void* workspace, long workspace_bytes,
-                                 int B, int H, int Wd, int Ci, int Co, int cu_budget, spg_stream_t stream) {
+                                 int B, int H, int Wd, int Ci, int Co, int torch_layout, int cu_budget, spg_stream_t stream) {
   SPG_REQUIRE(dtype == SPG_BF16, "conv3x3_wgrad: bf16 only (dtype %d)", dtype);
   const int cus = halo_cus(cu_budget);
   const long need = 4L * conv3x3_wgrad_halo_ws_floats(B, H, Wd, Ci, Co, cus);
   SPG_REQUIRE(need > 0, "conv3x3_wgrad: no instance for B=%d H=%d W=%d Ci=%d Co=%d (ask spg_conv3x3_wgrad_workspace_bytes first)", B, H, Wd, Ci, Co);
   SPG_REQUIRE(workspace && workspace_bytes >= need, "conv3x3_wgrad: workspace of %ld bytes needed (got %ld)", need, workspace_bytes);
-  const int rc = launch_conv3x3_wgrad_halo(dY, X, dW, dbias, (float*)workspace, workspace_bytes / 4, B, H, Wd, Ci, Co, cus, (hipStream_t)stream);
+  const int rc = launch_conv3x3_wgrad_halo(dY, X, dW, dbias, (float*)workspace, workspace_bytes / 4, B, H, Wd, Ci, Co, cus, (hipStream_t)stream,
+                                           torch_layout);
   if (rc == 1) { set_error("conv3x3_wgrad: problem outside the kernel's domain"); return SPG_ERR_UNSUPPORTED; }
   return rc;
 }

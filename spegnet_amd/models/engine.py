@@ -523,6 +523,8 @@ class Engine:
         gw, gb = self.grad(name + ".weight"), (self.grad(name + ".bias") if bias else None)
 
         def launch():
+            if ops.conv3x3_wgrad_direct(dy, x, gw, gb, (B, H, W, Ci)):     # halo-tile kernel, straight into the [Co,Ci,3,3] gradient
+                return
             gp = ops.zeros_f32((Co, 9 * Ci), dy.device)
             ops.gemm_tn(dy, x, gp, conv=(B, H, W, Ci), dbias=gb)
             ops.unpack_conv3x3_grad(gp, gw)

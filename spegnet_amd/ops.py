@@ -190,7 +190,7 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
         if hb > 0:
             hws = torch.empty(hb, dtype=torch.uint8, device=x.device)
             with _prof("gemm_tn<bf16,conv3x3> (+reduce)", "mfma", 2.0 * M * N * K):
-                _lib.call("spg_conv3x3_wgrad", dcode(x), _p(_c(dy)), _p(_c(x)), dw.data_ptr(), _p(dbias), _p(hws), hb, B, H, W, Ci, N,
+                _lib.call("spg_conv3x3_wgrad", dcode(x), _p(_c(dy)), _p(_c(x)), dw.data_ptr(), _p(dbias), _p(hws), hb, B, H, W, Ci, N, 0,
                           cu_budget_now(), _stream())
             return
     wsb = _lib.load().spg_gemm_tn_workspace_bytes(dcode(x), M, N, K)
@@ -289,6 +289,24 @@ def tn_blocks_count(jobs) -> int:
 def num_cus() -> int:
     """CUs the persistent grids are sized for under the calling thread's CU budget."""
     return int(_lib.load().spg_num_cus(cu_budget_now()))
+
+
+def conv3x3_wgrad_direct(dy: Tensor, x: Tensor, gw: Tensor, dbias: Optional[Tensor], conv: tuple) -> bool:
+    """gw [Co,Ci,3,3] f32 (the parameter's own gradient) += the 3x3 convolution's weight gradient, dbias += colsum(dy), by the halo-tile
+    kernel writing the torch layout itself (no packed scratch, no zero fill, no unpack launch).  False: no instance for the shape (the
+    caller goes through gemm_tn(conv=...) + unpack_conv3x3_grad)."""
+    B, H, W, Ci = conv
+    Co = dy.shape[-1]
+    if not (x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and gw.dtype == torch.float32 and gw.is_contiguous() and gw.numel() == Co * Ci * 9):
+        return False
+    hb = _lib.load().spg_conv3x3_wgrad_workspace_bytes(dcode(x), B, H, W, Ci, Co, cu_budget_now())
+    if hb <= 0:
+        return False
+    hws = torch.empty(hb, dtype=torch.uint8, device=x.device)
+    with _prof("gemm_tn<bf16,conv3x3> (+reduce)", "mfma", 2.0 * B * H * W * Co * 9 * Ci):
+        _lib.call("spg_conv3x3_wgrad", dcode(x), _p(_c(dy)), _p(_c(x)), gw.data_ptr(), _p(dbias), _p(hws), hb, B, H, W, Ci, Co, 1,
+                  cu_budget_now(), _stream())
+    return True
 
 
 def gemm_tn_blocks(jobs) -> None:

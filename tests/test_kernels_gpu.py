@@ -954,3 +954,11 @@ def test_conv3x3_wgrad_halo_matches_torch(ops, B, H, W, Ci, Co):
     ops.unpack_conv3x3_grad(dwp - 0.5, dwt)
     check(dwt, w.grad, 2e-3, "conv wgrad (halo)")
     check(dbc + 1.0, dyn.float().sum((0, 1, 2)), 1e-4, "conv fused bias grad (halo)")
+    # torch_layout = 1: the reduce adds straight into a [Co,Ci,3,3] gradient -- the same sums, element for element
+    gw = torch.full((Co, Ci, 3, 3), 0.25, device="cuda")
+    gb = torch.full((Co,), -1.0, device="cuda")
+    assert ops.conv3x3_wgrad_direct(dyn, xn, gw, gb, (B, H, W, Ci))
+    want = torch.zeros(Co, Ci, 3, 3, device="cuda")
+    ops.unpack_conv3x3_grad(dwp - 0.5, want)
+    check(gw - 0.25, want, 1e-6, "conv wgrad written in the torch layout")
+    assert torch.equal(gb, dbc)
