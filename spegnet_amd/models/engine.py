@@ -55,7 +55,7 @@ class Engine:
         # launch in which every workgroup owns a whole block over all of M -- no partial sums, no reduce.  Their dY / X operands stay
         # referenced by the pending list until then.  Not used while a per-unit gradient callback needs finished ranges mid-backward.
         self.block_wgrads = os.environ.get("SPG_BLOCK_WGRADS", "1") != "0"
-        self._wg_pending = []       # [(jobs of one trunk block, its block count)]
+        self._wg_pending = {}       # M -> [(jobs of one trunk block with that row count, their block count)]
         self.batch_ln_params = True  # trunk: LayerNorm dgamma / dbeta in batched launches
         self._ln_jobs = []
         self._tn_defer = []
@@ -287,24 +287,35 @@ class Engine:
         return total / float(-(-total // cus) * cus)
 
     def queue_block_wgrads(self, jobs) -> None:
-        """One trunk block's wgrad jobs: launched now (grouped tile kernel) or held until the pending trunk blocks fill whole rounds of CUs."""
-        # (not under a CU budget -- graph segments that replay beside a collective: 84-block sets no longer fill whole rounds of 240 CUs)
+        """One trunk block's wgrad jobs.  Problems outside the whole-block kernel's domain go out now (grouped tile kernel); the others
+        join the pending set of their row count M and wait until the set fills whole rounds of CUs.  (A transition block has problems
+        with two different M: each part joins its own set -- block 44's M = 4608 part rides with the first stage-3 blocks.)"""
         use = self.block_wgrads and self.unit_cb is None and not self.wgrad_async and ops.cu_budget_now() == 0
-        cnt = ops.tn_blocks_count(jobs) if use else -1
-        M = jobs[0][0].shape[0]
-        if cnt < 1 or M < 1024:                  # outside the kernel's domain, or too few rows for whole-M owners to pay
-            self.flush_block_wgrads()
-            self._issue_block_wgrads(jobs)
-            return
-        pend = self._wg_pending
-        if pend and (pend[0][0][0][0].shape[0] != M or sum(len(j) for j, _ in pend) + len(jobs) > ops.TN_BLOCKS_MAX):
-            self.flush_block_wgrads()
-        pend.append((jobs, cnt))
-        if self._round_fill(sum(c for _, c in pend), ops.num_cus()) >= 0.9:        # the rounds are full: go now, release the operands
-            self.flush_block_wgrads()
+        # (not under a CU budget -- graph segments that replay beside a collective: 84-block sets no longer fill whole rounds of 240 CUs)
+        by_m, now = {}, []
+        for j in jobs:
+            M = j[0].shape[0]
+            if use and M >= 1024 and ops.tn_blocks_count([j]) > 0:
+                by_m.setdefault(M, []).append(j)
+            else:
+                now.append(j)
+        if now:
+            self._issue_block_wgrads(now)
+        cus = ops.num_cus()
+        for M, part in by_m.items():
+            cnt = ops.tn_blocks_count(part)
+            pend = self._wg_pending.setdefault(M, [])
+            total = sum(c for _, c in pend)
+            if pend and (sum(len(j) for j, _ in pend) + len(part) > ops.TN_BLOCKS_MAX or
+                         (self._round_fill(total + cnt, cus) < self._round_fill(total, cus) and self._round_fill(total, cus) >= 0.75)):
+                self._flush_pending(M)       # the set is as full as it gets: another trunk block would open a nearly empty round
+                pend = self._wg_pending.setdefault(M, [])
+            pend.append((part, cnt))
+            if self._round_fill(sum(c for _, c in pend), cus) >= 0.9:              # the rounds are full: go now, release the operands
+                self._flush_pending(M)
 
-    def flush_block_wgrads(self) -> None:
-        pend, self._wg_pending = self._wg_pending, []
+    def _flush_pending(self, M) -> None:
+        pend = self._wg_pending.pop(M, [])
         if not pend:
             return
         if self._round_fill(sum(c for _, c in pend), ops.num_cus()) >= 0.75:
@@ -312,6 +323,10 @@ class Engine:
         else:
             for jobs, _ in pend:
                 self._issue_block_wgrads(jobs)
+
+    def flush_block_wgrads(self) -> None:
+        for M in list(self._wg_pending.keys()):
+            self._flush_pending(M)
 
     # ------------------------------------------------------------------------------------------------ linear helpers
     def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
