@@ -4237,7 +4237,23 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   SPG_REQUIRE(tiles * S < 0x7FFFFFFFL, "gemm_tn_group: too many steps");
   g.njobs = njobs; g.M = M; g.S = S; g.T = (int)tiles;
   const long total_steps = tiles * S;
-  const int G = total_steps < num_cus(cu_budget) ? (int)total_steps : num_cus(cu_budget);
+  int G = total_steps < num_cus(cu_budget) ? (int)total_steps : num_cus(cu_budget);
+#ifndef SPG_TN_ALIGN   // (A/B builds: -DSPG_TN_ALIGN=0 keeps one workgroup per CU whatever the tile count)
+#define SPG_TN_ALIGN 1
+#endif
+  // Fewer tiles than CUs: every tile is cut into `parts` runs of steps.  With G = CUs the cuts fall at multiples of T S / G steps (stage 2:
+  // 84 tiles x 288 steps / 256 = 94.5), so no two workgroups ever walk the same rows of M at the same time and every operand panel comes
+  // from HBM once per TILE (measured: 583 MB fetched per stage-2 launch for 170 MB of operands, 98 us = 5.9 TB/s: HBM-bound).  With
+  // G = T x parts (252) a run is exactly S / parts steps: the workgroups that hold the same part of neighbouring tiles start at the same
+  // row, walk in lockstep and share the dY / X panels through their XCD's L2.  parts = 1 (243 tiles): whole tiles, no slabs at all.
+  // Measured (tools/tn_group_bench.py, same box): a stage-2 trunk block 103.3 -> 70.3 us, the train step 22.9 -> 22.7 ms.
+  if (SPG_TN_ALIGN && tiles <= G && total_steps >= G) {
+    for (int parts = G / (int)tiles; parts >= 1; --parts) {
+      if (S % parts != 0) continue;
+      if ((long)tiles * parts * 100 >= (long)G * 85) G = (int)tiles * parts;     // (at least 85 % of the CUs keep a workgroup)
+      break;
+    }
+  }
   g.W = (int)(tiles / G);
   g.RS = (int)((tiles - (long)g.W * G) * S);
   const long need = (long)G * 2 * TN_SLOT_FLOATS * (long)sizeof(float);
