@@ -2212,6 +2212,7 @@ struct TnGroup {
   TnJob job[TN_GROUP_MAX];
   int njobs, M, S, T;         // S = 64-row steps per tile, T = tiles in all
   int W, RS;                  // whole tiles per workgroup; steps of the remainder tiles (shared evenly)
+  int parts;                  // > 0: G = T x parts workgroups, a run = S / parts steps (aligned cuts); physical workgroup ids are part-major
 };
 
 __device__ __forceinline__ void tn_locate_tile(const TnGroup& g, int gt, int& j, int& tile) {
@@ -2522,7 +2523,10 @@ __global__ __launch_bounds__((CW + 4) * 64) void gemm_tn_group4_kernel(TnGroup g
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = (int)gridDim.x;
-  const int c = xcd_remap(blockIdx.x, G);
+  // aligned cuts: physical ids (contiguous per XCD) run part-major -- an XCD holds the SAME part of ~32 different tiles, which start at the
+  // same row of M, walk in lockstep and share their dY / X panels through that L2; logical c (tile-major) names the slab slots
+  const int ci = xcd_remap(blockIdx.x, G);
+  const int c = g.parts > 0 ? (ci % g.T) * g.parts + ci / g.T : ci;
   const int S = g.S;
   const int WS = g.W * S;                                                   // steps of this workgroup's whole tiles
   const int rb = (int)((long)c * g.RS / G), re = (int)((long)(c + 1) * g.RS / G);   // its share of the remainder steps
@@ -4247,10 +4251,11 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   // G = T x parts (252) a run is exactly S / parts steps: the workgroups that hold the same part of neighbouring tiles start at the same
   // row, walk in lockstep and share the dY / X panels through their XCD's L2.  parts = 1 (243 tiles): whole tiles, no slabs at all.
   // Measured (tools/tn_group_bench.py, same box): a stage-2 trunk block 103.3 -> 70.3 us, the train step 22.9 -> 22.7 ms.
+  g.parts = 0;
   if (SPG_TN_ALIGN && tiles <= G && total_steps >= G) {
     for (int parts = G / (int)tiles; parts >= 1; --parts) {
       if (S % parts != 0) continue;
-      if ((long)tiles * parts * 100 >= (long)G * 85) G = (int)tiles * parts;     // (at least 85 % of the CUs keep a workgroup)
+      if ((long)tiles * parts * 100 >= (long)G * 85) { G = (int)tiles * parts; g.parts = SPG_TN_ALIGN == 2 ? 0 : parts; }   // (at least 85 % of the CUs keep a workgroup)
       break;
     }
   }
