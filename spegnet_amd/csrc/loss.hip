@@ -289,28 +289,34 @@ __global__ __launch_bounds__(256) void loss_dz_kernel(const T* __restrict__ pred
     dz[i] = g;
   }
 }
-// pass 2: one 64-lane wave per low-res logit over its (3 sy) x (3 sx) candidate window (candidates outside its taps weigh 0)
-template <typename T>
+// pass 2: a group of L lanes per low-res logit over its (2 sy) x (2 sx) candidate window ((3 sy) x (3 sx) for an odd scale; candidates
+// outside its taps weigh 0).  L is sized to the window -- 4 lanes for the x2 scale's 16 candidates, 16 for x4's 64, a whole wave for x8's
+// 256: with a wave per logit the x2 scale (295 k logits at batch 8) ran 16 of 64 lanes for one load each, 38 us per launch.
+template <typename T, int L>
 __global__ __launch_bounds__(256) void loss_gather_kernel(const float* __restrict__ dz, const float* __restrict__ go, T* __restrict__ dpred,
                                                           int B, int S, int h, int w, float coef) {
   const long total = (long)B * h * w;
   const long HW = (long)S * S;
   const int sy = S / h, sx = S / w;
   const float g0 = go ? go[0] : 1.f;
-  const int lane = threadIdx.x & 63;
-  const long wave0 = (blockIdx.x * 256L + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * 256) >> 6;
-  for (long i = wave0; i < total; i += nwaves) {
-    const int xl = (int)(i % w);
-    const int yl = (int)((i / w) % h);
-    const int b = (int)(i / ((long)w * h));
+  const int sub = threadIdx.x & (L - 1);
+  const long grp0 = (blockIdx.x * 256L + threadIdx.x) / L, ngrp = ((long)gridDim.x * 256) / L;
+  const long iters = (total + ngrp - 1) / ngrp;             // (every lane of a wave runs the same number of rounds: the shuffles need them all)
+  for (long it = 0; it < iters; ++it) {
+    const long i = grp0 + it * ngrp;
+    const bool live = i < total;
+    const long ii = live ? i : 0;
+    const int xl = (int)(ii % w);
+    const int yl = (int)((ii / w) % h);
+    const int b = (int)(ii / ((long)w * h));
     // full-res pixels whose taps include (yl, xl): source coordinate (Y + 0.5) / sy - 0.5 in [yl - 1, yl + 1), i.e. for an even scale
     // exactly the 2 sy rows [yl sy - sy/2, yl sy + 3 sy/2 - 1] (clamped: the border clamps of the interpolation fall inside); an odd
     // scale keeps the conservative (3 sy)-row window -- candidates outside the taps weigh 0 either way
     const int Y0 = (sy & 1) ? max(0, (yl - 1) * sy) : max(0, yl * sy - sy / 2), Y1 = (sy & 1) ? min(S - 1, (yl + 2) * sy) : min(S - 1, yl * sy + 3 * sy / 2 - 1);
     const int X0 = (sx & 1) ? max(0, (xl - 1) * sx) : max(0, xl * sx - sx / 2), X1 = (sx & 1) ? min(S - 1, (xl + 2) * sx) : min(S - 1, xl * sx + 3 * sx / 2 - 1);
-    const int nx = X1 - X0 + 1, ncand = (Y1 - Y0 + 1) * nx;
+    const int nx = X1 - X0 + 1, ncand = live ? (Y1 - Y0 + 1) * nx : 0;
     float acc = 0.f;
-    for (int c = lane; c < ncand; c += 64) {
+    for (int c = sub; c < ncand; c += L) {
       const int Y = Y0 + c / nx, X = X0 + c % nx;
       float wy, wx;
       { int y0, y1; float ly; bil_src_l(Y, h, S, y0, y1, ly); wy = (y0 == yl ? 1.f - ly : 0.f) + (y1 == yl ? ly : 0.f); }
@@ -318,8 +324,9 @@ __global__ __launch_bounds__(256) void loss_gather_kernel(const float* __restric
       const float wgt = wy * wx;
       if (wgt != 0.f) acc += wgt * dz[b * HW + (long)Y * S + X];
     }
-    acc = wave_sum(acc);
-    if (lane == 0) ST<T>::st(dpred + i, acc * coef * g0);
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0 && live) ST<T>::st(dpred + i, acc * coef * g0);
   }
 }
 
@@ -386,10 +393,15 @@ extern "C" int spg_loss_grad(int dtype, const void* pred, const float* target, c
     }
     int rc = check_launch("loss_grad(dz)");
     if (rc) return rc;
-    long g2 = ((long)B * h * w + 3) / 4;
+    // lanes per logit: a quarter of the even-scale window's candidates each (at least 4, at most a wave)
+    const int win = (S / h) * (S / w) * (((S / h) & 1) ? 9 : 4);
+    const int L = win <= 16 ? 4 : (win <= 64 ? 16 : 64);
+    long g2 = ((long)B * h * w * L + 255) / 256;
     if (g2 > 8192) g2 = 8192;
-    if (dtype == SPG_BF16) hipLaunchKernelGGL(loss_gather_kernel<bf16_t>, dim3((int)g2), dim3(256), 0, s2, dz_ws, grad_out, (bf16_t*)dpred, B, S, h, w, coef);
-    else hipLaunchKernelGGL(loss_gather_kernel<float>, dim3((int)g2), dim3(256), 0, s2, dz_ws, grad_out, (float*)dpred, B, S, h, w, coef);
+#define SPG_GATHER(T_, L_) hipLaunchKernelGGL((loss_gather_kernel<T_, L_>), dim3((int)g2), dim3(256), 0, s2, dz_ws, grad_out, (T_*)dpred, B, S, h, w, coef)
+    if (dtype == SPG_BF16) { if (L == 4) SPG_GATHER(bf16_t, 4); else if (L == 16) SPG_GATHER(bf16_t, 16); else SPG_GATHER(bf16_t, 64); }
+    else { if (L == 4) SPG_GATHER(float, 4); else if (L == 16) SPG_GATHER(float, 16); else SPG_GATHER(float, 64); }
+#undef SPG_GATHER
     return check_launch("loss_grad(gather)");
   }
   const long total = (long)B * h * w;   // one wave per low-res pixel (one thread when h == S)
