@@ -482,6 +482,7 @@ class Engine:
     # gradient all-reduce of finished ranges between them (engine/trainer.py, multi-GPU graph mode).
     def trunk_bwd_begin(self, ctx, dfeats: List[Optional[Tensor]]):
         self._bw = dict(ctx=ctx, dfeats=dfeats, dx=None, stage=len(dfeats) - 1, unit=0)
+        self._wg_pending = {}     # (a backward that raised half-way must not leave its deferred weight gradients to the next one)
         if self.unit_cb is not None:
             self.unit_cb(0)   # head gradients are final once trunk backward starts
 

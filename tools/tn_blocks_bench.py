@@ -39,7 +39,7 @@ for b in range(NBLK):
     for N, K in LAYER:
         dy = torch.randn(M, N, device="cuda").to(torch.bfloat16)
         x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
-        jobs.append((dy, x, torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")))
+        jobs.append((dy, x, torch.zeros(N, K, device="cuda"), None if os.environ.get("NOBIAS") else torch.zeros(N, device="cuda")))
     blocks.append(jobs)
 flat = [j for jobs in blocks for j in jobs]
 fl = sum(2.0 * M * j[0].shape[-1] * j[1].shape[-1] for j in flat)
