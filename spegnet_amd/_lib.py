@@ -121,6 +121,10 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  Loaded after this library, the process would hold two
+    # runtimes -- this library bound to the system one, which then finds no device ("no ROCm-capable device is detected" on the first
+    # launch; seen on the GPU box when build() and smoke() ran in one process)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the SPEGNet HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
