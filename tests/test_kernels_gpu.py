@@ -897,8 +897,8 @@ def test_fused_codloss_matches_torch_formula(dt, case):
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 9, 33, 64, 64), (3, 17, 31, 128, 320), (2, 48, 48, 256, 64), (8, 96, 96, 64, 128)])
 def test_conv3x3_fwd_stats_matches_conv_then_bn_stats(ops, B, H, W, Ci, Co):
-    """The fused launch (halo-tile convolution whose epilogue writes per-tile BatchNorm partial sums) + bn_stats_finalize_part against the
-    unfused pair: the convolution output must be bit-identical to gemm_nt(conv=...), and scale/shift, mean/invstd and the running statistics
+    """The fused launch (halo-tile convolution whose epilogue writes per-tile BatchNorm partial sums) + bn_stats_finalize_part: the
+    convolution output against torch's F.conv2d on the bf16-rounded operands (and bit-identical to the non-STATS instance), and scale/shift, mean/invstd and the running statistics
     must equal those of bn_stats_finalize over that output (both reduce the same rounded values in fp32; only the summation order differs).
     Ragged tiles (H, W no multiples of 8 / 32) check that masked pixels stay out of the sums; Co = 320 the five 64-wide n-tiles."""
     dt = torch.bfloat16
@@ -909,6 +909,10 @@ def test_conv3x3_fwd_stats_matches_conv_then_bn_stats(ops, B, H, W, Ci, Co):
     sp = B * ((H + 7) // 8) * ((W + 31) // 32)
     assert rows == (4 * min(sp, 256) if Co in (64, 128) else 4 * sp)
     out, part = ops.conv3x3_fwd_stats(x, w, bias, B, H, W, Ci, rows)
+    # the reference is torch's convolution on the same bf16-rounded operands (fp32 arithmetic); the non-STATS instance of the halo kernel
+    # must give the same bits, but is not a reference (ops.gemm_nt(conv=...) routes these shapes to the same kernel family)
+    want = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    check(out.float().view(B, H, W, Co), want, 1e-2, "halo conv (STATS instance) vs F.conv2d")
     ref = ops.gemm_nt(x, w, bias=bias, conv=(B, H, W, Ci))
     assert torch.equal(out, ref)
     M = B * H * W
@@ -962,3 +966,66 @@ def test_conv3x3_wgrad_halo_matches_torch(ops, B, H, W, Ci, Co):
     ops.unpack_conv3x3_grad(dwp - 0.5, want)
     check(gw - 0.25, want, 1e-6, "conv wgrad written in the torch layout")
     assert torch.equal(gb, dbc)
+
+
+# (B, H, W, Ci, Co): the halo-tile kernel's instances and edge cases, each against torch (tools/conv_check.py's SMALL list)
+HALO_SHAPES = [(1, 8, 32, 64, 64),      # exactly one 8 x 32 tile, one 64-channel chunk, BN = 64
+               (2, 9, 33, 64, 64),      # ragged in both directions: masked pixels, one-pixel tiles
+               (1, 16, 64, 128, 128),   # 2 x 2 tiles, two K chunks, BN = 128
+               (2, 24, 40, 64, 256),    # Co = 256: two 128-wide n-tiles
+               (1, 40, 72, 320, 64),    # Ci = 320: five K chunks (PED conv1 of stages 1 / 2)
+               (3, 17, 31, 128, 320),   # Co = 320: five 64-wide n-tiles (dgrad of those convolutions)
+               (2, 48, 48, 256, 64),    # the EFE convolution's geometry
+               (1, 200, 96, 64, 128)]   # more tiles than a workgroup's first round: the persistent tile walk
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", HALO_SHAPES)
+def test_conv3x3_halo_fwd_dgrad_match_torch(ops, B, H, W, Ci, Co):
+    """bf16 3x3 convolution forward and input gradient on the halo-tile kernel (csrc/conv_halo.hip; every shape here is in its domain:
+    Ci, Co multiples of 64) against torch's fp32 convolution / autograd on the same bf16-rounded operands.  Replaces nn.Conv2d(3, pad 1)
+    of the reference's EdgeDetectionModule / DecoderBlock (models/object_detection.py:115-123, 193-199, 230-236).  Outputs are rounded
+    to bf16 once (2^-9 of the value), so 1e-2 of the largest reference value is ~3x the rounding."""
+    dt = torch.bfloat16
+    x = rnd(B, Ci, H, W, seed=1).to(dt).float().requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=(9 * Ci) ** -0.5).to(dt).float().requires_grad_(True)
+    bias = rnd(Co, seed=3)
+    y = F.conv2d(x, w, bias, padding=1)
+    dy = rnd(B, Co, H, W, seed=4).to(dt).float()
+    y.backward(dy)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(dt)
+    wf, wd = ops.pack_conv3x3(w.detach().contiguous(), dt)
+    assert ops.conv3x3_stats_rows(xn, B, H, W, Ci, Co) > 0, "shape must be in the halo kernel's domain"
+    out = torch.full((B * H * W, Co), float("nan"), device="cuda", dtype=dt)
+    ops.gemm_nt(xn, wf, bias=bias, conv=(B, H, W, Ci), out=out)
+    assert bool(torch.isfinite(out.float()).all()), "every output element must be written"
+    check(out.float().view(B, H, W, Co).permute(0, 3, 1, 2), y.detach(), 1e-2, "halo conv fwd")
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(dt)
+    dx = torch.full((B * H * W, Ci), float("nan"), device="cuda", dtype=dt)
+    ops.gemm_nt(dyn, wd, conv=(B, H, W, Co), out=dx)
+    assert bool(torch.isfinite(dx.float()).all())
+    check(dx.float().view(B, H, W, Ci).permute(0, 3, 1, 2), x.grad, 1e-2, "halo conv dgrad")
+
+
+def test_conv3x3_halo_image_groups_beyond_one_descriptor(ops):
+    """Operands larger than one buffer descriptor reaches (input >= 2 GiB): the launcher splits the batch into image groups.  Reduced
+    channel count (64 -> 64) so the case stays cheap: 5 images of 1840 x 1840 = 2.17 GB of input, groups of 4 + 1.  Every image against
+    torch's convolution (one image at a time, fp32 on the bf16-rounded operands)."""
+    dt = torch.bfloat16
+    B, H, W, Ci, Co = 5, 1840, 1840, 64, 64
+    assert B * H * W * Ci * 2 >= 0x7FFFFFF0
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, H, W, Ci, device="cuda", generator=g).to(dt)
+    w = (torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) * (9 * Ci) ** -0.5).to(dt)
+    bias = torch.randn(Co, device="cuda", generator=g)
+    wf, _ = ops.pack_conv3x3(w.float().contiguous(), dt)
+    out = torch.full((B * H * W, Co), float("nan"), device="cuda", dtype=dt)
+    ops.gemm_nt(x, wf, bias=bias, conv=(B, H, W, Ci), out=out)
+    out = out.view(B, H, W, Co)
+    wt = w.float()
+    for b in range(B):
+        ref = F.conv2d(x[b:b + 1].float().permute(0, 3, 1, 2), wt, bias, padding=1)[0].permute(1, 2, 0)
+        got = out[b].float()
+        assert bool(torch.isfinite(got).all()), f"image {b}: unwritten output"
+        e = float((got - ref).abs().max() / ref.abs().max())
+        assert e < 1e-2, f"image {b}: rel err {e:.3e}"
+        del ref, got

@@ -306,6 +306,95 @@ def test_trunk_backward_bf16_per_parameter_matches_fp32_oracle():
     assert last[len(last) // 2] < 0.03 and last[int(0.9 * len(last))] < 0.06 and last[-1] < 0.16, ("blocks 36-47", last[len(last) // 2], last[-1], lw)
 
 
+def _head_grads_oracle(sd, feats_nchw, dws, round_bf16):
+    """fp32 CPU oracle gradients of  loss = sum_i <pred_i, w_i> + <edge, w_e>  w.r.t. every head parameter and the three feature maps.
+    round_bf16: the yardstick -- the same fp32 arithmetic with ONLY the weights and the inputs rounded to bf16 once."""
+    rd = (lambda t: t.to(torch.bfloat16).float()) if round_bf16 else (lambda t: t)
+    osd = {k: (rd(v.clone()) if (v.is_floating_point() and not O.is_buffer_key(k)) else v.clone()) for k, v in sd.items()}
+    params = {k: v.requires_grad_(True) for k, v in osd.items() if not O.is_buffer_key(k) and not k.startswith("encoder.")}
+    fin = [rd(f.clone()).requires_grad_(True) for f in feats_nchw]
+    out = O.head_forward(osd, fin, training=True)
+    loss = sum((p_ * w).sum() for p_, w in zip(out["predictions"] + [out["edge"]], dws))
+    gs = torch.autograd.grad(loss, list(params.values()) + fin, allow_unused=True)
+    n = len(params)
+    return dict(zip(params.keys(), gs[:n])), list(gs[n:]), out
+
+
+def test_head_backward_bf16_per_parameter_matches_fp32_oracle():
+    """Well-conditioned check of the bf16 HEAD backward kernels composed (conv3x3_halo dgrad, conv3x3_wgrad_halo, bn_bwd / bn_bwd_head,
+    ped_gather_bwd, e-ASPP backward, SE, the CFI fusion's three dgrads): head_fwd / head_bwd driven by FIXED feature maps and FIXED upstream
+    gradients on the three predictions and the edge map at batch 16 (train-mode BatchNorm over >= 16 samples per channel everywhere,
+    the global e-ASPP branch included), PER PARAMETER against the fp32 CPU oracle (reference models/object_detection.py:115-123,193-199,
+    219-236; models/feature_integration.py:205-246,369-417).  Thresholds come from the yardstick computed in the same test: the fp32 oracle
+    with only the weights and the inputs rounded to bf16 -- the bf16 path, which also rounds every stored activation, may be a small
+    multiple of that away.  The five worst parameters are printed."""
+    m, sd, cfg = make_model("large", "bf16", train=True)
+    B, S = 16, 96
+    g = torch.Generator().manual_seed(77)
+    C2, C3, C4 = 2 * cfg["embed_dim"], 4 * cfg["embed_dim"], 8 * cfg["embed_dim"]
+    shapes = [(B, C2, S // 8, S // 8), (B, C3, S // 16, S // 16), (B, C4, S // 32, S // 32)]
+    feats = [torch.randn(sh, generator=g).to(torch.bfloat16).float() for sh in shapes]           # NCHW, exactly representable in bf16
+    pshapes = [(B, 1, S // 4, S // 4), (B, 1, S // 2, S // 2), (B, 1, S, S), (B, 1, S // 8, S // 8)]
+    # upstream gradients: smooth positive patterns, different per image and per output.  (With i.i.d. noise every parameter gradient
+    # is a random-walk sum over pixels and a 1 % change of the ReLU masks moves it by 10 %: nothing could be told apart.)
+    import math
+
+    def smooth(sh, k):
+        Bq, _, H, W = sh
+        yy, xx = torch.arange(H).float().view(1, 1, H, 1) / H, torch.arange(W).float().view(1, 1, 1, W) / W
+        bb = torch.arange(Bq).float().view(Bq, 1, 1, 1) / Bq
+        w = (1.0 + 0.5 * torch.cos(2 * math.pi * (xx + bb + 0.1 * k)) * torch.sin(math.pi * (yy + 0.05 * k))) / (H * W) ** 0.5
+        return w.to(torch.bfloat16).float()
+    dws = [smooth(sh, k) for k, sh in enumerate(pshapes)]
+    g_ref, gf_ref, out_ref = _head_grads_oracle(sd, feats, dws, False)
+    g_yard, gf_yard, _ = _head_grads_oracle(sd, feats, dws, True)
+    eng = m.engine
+    for p_ in m.parameters():
+        p_.grad = None
+    fn = [f.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda() for f in feats]
+    out, hctx = eng.head_fwd(fn, True, True)
+    for i in range(3):
+        assert rel_err(out["predictions"][i].float(), out_ref["predictions"][i].detach()) < 6e-2
+    d = eng.head_bwd(hctx, [w.to(torch.bfloat16).cuda() for w in dws[:3]], dws[3].to(torch.bfloat16).cuda())
+    torch.cuda.synchronize()
+    P = dict(m.named_parameters())
+    gmax = max(float(v.abs().max()) for v in g_ref.values() if v is not None)
+
+    def stats(get, ref):
+        cos, rn = {}, {}
+        for k, r in ref.items():
+            if r is None or float(r.abs().max()) < 1e-3 * gmax:
+                continue
+            a_, b_ = get(k).double().flatten(), r.double().flatten()
+            cos[k] = float(torch.dot(a_, b_) / (a_.norm() * b_.norm()).clamp_min(1e-30))
+            rn[k] = float((a_ - b_).norm() / b_.norm())
+        return cos, rn
+    cos_h, rn_h = stats(lambda k: P[k].grad.detach().cpu(), g_ref)
+    cos_y, rn_y = stats(lambda k: g_yard[k], g_ref)
+    med = lambda d_: sorted(d_.values())[len(d_) // 2]
+    worst = sorted(rn_h.items(), key=lambda kv: -kv[1])[:5]
+    rep = (f"{len(rn_h)} head parameters: relative L2 median {med(rn_h):.4f} max {max(rn_h.values()):.4f} (yardstick: median {med(rn_y):.4f} "
+           f"max {max(rn_y.values()):.4f}); cosine min {min(cos_h.values()):.5f} median {med(cos_h):.5f} (yardstick min {min(cos_y.values()):.5f}); "
+           f"worst 5 {[(k, round(v, 4), round(rn_y.get(k, 0.0), 4), round(cos_h[k], 5)) for k, v in worst]}")
+    print("bf16 head gradients vs fp32 oracle:", rep)
+    assert len(rn_h) >= 40, rep
+    # input-side gradients (what the trunk backward receives)
+    for a_, b_, y_, nm in zip(d, gf_ref, gf_yard, ("d_s2", "d_s3", "d_s4")):
+        a_ = a_.float().permute(0, 3, 1, 2).cpu().double().flatten()
+        b_, y_ = b_.double().flatten(), y_.double().flatten()
+        e_h, e_y = float((a_ - b_).norm() / b_.norm()), float((y_ - b_).norm() / b_.norm())
+        c_h = float(torch.dot(a_, b_) / (a_.norm() * b_.norm()))
+        print(f"  {nm}: relative L2 {e_h:.4f} (yardstick {e_y:.4f}), cosine {c_h:.5f}")
+        assert e_h < 4 * e_y + 0.03 and c_h > 0.9, (nm, e_h, e_y, c_h)
+    # Per parameter: within a small multiple of what rounding the weights and inputs alone costs.  (Every BatchNorm backward removes the
+    # coherent part of the gradient, so the yardstick itself grows from ~0.002 at the prediction heads to ~0.2 at the CFI fusion.)  A wrong
+    # kernel leaves its parameter -- and everything upstream of it -- at relative error ~1 / cosine ~0.
+    assert med(rn_h) < 4 * med(rn_y) + 0.02, rep
+    assert min(cos_h.values()) > 0.85 and med(cos_h) > 0.98, rep
+    for k, v in rn_h.items():
+        assert v < 5 * rn_y[k] + 0.05, (k, v, rn_y[k], cos_h[k])
+
+
 def test_deferred_block_wgrads_equal_per_block_wgrads():
     """Hiera-L bf16 at 384 px, batch 2 (stage 3: M = 1152 rows, 84 blocks of dW per trunk block -> three trunk blocks per
     spg_gemm_tn_blocks launch; stage 4 below the row threshold): the engine's deferred whole-block weight gradients (operands of up to
