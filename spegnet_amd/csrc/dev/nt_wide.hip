@@ -41,7 +41,7 @@
 #ifdef SPG_DEV_KERNELS
 #include <algorithm>
 #include <type_traits>
-#include "common.h"
+#include "../common.h"
 
 namespace spg {
 

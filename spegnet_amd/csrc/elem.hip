@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ scale, const float* __restrict__ dscale,
                                                          float* __restrict__ dgap, float* __restrict__ dw1,
                                                          float* __restrict__ dw2, int C, int R, float* __restrict__ ws,
-                                                         unsigned* __restrict__ counter, float in_scale) {
+                                                         unsigned* __restrict__ counter, float in_scale, int bchunk) {
   extern __shared__ float sm[];  // dz[C] + dh[R]; the last block re-uses it as gdz[B][C] | gap[B][C] | gdh[B][R] | hidden[B][R]
   __shared__ unsigned s_last;
   const int b = blockIdx.x, B = gridDim.x, nt = (int)blockDim.x;
@@ -328,22 +328,27 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* __restrict
     dgap[(long)b * C + c] = s;
   }
   if (!arrive_last(counter, (unsigned)B, &s_last)) return;
-  // the last block: weight gradients summed over the images in image order, operands staged in LDS (coalesced) first
-  float* l_dz = sm; float* l_gap = l_dz + B * C; float* l_dh = l_gap + B * C; float* l_hid = l_dh + B * R;
-  for (int i = threadIdx.x; i < B * C; i += nt) { l_dz[i] = gdz[i]; l_gap[i] = gap[i] * in_scale; }
-  for (int i = threadIdx.x; i < B * R; i += nt) { l_dh[i] = gdh[i]; l_hid[i] = hidden[i]; }
-  __syncthreads();
-  for (int i = threadIdx.x; i < C * R; i += nt) {          // dw2 [C][R]: consecutive threads, consecutive r
-    const int c = i / R, r = i - c * R;
-    float s2 = 0.f;
-    for (int bb = 0; bb < B; ++bb) s2 += l_dz[bb * C + c] * l_hid[bb * R + r];
-    dw2[i] += s2;
-  }
-  for (int i = threadIdx.x; i < C * R; i += nt) {          // dw1 [R][C]: consecutive threads, consecutive c
-    const int r = i / C, c = i - r * C;
-    float s1 = 0.f;
-    for (int bb = 0; bb < B; ++bb) s1 += l_dh[bb * R + r] * l_gap[bb * C + c];
-    dw1[i] += s1;
+  // the last block: weight gradients summed over the images in image order, operands staged in LDS (coalesced) first -- `bchunk` images
+  // at a time (what 64 KiB of LDS hold: one chunk up to batch 15 at C = 512, R = 32; larger batches add chunk after chunk, still in image order)
+  for (int b0 = 0; b0 < B; b0 += bchunk) {
+    const int nb = min(bchunk, B - b0);
+    float* l_dz = sm; float* l_gap = l_dz + nb * C; float* l_dh = l_gap + nb * C; float* l_hid = l_dh + nb * R;
+    __syncthreads();                                        // (the previous chunk's readers are done with the staging area)
+    for (int i = threadIdx.x; i < nb * C; i += nt) { l_dz[i] = gdz[(long)b0 * C + i]; l_gap[i] = gap[(long)b0 * C + i] * in_scale; }
+    for (int i = threadIdx.x; i < nb * R; i += nt) { l_dh[i] = gdh[(long)b0 * R + i]; l_hid[i] = hidden[(long)b0 * R + i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * R; i += nt) {          // dw2 [C][R]: consecutive threads, consecutive r
+      const int c = i / R, r = i - c * R;
+      float s2 = 0.f;
+      for (int bb = 0; bb < nb; ++bb) s2 += l_dz[bb * C + c] * l_hid[bb * R + r];
+      dw2[i] += s2;
+    }
+    for (int i = threadIdx.x; i < C * R; i += nt) {          // dw1 [R][C]: consecutive threads, consecutive c
+      const int r = i / C, c = i - r * C;
+      float s1 = 0.f;
+      for (int bb = 0; bb < nb; ++bb) s1 += l_dh[bb * R + r] * l_gap[bb * C + c];
+      dw1[i] += s1;
+    }
   }
 }
 
@@ -900,10 +905,12 @@ extern "C" int spg_se_fc_bwd(const float* gap, const float* w1, const float* w2,
                              const float* dscale, float* dgap, float* dw1, float* dw2, int B, int C, int R, float in_scale, float* red_ws,
                              long red_ws_floats, unsigned* red_counter, spg_stream_t stream) {
   SPG_REQUIRE(red_ws && red_counter && red_ws_floats >= (long)B * (C + R), "se_fc_bwd: needs B*(C+R) floats of scratch and one zeroed counter");
-  const size_t lds = (size_t)2 * B * (C + R) * sizeof(float);     // (>= the C + R floats of the per-image phase)
-  SPG_REQUIRE(lds <= 64 * 1024, "se_fc_bwd: B * (C + R) = %ld exceeds the 64 KiB of LDS the last block stages", (long)B * (C + R));
+  int bchunk = (int)((64 * 1024) / ((size_t)2 * (C + R) * sizeof(float)));     // images whose dz / gap / dh / hidden rows fit 64 KiB of LDS
+  SPG_REQUIRE(bchunk >= 1, "se_fc_bwd: C + R = %d: one image's rows exceed the 64 KiB the last block stages", C + R);
+  if (bchunk > B) bchunk = B;
+  const size_t lds = (size_t)2 * bchunk * (C + R) * sizeof(float);     // (>= the C + R floats of the per-image phase)
   hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, gap, w1, w2, hidden, scale, dscale, dgap, dw1, dw2, C, R,
-                     red_ws, red_counter, in_scale);
+                     red_ws, red_counter, in_scale, bchunk);
   return check_launch("se_fc_bwd");
 }
 extern "C" int spg_chan_scale(int dtype, const void* x, const float* scale, void* y, int B, long HW, int C, spg_stream_t stream) {

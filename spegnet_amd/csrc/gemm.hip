@@ -185,164 +185,7 @@ struct NtEpi {
 };
 
 #ifdef SPG_DEV_KERNELS
-template <typename T, bool CONV>
-__global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                             T* __restrict__ C, NtEpi epi, int M, int N, int K,
-                                                             int ldx, int ldc, ConvGeom g, int tiles_n, int nwg,
-                                                             unsigned xbytes, unsigned wbytes) {
-  constexpr int VEC = ST<T>::VEC;
-  constexpr int BK = ROWB / (int)sizeof(T);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Xs = smem;                     // [2][BM][ROWB]
-  char* Ws = smem + 2 * BM * ROWB;     // [2][BN][ROWB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave & 1, wm = wave >> 1;
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int tn = tile % tiles_n, tm = tile / tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // staging assignment: chunk c = tid&7 of rows (tid>>3) + 32*i
-  const int sc = tid & 7, sr = tid >> 3;
-  int py[4], px[4];
-  if constexpr (CONV) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + sr + 32 * i;
-      const int hw = g.H * g.W;
-      const int b = m / hw, rem = m - b * hw;
-      py[i] = rem / g.W;
-      px[i] = rem - py[i] * g.W;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { py[i] = px[i] = 0; }
-  }
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, xbytes), wr = make_rsrc(W, wbytes);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // two register stages: tile t+1 and t+2 are in flight while tile t is multiplied (global latency spans two MFMA phases)
-  u32x4 rxA[4], rwA[4], rxB[4], rwB[4];
-  auto gload = [&](int kt, u32x4 (&rx)[4], u32x4 (&rw)[4]) {
-    const int k0 = kt * BK + sc * VEC;
-    const bool kin = k0 < K;   // K tail (only the last tile): out-of-range offset -> hardware returns 0, no branch, no post-load op
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned xo = x_chunk_off<T, CONV>(m0 + sr + 32 * i, k0, ldx, g, py[i], px[i]);
-      const unsigned wo = (unsigned)(((long)(n0 + sr + 32 * i) * K + k0) * (long)sizeof(T));
-      rx[i] = bload16(xr, kin ? xo : OOB);
-      rw[i] = bload16(wr, kin ? wo : OOB);
-    }
-  };
-  auto sstore = [&](int buf, const u32x4 (&rx)[4], const u32x4 (&rw)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = sr + 32 * i;
-      const int off = row * ROWB + ((sc ^ (row & 7)) << 4);
-      *reinterpret_cast<u32x4*>(Xs + buf * BM * ROWB + off) = rx[i];
-      *reinterpret_cast<u32x4*>(Ws + buf * BN * ROWB + off) = rw[i];
-    }
-  };
-
-  const int nk = (K + BK - 1) / BK;
-  gload(0, rxA, rwA);
-  if (nk > 1) gload(1, rxB, rwB);
-  sstore(0, rxA, rwA);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) gload(kt + 2, rxA, rwA);
-    mma_tile<T>(Ws, Xs, wn, wm, lane, acc);
-    if (kt + 1 < nk) sstore(1, rxB, rwB);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      if (kt + 3 < nk) gload(kt + 3, rxB, rwB);
-      mma_tile<T>(Ws + BN * ROWB, Xs + BM * ROWB, wn, wm, lane, acc);
-      if (kt + 2 < nk) sstore(0, rxA, rwA);
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue: accumulators -> LDS (per-wave 32 x 64 f32 slab, two halves) -> 16-byte coalesced row segments.
-  // lane holds acc[ni][mi][r] = D[n = ni*16 + 4q + r][m = mi*16 + (lane&15)]
-  constexpr int EPS = 68;  // f32 row stride of the slab (64 + 4 pad: conflict-free b128 writes)
-  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * EPS);
-  const int r15 = lane & 15, q = lane >> 4;
-  const T* R = reinterpret_cast<const T*>(epi.residual);
-  const T* Hh = reinterpret_cast<const T*>(epi.gelu_h);
-  T* C2 = reinterpret_cast<T*>(epi.C2);
-  const bool vec_ok = (ldc % 8 == 0);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int mi2 = 0; mi2 < 2; ++mi2)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        *reinterpret_cast<f32x4*>(slab + (mi2 * 16 + r15) * EPS + ni * 16 + q * 4) = acc[ni][half * 2 + mi2];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (lane >> 3) + 8 * j, ch = lane & 7;
-      const int m = m0 + wm * 64 + half * 32 + row;
-      const int n = n0 + wn * 64 + ch * 8;
-      if (m < M && n < N) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * EPS + ch * 8 + 4);
-        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        const long o = (long)m * ldc + n;
-        if (vec_ok && n + 7 < N) {
-          if (epi.bias) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(epi.bias + n), b1 = *reinterpret_cast<const f32x4*>(epi.bias + n + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-          }
-          if (C2) {
-            if constexpr (sizeof(T) == 2) st16(C2 + o, pack16<T>(v));
-            else { st16(C2 + o, pack16<T>(v)); st16(C2 + o + 4, pack16<T>(v + 4)); }
-          }
-          if (epi.act == SPG_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-          } else if (epi.act == SPG_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (Hh) {
-            float h[8];
-            if constexpr (sizeof(T) == 2) unpack16<T>(ld16(Hh + o), h);
-            else { unpack16<T>(ld16(Hh + o), h); unpack16<T>(ld16(Hh + o + 4), h + 4); }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(h[e]);
-          }
-          if (R) {
-            float rr[8];
-            if constexpr (sizeof(T) == 2) unpack16<T>(ld16(R + o), rr);
-            else { unpack16<T>(ld16(R + o), rr); unpack16<T>(ld16(R + o + 4), rr + 4); }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rr[e];
-          }
-          if constexpr (sizeof(T) == 2) st16(C + o, pack16<T>(v));
-          else { st16(C + o, pack16<T>(v)); st16(C + o + 4, pack16<T>(v + 4)); }
-        } else {
-          for (int e = 0; e < 8 && n + e < N; ++e) {
-            float x = v[e];
-            if (epi.bias) x += epi.bias[n + e];
-            if (C2) ST<T>::st(C2 + o + e, x);
-            if (epi.act == SPG_ACT_GELU) x = gelu_f(x);
-            else if (epi.act == SPG_ACT_RELU) x = fmaxf(x, 0.f);
-            if (Hh) x *= gelu_grad_f(ST<T>::ld(Hh + o + e));
-            if (R) x += ST<T>::ld(R + o + e);
-            ST<T>::st(C + o + e, x);
-          }
-        }
-      }
-    }
-    if (half == 0) __syncthreads();
-  }
-}
+#include "dev/gemm_nt_regstage.inc"
 #endif  // SPG_DEV_KERNELS (register-staged NT kernel)
 
 
@@ -1256,241 +1099,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
 }
 
 #ifdef SPG_DEV_KERNELS
-// ------------------------------------------------------------------------------------------------
-// gemm_nt_v5: persistent 128 x (32 NB) tiles with SPECIALISED waves -- waves 0-3 multiply (64 x 16 NB each, one per SIMD) and run the
-// accumulator-direct epilogue of gemm_nt_v3, waves 4-7 only issue the LDS-DMA fill (4 stages of 64 K, three groups in flight, running
-// ahead across tile boundaries so a tile's epilogue sits under the next tile's fill).
-// Why: stamps and ablations of the grouped wgrad kernel (tools/tn_stamps.py) showed the 8-wave pipelined kernels bound by each wave's
-// own instruction issue -- MFMAs, fragment reads, ~80-100 cycles per DMA piece and the cursor bookkeeping add up in one in-order
-// stream -- not by the matrix pipe.  Split by role, a multiplying wave issues 32 MFMAs + 16 ds_read_b128 per 64 of K and the fill's
-// issue cost runs beside it on the same SIMD.
-// Hand-off: one workgroup barrier per K step, B_k, between the step's two 32-deep halves.  Before it a multiplier has waited for its
-// reads of stage k (lgkmcnt(0)), a loader for ITS pieces of group k+1 (vmcnt(2 NP)); after it the multipliers read half 0 of stage
-// k+1 and the loaders overwrite stage k's slot with group k+4.  Both roles pass 1 + (tiles x K steps) barriers.
-// Result (round 2): NOT faster in the training step -- NT steps already run at the fill path's rate (~800 cycles per 32 KiB stage
-// with four issuing waves, tools/tn_stamps.py), so taking the fill out of the multiplying waves buys nothing here; back-to-back
-// replays of one problem (tools/nt_check.py) showed 8 % on the long-K projections, the step with cold operands lost 0.3 ms
-// (28.17 vs 27.87 ms, two A/B pairs on one box).  Dev builds only (SPG_NT_V5=1).
-// ------------------------------------------------------------------------------------------------
-template <bool CONV, int ACT, int NB>
-__global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
-                                                         NtEpi epi, PipeEpi pe, int M, int N, int K, int ldx, int ldc, ConvGeom g,
-                                                         int tiles_n, int ntiles, unsigned xbytes, unsigned wbytes) {
-  using T = bf16_t;
-  static_assert(NB == 4 || NB == 2, "accumulator pairs hold 8 consecutive columns");
-  constexpr int RB = 128, NS = 4;
-  constexpr int BN_ = 32 * NB;
-  constexpr int STAGE = (BM + BN_) * RB;
-  constexpr int WROWS = BN_ / 4;            // W rows each loader fills per stage
-  constexpr int XP = 4, WP = WROWS / 8;     // 1 KiB pieces (8 rows) per loader and stage
-  constexpr int NP = XP + WP;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nkt = (K + 63) >> 6;
-  const int G = (int)gridDim.x;
-  const int first = xcd_remap(blockIdx.x, G);
-  if (first >= ntiles) return;
-  const int my_tiles = (ntiles - first + G - 1) / G;
-  const int total = my_tiles * nkt;
-
-  if (wave >= 4) {
-    // ================================================================ loader waves
-    const int lw = wave - 4;
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, xbytes), wr = make_rsrc(W, wbytes);
-    const int lrow = lane >> 3;
-    const int kch = (lane & 7) ^ lrow;        // logical 16-byte chunk this lane fetches
-    unsigned xoff[XP], woff[WP];
-    bool xin[XP], win[WP];
-    int py[XP], px[XP];
-    int is_tile = first, is_kt = 0, is_slot = 0;
-    bool is_live = true;
-    auto enter_tile = [&]() __attribute__((always_inline)) {
-      const int tn = is_tile % tiles_n, tm = is_tile / tiles_n;
-      const int m0 = tm * BM, n0 = tn * BN_;
-#pragma unroll
-      for (int p = 0; p < XP; ++p) {
-        const int m = m0 + lw * 32 + p * 8 + lrow;
-        xin[p] = m < M;
-        if constexpr (CONV) {
-          const int hw = g.H * g.W;
-          const int b = m / hw, rem = m - b * hw;
-          py[p] = rem / g.W; px[p] = rem - py[p] * g.W;
-          xoff[p] = (unsigned)m;
-        } else {
-          py[p] = 0; px[p] = 0;
-          xoff[p] = (unsigned)(((long)m * ldx + kch * 8) * 2);
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < WP; ++p) {
-        const int i = lw * WROWS + p * 8 + lrow;              // row of the W image (permuted: see gemm_nt_v3)
-        const int half = i / (16 * NB), l = i - half * (16 * NB), ni = l >> 4, j = l & 15;
-        const int n = n0 + half * (16 * NB) + (ni >> 1) * 32 + (j >> 2) * 8 + (ni & 1) * 4 + (j & 3);
-        win[p] = n < N;
-        woff[p] = (unsigned)(((long)n * K + kch * 8) * 2);
-      }
-    };
-    enter_tile();
-    auto issue_group = [&]() __attribute__((always_inline)) {
-      char* st = smem + is_slot * STAGE;
-      const int k0 = is_kt * 64 + kch * 8;
-      const bool kin = is_live && k0 < K;
-#pragma unroll
-      for (int p = 0; p < XP; ++p) {
-        unsigned off;
-        if constexpr (CONV) off = x_chunk_off<T, true>((int)xoff[p], k0, ldx, g, py[p], px[p]);
-        else off = xoff[p] + (unsigned)is_kt * 128u;
-        lds_dma16(xr, st + (lw * 32 + p * 8) * RB, (kin && xin[p]) ? off : OOB);
-      }
-#pragma unroll
-      for (int p = 0; p < WP; ++p)
-        lds_dma16(wr, st + (BM + lw * WROWS + p * 8) * RB, (kin && win[p]) ? woff[p] + (unsigned)is_kt * 128u : OOB);
-      is_slot = is_slot + 1 == NS ? 0 : is_slot + 1;
-      if (++is_kt == nkt) {
-        is_kt = 0; is_tile += G;
-        if (is_tile < ntiles) enter_tile(); else is_live = false;
-      }
-    };
-#pragma unroll 1
-    for (int i = 0; i < NS; ++i) issue_group();
-    wait_vm_only<(NS - 1) * NP>();          // group 0
-    __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-    for (int k = 0; k < total; ++k) {
-      wait_vm_only<(NS - 2) * NP>();        // group k+1 (two younger groups stay in flight)
-      __builtin_amdgcn_s_barrier();         // B_k
-      issue_group();                        // group k+4 -> the slot of stage k
-    }
-    wait_vm_only<0>();                      // the trailing no-op pieces
-    return;
-  }
-
-  // ================================================================== multiplying waves
-  const int wn = wave & 1, wm = wave >> 1;
-  f32x4 acc[NB][4];
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int r15 = lane & 15, q = lane >> 4;
-  const int fro = r15 * RB + ((q ^ (r15 & 7)) << 4);        // this lane's fragment chunk inside a 16-row block (k half 1: ^ 64)
-  const int boff = (wm * 64) * RB + fro, aoff = (BM + wn * (16 * NB)) * RB + fro;
-  bf16x8_t fa0[NB], fb0[4], fa1[NB], fb1[4];
-  auto read_frag = [&](bf16x8_t* fa, bf16x8_t* fb, const char* st, int sub, int r) __attribute__((always_inline)) {
-    const int x = sub * 64;
-    if (r < 4) fb[r] = *reinterpret_cast<const bf16x8_t*>(st + ((boff + r * 16 * RB) ^ x));
-    else fa[r - 4] = *reinterpret_cast<const bf16x8_t*>(st + ((aoff + (r - 4) * 16 * RB) ^ x));
-  };
-  constexpr int NH = NB * 4, NR = NB + 4;   // MFMAs / fragment reads per half step
-  const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, pe.c_bytes), c2r = make_rsrc(epi.C2, pe.c2_bytes);
-  const __amdgpu_buffer_rsrc_t rr = make_rsrc(epi.residual, pe.r_bytes), hr = make_rsrc(epi.gelu_h, pe.h_bytes);
-  const __amdgpu_buffer_rsrc_t br = make_rsrc(epi.bias, pe.bias_bytes);
-  constexpr int NV = NB / 2;                                 // 16-byte vectors per lane and m block
-  int tile = first, kt = 0, slot = 0;
-  int ncol = 0, mrow = 0;
-  unsigned eo[4];
-  u32x4 er[4][NV], eh[4][NV];
-  f32x4 eb[NB];
-  auto epi_request = [&]() __attribute__((always_inline)) {
-    const int tn = tile % tiles_n, tm = tile / tiles_n;
-    ncol = tn * BN_ + wn * (16 * NB) + q * 8;              // first of this lane's 8 consecutive columns of vector 0 (vector v: + 32 v)
-    mrow = tm * BM + wm * 64 + r15;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const bufvec_t b = __builtin_amdgcn_raw_buffer_load_b128(br, (unsigned)((ncol + 32 * (i >> 1) + 4 * (i & 1)) * 4), 0, 0);
-      eb[i] = f32x4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int m = mrow + mi * 16;
-      eo[mi] = (m < M) ? (unsigned)(((long)m * ldc + ncol) * 2) : OOB;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
-        er[mi][v] = bload16(rr, o);
-        if constexpr (ACT == PIPE_ACT_HH || ACT == PIPE_ACT_MULH) eh[mi][v] = bload16(hr, o);
-      }
-    }
-  };
-  auto epi_run = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        float ev[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ev[e] = acc[2 * v][mi][e] + eb[2 * v][e];
-          ev[4 + e] = acc[2 * v + 1][mi][e] + eb[2 * v + 1][e];
-        }
-        acc[2 * v][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[2 * v + 1][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
-        if constexpr (ACT == PIPE_ACT_GELU) {
-          bstore16(c2r, o, pack16<T>(ev));
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ev[e] = gelu_f(ev[e]);
-        }
-        if constexpr (ACT == PIPE_ACT_HH) {
-          float h[8];
-          unpack16<T>(eh[mi][v], h);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ev[e] *= gelu_grad_f(h[e]);
-        }
-        float rres[8];
-        unpack16<T>(er[mi][v], rres);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ev[e] += rres[e];
-        bstore16(cr, o, pack16<T>(ev));
-      }
-    }
-  };
-
-  __builtin_amdgcn_s_barrier();             // group 0 has landed
-#pragma unroll
-  for (int r = 0; r < NR; ++r) read_frag(fa0, fb0, smem, 0, r);
-#pragma unroll 1
-  for (int gs = 0; gs < total; ++gs) {
-    const char* st = smem + slot * STAGE;
-    const int nslot = slot + 1 == NS ? 0 : slot + 1;
-    const char* nst = smem + nslot * STAGE;
-    const bool last = kt + 1 == nkt;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // half 0's fragments (read during the previous step's second half)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      acc[i >> 2][i & 3] = Mma<T>::mma(fa0[i >> 2], fb0[i & 3], acc[i >> 2][i & 3]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-        if (r * NH / NR == i) read_frag(fa1, fb1, st, 1, r);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // stage k has been read completely
-    __builtin_amdgcn_s_barrier();                          // B_k
-    __builtin_amdgcn_sched_barrier(0);
-    if (last) epi_request();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      acc[i >> 2][i & 3] = Mma<T>::mma(fa1[i >> 2], fb1[i & 3], acc[i >> 2][i & 3]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-        if (r * NH / NR == i) read_frag(fa0, fb0, nst, 0, r);   // (after the last step: a stale stage, unused)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (last) {
-      epi_run();
-      kt = 0; tile += G;
-    } else {
-      ++kt;
-    }
-    slot = nslot;
-  }
-}
-
+#include "dev/gemm_nt_v5.inc"
 #endif  // SPG_DEV_KERNELS (gemm_nt_v5)
 
 // TN: dW[n][k] += sum_m dY[m][n] * X[m][k].  LDS rows are output features (n for the dY operand, k for the
@@ -1784,208 +1393,8 @@ __device__ __forceinline__ int div_small(int m, int d, float rd) {
   return qq;
 }
 
-#ifdef SPG_DEV_KERNELS   // superseded by gemm_tn_pipe4_kernel (specialised waves); kept for A/B runs (SPG_TN_GROUP_V4=0)
-template <typename T, bool CONV, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const T* __restrict__ dY, const T* __restrict__ X, int M, int N, int K, int ldy,
-                                                           int ldx, ConvGeom g, int tiles_k, int tiles, int splits, int m_per_split,
-                                                           unsigned ybytes, unsigned xbytes, float* __restrict__ dbias,
-                                                           float* __restrict__ slabs, unsigned slab_bytes) {
-  static_assert(sizeof(T) == 2, "bf16 only");
-  using F = TnFrag<T>;
-  constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 1, wk = wave >> 1;                      // wave tile: n [64*wn, +64), k [32*wk, +32)
-  const int G = (int)gridDim.x;
-  const int first = xcd_remap(blockIdx.x, G);
-  const int units = tiles * splits;
-  if (first >= units) return;
-  const int my_units = (units - first + G - 1) / G;
-  const int nsteps = m_per_split / MSTEP;
-  const int total = my_units * nsteps;
-  const rsrc_words_t yr = make_rsrc_words(dY, ybytes), xr = make_rsrc_words(X, xbytes);
-  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
-  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
-
-  // ---- DMA issue stream: a wave moves pieces {wave, wave + 8} (4 rows x 256 B each) of both operands per step
-  const int lrow = lane >> 4, lpc = lane & 15;
-  const int prow0 = wave * 4 + lrow;                              // row of piece 0 inside the stage tile (piece 1: + 32, same swizzle)
-  const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;   // logical feature column stored at physical chunk lpc
-  int is_step = 0, is_unit = first, is_slot = 0;
-  bool is_live = true, is_yin = false, is_xin = false;
-  unsigned yoff = 0, xoff = 0;                                    // byte offsets of piece 0 for the current step
-  const unsigned ystride = (unsigned)(MSTEP * ldy * 2), xstride = (unsigned)(MSTEP * ldx * 2);
-  const unsigned y32 = (unsigned)(32 * ldy * 2), x32 = (unsigned)(32 * ldx * 2);
-  // conv gather (X is the NHWC input of a 3x3 / pad 1 convolution, K = 9 * Ci): per-unit lane constants of the tap this lane's 8
-  // channels belong to, and the lane's current row index m (advanced with the stream)
-  int cv_dy = 0, cv_dx = 0, cv_m = 0;
-  long cv_delta = 0;
-  const int cv_hw = g.H * g.W;
-  const float cv_rhw = 1.f / (float)(CONV ? cv_hw : 1), cv_rw = 1.f / (float)(CONV ? g.W : 1);
-  auto enter_unit = [&]() __attribute__((always_inline)) {
-    const int tile = is_unit % tiles, split = is_unit / tiles;
-    const int tk = tile % tiles_k, tn = tile / tiles_k;
-    const int n0 = tn * 128, k0 = tk * 128;
-    const long m0 = (long)split * m_per_split + prow0;
-    yoff = (unsigned)((m0 * ldy + n0 + fcol) * 2);
-    is_yin = n0 + fcol < N; is_xin = k0 + fcol < K;
-    if constexpr (!CONV) {
-      xoff = (unsigned)((m0 * ldx + k0 + fcol) * 2);
-    } else {
-      const int kk = k0 + fcol;
-      const int tap = kk / g.Ci, ci = kk - tap * g.Ci;
-      cv_dy = tap / 3 - 1; cv_dx = tap - (tap / 3) * 3 - 1;
-      cv_delta = ((long)(cv_dy * g.W + cv_dx) * g.Ci + ci) * 2;
-      cv_m = (int)m0;
-    }
-  };
-  enter_unit();
-  unsigned dyo[2], dxo[2];
-  auto dma_addr = [&](int i) __attribute__((always_inline)) {    // rows past M fall outside the descriptors: hardware zero fill
-    dyo[i] = (is_live && is_yin) ? yoff + (i ? y32 : 0u) : OOB;
-    if constexpr (!CONV) {
-      dxo[i] = (is_live && is_xin) ? xoff + (i ? x32 : 0u) : OOB;
-    } else {
-      const int m = cv_m + 32 * i;
-      const int bimg = div_small(m, cv_hw, cv_rhw);
-      const int pix = m - bimg * cv_hw;
-      const int y = div_small(pix, g.W, cv_rw), x = pix - y * g.W;
-      const bool ok = is_live && is_xin && m < M && (unsigned)(y + cv_dy) < (unsigned)g.H && (unsigned)(x + cv_dx) < (unsigned)g.W;
-      dxo[i] = ok ? (unsigned)((long)m * g.Ci * 2 + cv_delta) : OOB;
-    }
-  };
-  auto dma_go = [&](int i, int which) __attribute__((always_inline)) {
-    const unsigned st = smem_base + is_slot * STAGE_B + (i * 8 + wave) * 1024;
-    if constexpr (DBG != 1) {
-      if (which == 0) dma16_asm(yr, st, dyo[i]);
-      else dma16_asm(xr, st + 16384, dxo[i]);
-    } else {
-      asm volatile("" :: "v"(dyo[i]), "v"(dxo[i]));
-    }
-  };
-  auto issue_advance = [&]() __attribute__((always_inline)) {
-    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
-    const bool wrap = is_step + 1 == nsteps;
-    yoff += ystride; xoff += xstride; cv_m += MSTEP;
-    is_step = wrap ? 0 : is_step + 1;
-    is_unit = wrap ? is_unit + G : is_unit;
-    if (wrap) { if (is_unit < units) enter_unit(); else is_live = false; }
-  };
-
-  // ---- fragment read offsets (lane constants) and registers
-  int oa[2][4][2], ob[2][2][2];
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) F::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) F::offsets(s2, wk * 32 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
-  }
-  struct Frags { typename F::Frag a[2][4], b[2][2]; };
-  Frags fa, fb;
-  auto read_frag = [&](Frags& f, const char* st, int idx) __attribute__((always_inline)) {   // idx 0..11: per k-half {b0, b1, a0..a3}
-    const int sx = idx / 6, r = idx % 6;
-    if (r < 2) f.b[sx][r] = F::load_at(st + 16384, ob[sx][r][0], ob[sx][r][1]);
-    else f.a[sx][r - 2] = F::load_at(st, oa[sx][r - 2][0], oa[sx][r - 2][1]);
-  };
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  float bsum = 0.f;                                               // bias partial: column 64*wn + 16*wk + (lane & 15), this lane's m rows
-  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
-
-  // ---- prologue
-  for (int i = 0; i < STAGES; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { dma_addr(j); dma_go(j, 0); dma_go(j, 1); }
-    issue_advance();
-  }
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int i = 0; i < 12; ++i) read_frag(fa, smem, i);
-
-  int st_i = 0, unit = first, rd_slot = 1, st1 = 0, st2 = 0;
-  const int r15 = lane & 15, q = lane >> 4;
-  auto mma_block = [&](Frags& cur, Frags& nxt, auto BIAS_) __attribute__((always_inline)) {
-    constexpr bool BIAS = decltype(BIAS_)::value;
-    const char* rst = smem + rd_slot * STAGE_B;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if constexpr (DBG != 2) {
-        const int ms = i >> 3, r = i & 7, ni = r >> 1, ki = r & 1;
-        acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);     // D[k][n]: 4 consecutive k per lane
-      }
-      if (i < 12) read_frag(nxt, rst, i);
-      if (i == 0) dma_addr(0);
-      if (i == 1) dma_go(0, 0);
-      if (i == 2) dma_go(0, 1);
-      if (i == 3) dma_addr(1);
-      if (i == 4) dma_go(1, 0);
-      if (i == 5) dma_go(1, 1);
-      if (i == 6) issue_advance();   // (inside the block: scalar work in the issue slots the MFMAs leave free)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (BIAS) {
-      // column sums from the fragments just multiplied (wave-uniform choice of n block; the selects are on whole registers)
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms) {
-        const typename F::Frag v = wk == 0 ? cur.a[ms][0] : (wk == 1 ? cur.a[ms][1] : (wk == 2 ? cur.a[ms][2] : cur.a[ms][3]));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bf16x2_t pr = {v[2 * e], v[2 * e + 1]};
-          bsum = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum, false);
-        }
-      }
-    }
-  };
-  auto step = [&](Frags& cur, Frags& nxt) __attribute__((always_inline)) {
-    if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else { wait_vm(8 + st1 + st2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    st2 = st1; st1 = 0;
-    const int tile = unit % tiles;                       // (scalar divisions once per step; the DMA stream itself has none)
-    const int tk = tile % tiles_k, tn = tile / tiles_k;
-    const bool bias_unit = dbias != nullptr && tk == 0;
-    if (bias_unit) mma_block(cur, nxt, std::true_type{}); else mma_block(cur, nxt, std::false_type{});
-    __builtin_amdgcn_sched_barrier(0);
-    const bool last = __builtin_amdgcn_readfirstlane(st_i + 1) == nsteps;
-    if (last) {
-      const int split = unit / tiles;
-      const int n0 = tn * 128 + wn * 64, k0 = tk * 128 + wk * 32;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int ki = 0; ki < 2; ++ki) {
-          const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
-          const unsigned o = (n < N && k < K) ? (unsigned)((((long)split * N + n) * K + k) * 4) : OOB;   // K % 4 == 0
-          if constexpr (DBG != 3) bstore16(sr, o, u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
-                                                        __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
-          acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      st1 = 8;
-      if (bias_unit) {   // fold the 4 m groups of a column (lanes l, l+16, l+32, l+48), then one atomic per column
-        float b = bsum;
-        b += __shfl_xor(b, 16, 64);
-        b += __shfl_xor(b, 32, 64);
-        const int n = n0 + wk * 16 + r15;
-        if (q == 0 && n < N) atomicAdd(dbias + n, b);
-      }
-      bsum = 0.f;
-    }
-    st_i = last ? 0 : st_i + 1;
-    unit = last ? unit + G : unit;
-    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
-  };
-  for (int gc = 0; gc < total; gc += 2) {
-    step(fa, fb);
-    if (gc + 1 < total) step(fb, fa);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
+#ifdef SPG_DEV_KERNELS
+#include "dev/gemm_tn_pipe8.inc"
 #endif  // SPG_DEV_KERNELS (8-wave single-problem wgrad kernel)
 
 // ------------------------------------------------------------------------------------------------
@@ -2233,270 +1642,8 @@ __device__ __forceinline__ unsigned long long stamp_now() {
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
-#ifdef SPG_DEV_KERNELS   // superseded by gemm_tn_group4_kernel (specialised waves); kept for A/B runs and the ablation modes
-template <typename T, int DBG = 0>   // DBG 2: no MFMAs (times the fill + read pipeline alone; wrong results by construction)
-__global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
-  static_assert(sizeof(T) == 2, "bf16 only");
-  using F = TnFrag<T>;
-  constexpr int MSTEP = 64, STAGES = 4, STAGE_B = 32768;   // (a 5th stage, 4 groups in flight, was measured: no gain -- the fill is bandwidth-, not latency-bound)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 1, wk = wave >> 1;
-  const int G = (int)gridDim.x;
-  const int c = xcd_remap(blockIdx.x, G);
-  const int S = g.S;
-  const int WS = g.W * S;                                                   // steps of this workgroup's whole tiles
-  const int rb = (int)((long)c * g.RS / G), re = (int)((long)(c + 1) * g.RS / G);   // its share of the remainder steps
-  const int total = WS + (re - rb);
-  if (total <= 0) return;
-  const int gt_first = WS > 0 ? c * g.W : g.W * G + rb / S;                 // first tile / step of the sequence
-  const int m_first = WS > 0 ? 0 : rb % S;
-  const int gt_rem = g.W * G + rb / S, m_rem = rb % S;                      // where the remainder share starts
-  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
-  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
-
-  // ---- DMA issue stream
-  const int lrow = lane >> 4, lpc = lane & 15;
-  const int prow0 = wave * 4 + lrow;
-  const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;
-  int is_job = -1, is_gt = gt_first, is_tile, is_mstep = m_first, is_ls = 0, is_slot = 0;
-  bool is_live = true, is_yin = false, is_xin = false;
-  unsigned yoff = 0, xoff = 0, ystride = 0, xstride = 0, y32 = 0, x32 = 0;
-  rsrc_words_t yr, xr;
-  auto is_enter_tile = [&]() __attribute__((always_inline)) {   // (also switches descriptors when the tile belongs to another problem)
-    int j;
-    tn_locate_tile(g, is_gt, j, is_tile);
-    const TnJob& jb = g.job[j];
-    if (j != is_job) {
-      is_job = j;
-      yr = make_rsrc_words(jb.dY, (unsigned)((long)g.M * jb.ldy * 2));
-      xr = make_rsrc_words(jb.X, (unsigned)((long)g.M * jb.ldx * 2));
-      ystride = (unsigned)(MSTEP * jb.ldy * 2); xstride = (unsigned)(MSTEP * jb.ldx * 2);
-      y32 = (unsigned)(32 * jb.ldy * 2); x32 = (unsigned)(32 * jb.ldx * 2);
-    }
-    const int tk = is_tile % jb.tiles_k, tn = is_tile / jb.tiles_k;
-    const int n0 = tn * 128, k0 = tk * 128;
-    const long m0 = (long)is_mstep * MSTEP + prow0;
-    yoff = (unsigned)((m0 * jb.ldy + n0 + fcol) * 2);
-    xoff = (unsigned)((m0 * jb.ldx + k0 + fcol) * 2);
-    is_yin = n0 + fcol < jb.N; is_xin = k0 + fcol < jb.K;
-  };
-  is_enter_tile();
-  unsigned dyo[2], dxo[2];
-  auto dma_addr = [&](int i) __attribute__((always_inline)) {    // rows past M fall outside the descriptors: hardware zero fill
-    dyo[i] = (is_live && is_yin) ? yoff + (i ? y32 : 0u) : OOB;
-    dxo[i] = (is_live && is_xin) ? xoff + (i ? x32 : 0u) : OOB;
-  };
-  auto dma_go = [&](int i, int which) __attribute__((always_inline)) {
-    const unsigned st = smem_base + is_slot * STAGE_B + (i * 8 + wave) * 1024;
-    if constexpr (DBG == 4) { asm volatile("" :: "v"(dyo[i]), "v"(dxo[i]), "s"(st)); return; }   // ablation: no fill
-    if (which == 0) dma16_asm(yr, st, dyo[i]);
-    else dma16_asm(xr, st + 16384, dxo[i]);
-  };
-  auto issue_advance = [&]() __attribute__((always_inline)) {
-    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
-    yoff += ystride; xoff += xstride;
-    ++is_ls;
-    const bool tile_end = is_mstep + 1 == S;
-    if (is_ls >= total) is_live = false;
-    else if (is_ls == WS) { is_gt = gt_rem; is_mstep = m_rem; is_enter_tile(); }        // whole tiles done: jump to the remainder share
-    else if (tile_end) { is_gt = is_gt + 1; is_mstep = 0; is_enter_tile(); }
-    else is_mstep = is_mstep + 1;
-  };
-
-  // ---- fragments
-  int oa[2][4][2], ob[2][2][2];
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) F::offsets(s2, wn * 64 + i * 16, lane, oa[s2][i][0], oa[s2][i][1]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) F::offsets(s2, wk * 32 + i * 16, lane, ob[s2][i][0], ob[s2][i][1]);
-  }
-  struct Frags { typename F::Frag a[2][4], b[2][2]; };
-  Frags fa, fb;
-  auto read_frag = [&](Frags& f, const char* st, int idx) __attribute__((always_inline)) {
-    const int sx = idx / 6, r = idx % 6;
-    if (r < 2) f.b[sx][r] = F::load_at(st + 16384, ob[sx][r][0], ob[sx][r][1]);
-    else f.a[sx][r - 2] = F::load_at(st, oa[sx][r - 2][0], oa[sx][r - 2][1]);
-  };
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  float bsum = 0.f;
-  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
-
-  // ---- prologue
-  for (int i = 0; i < STAGES; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { dma_addr(j); dma_go(j, 0); dma_go(j, 1); }
-    issue_advance();
-  }
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int i = 0; i < 12; ++i) read_frag(fa, smem, i);
-  if constexpr (DBG == 3) fb = fa;
-
-  // ---- compute cursor
-  int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;   // seg0: m step at which this workgroup entered the current tile
-  int cj, ctile;
-  // per-tile quantities live in registers and change only when the cursor moves to another tile: looking them up in the argument
-  // struct every step (scalar loads share lgkmcnt with the LDS reads, then an integer division) stalled each step's first MFMA
-  int c_tk, c_tn;
-  bool c_bias;
-  auto locate = [&](int gt, int& j, int& tile, int& tn, int& tk, bool& bias) __attribute__((always_inline)) {
-    tn_locate_tile(g, gt, j, tile);
-    const TnJob& jb = g.job[j];
-    tn = tile / jb.tiles_k; tk = tile - tn * jb.tiles_k;
-    bias = jb.dbias != nullptr && tk == 0;
-  };
-  locate(cgt, cj, ctile, c_tn, c_tk, c_bias);
-  // the step's scalar bookkeeping (cursor advance, DMA stream advance) is placed INSIDE the MFMA block, in the issue slots the
-  // MFMAs leave free: after the block it ran with the matrix pipe idle on every wave at once (the barrier keeps them in phase)
-  bool s_tile_end = false, s_range_end = false, s_moved = false;
-  int n_cgt = 0, n_cm = 0, n_seg0 = 0, n_cj = 0, n_ctile = 0, n_tn = 0, n_tk = 0;
-  bool n_bias = false;
-  int rd_slot = 1, st1 = 0, st2 = 0;
-  const int r15 = lane & 15, q = lane >> 4;
-  auto mma_block = [&](Frags& cur, Frags& nxt, auto BIAS_) __attribute__((always_inline)) {
-    constexpr bool BIAS = decltype(BIAS_)::value;
-    const char* rst = smem + rd_slot * STAGE_B;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int ms = i >> 3, r = i & 7, ni = r >> 1, ki = r & 1;
-      if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(cur.b[ms][ki], cur.a[ms][ni], acc[ni][ki]);
-      else asm volatile("" :: "v"(cur.b[ms][ki]), "v"(cur.a[ms][ni]));
-      if (i < 12 && DBG != 3) read_frag(nxt, rst, i);   // (DBG 3: ablation without the fragment reads)
-      if constexpr (DBG == 6) {   // A/B: the DMA pieces behind the fragment reads
-        if (i == 11) { dma_addr(0); dma_addr(1); }
-        if (i == 12) dma_go(0, 0);
-        if (i == 13) dma_go(0, 1);
-        if (i == 14) dma_go(1, 0);
-        if (i == 15) { dma_go(1, 1); issue_advance(); }
-      } else {
-        if (i == 0) dma_addr(0);
-        if (i == 1) dma_go(0, 0);
-        if (i == 2) dma_go(0, 1);
-        if (i == 3) dma_addr(1);
-        if (i == 4) dma_go(1, 0);
-        if (i == 5) dma_go(1, 1);
-        if (i == 6) issue_advance();
-      }
-      if (i == 8) {
-        const int nls = cls + 1;
-        const bool jump = nls == WS && nls < total;          // whole tiles done: on to the remainder share
-        s_moved = (jump || s_tile_end) && !s_range_end;
-        n_cgt = jump ? gt_rem : (s_tile_end ? cgt + 1 : cgt);
-        n_cm = jump ? m_rem : (s_tile_end ? 0 : cm + 1);
-        n_seg0 = jump ? m_rem : (s_tile_end ? 0 : seg0);
-      }
-      if (i == 10) {
-        n_cj = cj; n_ctile = ctile; n_tn = c_tn; n_tk = c_tk; n_bias = c_bias;
-        if (s_moved) locate(n_cgt, n_cj, n_ctile, n_tn, n_tk, n_bias);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (BIAS) {
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms) {
-        const typename F::Frag v = wk == 0 ? cur.a[ms][0] : (wk == 1 ? cur.a[ms][1] : (wk == 2 ? cur.a[ms][2] : cur.a[ms][3]));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bf16x2_t pr = {v[2 * e], v[2 * e + 1]};
-          bsum = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum, false);
-        }
-      }
-    }
-  };
-  unsigned long long sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0, tlast = 0;
-  if constexpr (DBG == 5) tlast = stamp_now();
-  auto step = [&](Frags& cur, Frags& nxt) __attribute__((always_inline)) {
-    if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else { wait_vm(8 + st1 + st2); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg0 += t - tlast; tlast = t; }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg1 += t - tlast; tlast = t; }
-    st2 = st1; st1 = 0;
-    const bool bias_tile = c_bias;
-    const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
-    const bool range_end = cls + 1 == total;
-    s_tile_end = tile_end; s_range_end = range_end;
-    if (bias_tile) mma_block(cur, nxt, std::true_type{}); else mma_block(cur, nxt, std::false_type{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg2 += t - tlast; tlast = t; }
-    if (tile_end || range_end) {
-      const TnJob& jb = g.job[cj];
-      const int tk = c_tk, tn = c_tn;
-      const int n0 = tn * 128 + wn * 64, k0 = tk * 128 + wk * 32;
-      if (seg0 == 0 && tile_end) {
-        // the whole tile was multiplied here: accumulate into the gradient (single owner)
-        const __amdgpu_buffer_rsrc_t wr = make_rsrc(jb.dW, (unsigned)((long)jb.N * jb.ldw * 4));
-        u32x4 old[4][2];
-        unsigned o[4][2];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int ki = 0; ki < 2; ++ki) {
-            const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
-            o[ni][ki] = (n < jb.N && k < jb.K) ? (unsigned)(((long)n * jb.ldw + k) * 4) : OOB;   // K % 4 == 0
-            old[ni][ki] = bload16(wr, o[ni][ki]);
-          }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int ki = 0; ki < 2; ++ki) {
-            const f32x4 v = acc[ni][ki] + f32x4{__uint_as_float(old[ni][ki].x), __uint_as_float(old[ni][ki].y),
-                                                __uint_as_float(old[ni][ki].z), __uint_as_float(old[ni][ki].w)};
-            bstore16(wr, o[ni][ki], u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
-            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-      } else {
-        const int slot = seg0 != 0 ? 0 : 1;
-        const unsigned base = (unsigned)(((long)c * 2 + slot) * TN_SLOT_FLOATS * 4);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int ki = 0; ki < 2; ++ki) {
-            const int nl = wn * 64 + ni * 16 + r15, kl = wk * 32 + ki * 16 + q * 4;
-            bstore16(sr, base + (unsigned)((nl * 128 + kl) * 4), u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
-                                                                      __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
-            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-      }
-      st1 = 8;
-      if (bias_tile) {   // partial column sums of this segment: float atomics straight into the bias gradient
-        float b = bsum;
-        b += __shfl_xor(b, 16, 64);
-        b += __shfl_xor(b, 32, 64);
-        const int n = n0 + wk * 16 + r15;
-        if (q == 0 && n < jb.N) atomicAdd(jb.dbias + n, b);
-      }
-      bsum = 0.f;
-    }
-    // commit the cursor values computed inside the block
-    cgt = n_cgt; cm = n_cm; seg0 = n_seg0; cls = cls + 1;
-    cj = n_cj; ctile = n_ctile; c_tn = n_tn; c_tk = n_tk; c_bias = n_bias;
-    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
-    if constexpr (DBG == 5) { const unsigned long long t = stamp_now(); sg3 += t - tlast; tlast = t; }
-  };
-  for (int gc = 0; gc < total; gc += 2) {
-    step(fa, fb);
-    if (gc + 1 < total) step(fb, fa);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SPG_DEV_KERNELS
-  if constexpr (DBG == 5) {
-    if (lane == 0 && blockIdx.x < 256) {
-      unsigned long long* o = tn_stamp_sums + ((int)blockIdx.x * 8 + wave) * 4;
-      o[0] = sg0; o[1] = sg1; o[2] = sg2; o[3] = sg3;
-    }
-  }
-#endif
-}
-
+#include "dev/gemm_tn_group8.inc"
 #endif  // SPG_DEV_KERNELS (8-wave grouped wgrad kernel)
 
 // ------------------------------------------------------------------------------------------------
@@ -2829,611 +1976,7 @@ __global__ __launch_bounds__(256) void tn_group_reduce_batch_kernel(TnReduceBatc
 }
 
 #ifdef SPG_DEV_KERNELS
-// ------------------------------------------------------------------------------------------------
-// gemm_tn_wide_kernel: the grouped wgrad kernel with 256 x 128 (n x k) or 128 x 256 macro-tiles, chosen per problem on the host.
-// The grouped 128 x 128 kernel is fill-bound (81 of 99 us without any MFMA): a macro-tile moves 48 KiB per 64-row
-// step for twice the FLOPs of a 32 KiB 128 x 128 step, i.e. 0.75x the LDS-fill and panel re-read bytes per FLOP.
-// Stage = three [64 m][128] sub-tiles (48 KiB): wide-n: dY cols n0..+127, dY cols n0+128..+255, X cols k0..+127;
-//                                                wide-k: dY cols n0..+127, X cols k0..+127, X cols k0+128..+255.
-// 3 stages (144 KiB), two groups in flight; 8 waves as 4 (n) x 2 (k) or 2 x 4, wave tile 64 x 64 (32 MFMAs, 16 fragments per step).
-// MEASURED (tools/tn_group_bench.py): not faster than the 128 x 128 kernel where it matters -- its fill pipeline alone (no MFMAs)
-// takes 87.7 us for 484 MB on a stage-3 block against 81 us for 633 MB: with only two 48 KiB groups in flight per CU the sustained
-// fill rate drops (5.5 vs 7.8 TB/s aggregate), so fewer bytes per FLOP do not become less time.  Kept opt-in.  One lane offset per fragment: its second transpose read (+4 rows) and its second k-half
-// (+32 rows) keep the row swizzle, so they are immediates (+1 KiB, +8 KiB).  Schedule, slabs and reduce as in gemm_tn_group_kernel.
-// ------------------------------------------------------------------------------------------------
-constexpr int TNW_SLOT_FLOATS = 256 * 128;
-struct TnwJob {
-  const void* dY; const void* X; float* dW; float* dbias;
-  int N, K, ldy, ldx, ldw;
-  int wide_n;                 // 1: 256 (n) x 128 (k) macro-tiles, 0: 128 x 256
-  int tiles_k, tiles, tile0;
-};
-struct TnwGroup {
-  TnwJob job[TN_GROUP_MAX];
-  int njobs, M, S, T, W, RS;
-};
-__device__ __forceinline__ void tnw_locate_tile(const TnwGroup& g, int gt, int& j, int& tile) {
-  j = 0;
-#pragma unroll 1
-  for (int i = 1; i < g.njobs; ++i) if (gt >= g.job[i].tile0) j = i;
-  tile = gt - g.job[j].tile0;
-}
-
-template <typename T, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnwGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
-  static_assert(sizeof(T) == 2, "bf16 only");
-  using F = TnFrag<T>;
-  constexpr int MSTEP = 64, STAGES = 3, SUB_B = 16384, STAGE_B = 3 * SUB_B;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int G = (int)gridDim.x;
-  const int c = xcd_remap(blockIdx.x, G);
-  const int S = g.S;
-  const int WS = g.W * S;
-  const int rb = (int)((long)c * g.RS / G), re = (int)((long)(c + 1) * g.RS / G);
-  const int total = WS + (re - rb);
-  if (total <= 0) return;
-  const int gt_first = WS > 0 ? c * g.W : g.W * G + rb / S;
-  const int m_first = WS > 0 ? 0 : rb % S;
-  const int gt_rem = g.W * G + rb / S, m_rem = rb % S;
-  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
-  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
-
-  // ---- DMA issue stream: a wave moves pieces {wave, wave + 8} of each of the three sub-tiles per step
-  const int lrow = lane >> 4, lpc = lane & 15;
-  const int prow0 = wave * 4 + lrow;
-  const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;
-  int is_job = -1, is_gt = gt_first, is_tile, is_mstep = m_first, is_ls = 0, is_slot = 0, is_ndy = 1;
-  bool is_live = true;
-  bool sin[3] = {false, false, false};           // the sub-tile's 8 columns of this lane are inside the matrix
-  unsigned soff[3] = {0u, 0u, 0u}, sstride[3] = {0u, 0u, 0u}, s32[3] = {0u, 0u, 0u};
-  rsrc_words_t yr, xr;
-  auto is_enter_tile = [&]() __attribute__((always_inline)) {
-    int j;
-    tnw_locate_tile(g, is_gt, j, is_tile);
-    const TnwJob& jb = g.job[j];
-    if (j != is_job) {
-      is_job = j;
-      yr = make_rsrc_words(jb.dY, (unsigned)((long)g.M * jb.ldy * 2));
-      xr = make_rsrc_words(jb.X, (unsigned)((long)g.M * jb.ldx * 2));
-      is_ndy = jb.wide_n ? 2 : 1;
-    }
-    const int tk = is_tile % jb.tiles_k, tn = is_tile / jb.tiles_k;
-    const int n0 = tn * (jb.wide_n ? 256 : 128), k0 = tk * (jb.wide_n ? 128 : 256);
-    const long m0 = (long)is_mstep * MSTEP + prow0;
-#pragma unroll
-    for (int sb = 0; sb < 3; ++sb) {
-      const bool isy = sb < is_ndy;
-      const int col = (isy ? n0 + 128 * sb : k0 + 128 * (sb - is_ndy)) + fcol;
-      const int ld = isy ? jb.ldy : jb.ldx;
-      soff[sb] = (unsigned)((m0 * ld + col) * 2);
-      sstride[sb] = (unsigned)(MSTEP * ld * 2);
-      s32[sb] = (unsigned)(32 * ld * 2);
-      sin[sb] = col < (isy ? jb.N : jb.K);
-    }
-  };
-  is_enter_tile();
-  unsigned dof[3][2];
-  auto dma_addr = [&](int sb) __attribute__((always_inline)) {   // rows past M fall outside the descriptors: hardware zero fill
-    dof[sb][0] = (is_live && sin[sb]) ? soff[sb] : OOB;
-    dof[sb][1] = (is_live && sin[sb]) ? soff[sb] + s32[sb] : OOB;
-  };
-  auto dma_go = [&](int sb, int h) __attribute__((always_inline)) {
-    const unsigned st = smem_base + is_slot * STAGE_B + sb * SUB_B + (h * 8 + wave) * 1024;
-    if (sb < is_ndy) dma16_asm(yr, st, dof[sb][h]); else dma16_asm(xr, st, dof[sb][h]);
-  };
-  auto issue_advance = [&]() __attribute__((always_inline)) {
-    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
-#pragma unroll
-    for (int sb = 0; sb < 3; ++sb) soff[sb] += sstride[sb];
-    ++is_ls;
-    const bool tile_end = is_mstep + 1 == S;
-    if (is_ls >= total) is_live = false;
-    else if (is_ls == WS) { is_gt = gt_rem; is_mstep = m_rem; is_enter_tile(); }
-    else if (tile_end) { is_gt = is_gt + 1; is_mstep = 0; is_enter_tile(); }
-    else is_mstep = is_mstep + 1;
-  };
-
-  // ---- fragments: a = dY (n) blocks, b = X (k) blocks of this wave's 64 x 64 tile; one byte offset per fragment
-  int oa[4], ob[4];
-  int wn = 0, wk = 0;
-  auto set_wave_layout = [&](int wide_n) __attribute__((always_inline)) {
-    wn = wide_n ? (wave & 3) : (wave & 1);
-    wk = wide_n ? (wave >> 2) : (wave >> 1);
-    const int ndy = wide_n ? 2 : 1;
-    const int ncol = 64 * wn, kcol = 64 * wk;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int o0, o1;
-      F::offsets(0, (ncol & 127) + i * 16, lane, o0, o1);
-      oa[i] = (ncol >> 7) * SUB_B + o0;
-      F::offsets(0, (kcol & 127) + i * 16, lane, o0, o1);
-      ob[i] = (ndy + (kcol >> 7)) * SUB_B + o0;
-    }
-  };
-  // fragments are NOT double-buffered across steps here (acc 64 + 2 x 64 fragment registers spilled inside the loop): the kernel
-  // is fill-bound, so a step reads its first k-half up front and hides the second k-half's reads behind the first half's MFMAs
-  struct Frags { typename F::Frag a[2][4], b[2][4]; };
-  Frags fr;
-  auto read_frag = [&](const char* st, int idx) __attribute__((always_inline)) {   // idx 0..15: per k-half {b0..b3, a0..a3}
-    const int sx = idx >> 3, r = idx & 7;
-    const int o = (r < 4 ? ob[r] : oa[r - 4]) + sx * 8192;       // second k-half: +32 rows, same swizzle
-    const typename F::Frag v = F::load_at(st, o, o + 1024);      // second read: +4 rows, same swizzle
-    if (r < 4) fr.b[sx][r] = v; else fr.a[sx][r - 4] = v;
-  };
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
-  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
-
-  // ---- compute cursor
-  int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;
-  int cj, ctile;
-  tnw_locate_tile(g, cgt, cj, ctile);
-  set_wave_layout(g.job[cj].wide_n);
-
-  // ---- prologue: two groups in flight
-  for (int i = 0; i < STAGES - 1; ++i) {
-#pragma unroll
-    for (int sb = 0; sb < 3; ++sb) { dma_addr(sb); dma_go(sb, 0); dma_go(sb, 1); }
-    issue_advance();
-  }
-
-  int rd_slot = 0, st1 = 0, st2 = 0;
-  const int r15 = lane & 15, q = lane >> 4;
-  auto mma_block = [&](auto BIAS_) __attribute__((always_inline)) {
-    constexpr bool BIAS = decltype(BIAS_)::value;
-    const char* rst = smem + rd_slot * STAGE_B;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) read_frag(rst, i);             // k-half 0 of this step (exposed)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int ms = i >> 4, r = i & 15, ni = r >> 2, ki = r & 3;
-      if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(fr.b[ms][ki], fr.a[ms][ni], acc[ni][ki]);     // D[k][n]
-      else asm volatile("" :: "v"(fr.b[ms][ki]), "v"(fr.a[ms][ni]));
-      if (i < 8) read_frag(rst, 8 + i);                          // k-half 1 behind the first half's MFMAs
-      if (i == 8) dma_addr(0);
-      if (i == 9) dma_go(0, 0);
-      if (i == 10) dma_go(0, 1);
-      if (i == 11) dma_addr(1);
-      if (i == 12) dma_go(1, 0);
-      if (i == 13) dma_go(1, 1);
-      if (i == 14) dma_addr(2);
-      if (i == 15) dma_go(2, 0);
-      if (i == 16) dma_go(2, 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (BIAS) {
-      // column sums of dY from the fragments just multiplied: the waves sharing an n range split its four 16-column blocks
-      const bool two = g.job[cj].wide_n != 0;       // wide-n: 2 waves per n range -> 2 blocks each; wide-k: 4 waves -> 1 block each
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int blk = two ? 2 * wk + h : wk;
-          if (h == 0 || two) {
-            const typename F::Frag v = blk == 0 ? fr.a[ms][0] : (blk == 1 ? fr.a[ms][1] : (blk == 2 ? fr.a[ms][2] : fr.a[ms][3]));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bf16x2_t pr = {v[2 * e], v[2 * e + 1]};
-              bsum[h] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum[h], false);
-            }
-          }
-        }
-    }
-  };
-  auto step = [&]() __attribute__((always_inline)) {
-    // stage gc landed: one younger group (6 pieces) + the last two steps' flush stores (16 each) may stay outstanding
-    if (st1 + st2 == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    st2 = st1; st1 = 0;
-    const TnwJob& jb = g.job[cj];
-    const int tk = ctile % jb.tiles_k, tn = ctile / jb.tiles_k;
-    const bool bias_tile = jb.dbias != nullptr && tk == 0;
-    if (bias_tile) mma_block(std::true_type{}); else mma_block(std::false_type{});
-    __builtin_amdgcn_sched_barrier(0);
-    const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
-    const bool range_end = cls + 1 == total;
-    if (tile_end || range_end) {
-      const int TNn = jb.wide_n ? 256 : 128, TNk = jb.wide_n ? 128 : 256;
-      const int n0 = tn * TNn + wn * 64, k0 = tk * TNk + wk * 64;
-      if (seg0 == 0 && tile_end) {
-        const __amdgpu_buffer_rsrc_t wr = make_rsrc(jb.dW, (unsigned)((long)jb.N * jb.ldw * 4));
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {       // one n block at a time: 4 loads in flight, 16 VGPRs
-          u32x4 old[4];
-          unsigned o[4];
-#pragma unroll
-          for (int ki = 0; ki < 4; ++ki) {
-            const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
-            o[ki] = (n < jb.N && k < jb.K) ? (unsigned)(((long)n * jb.ldw + k) * 4) : OOB;
-            old[ki] = bload16(wr, o[ki]);
-          }
-#pragma unroll
-          for (int ki = 0; ki < 4; ++ki) {
-            const f32x4 v = acc[ni][ki] + f32x4{__uint_as_float(old[ki].x), __uint_as_float(old[ki].y), __uint_as_float(old[ki].z),
-                                                __uint_as_float(old[ki].w)};
-            bstore16(wr, o[ki], u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
-            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-        }
-      } else {
-        const int slot = seg0 != 0 ? 0 : 1;
-        const unsigned base = (unsigned)(((long)c * 2 + slot) * TNW_SLOT_FLOATS * 4);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int ki = 0; ki < 4; ++ki) {
-            const int nl = wn * 64 + ni * 16 + r15, kl = wk * 64 + ki * 16 + q * 4;
-            bstore16(sr, base + (unsigned)((nl * TNk + kl) * 4), u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
-                                                                       __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
-            acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-      }
-      st1 = 16;
-      if (bias_tile) {
-        const bool two = jb.wide_n != 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (h == 0 || two) {
-            float b = bsum[h];
-            b += __shfl_xor(b, 16, 64);
-            b += __shfl_xor(b, 32, 64);
-            const int n = n0 + (two ? 2 * wk + h : wk) * 16 + r15;
-            if (q == 0 && n < jb.N) atomicAdd(jb.dbias + n, b);
-          }
-        }
-      }
-      bsum[0] = 0.f; bsum[1] = 0.f;
-    }
-    const int nls = cls + 1;
-    const bool jump = nls == WS && nls < total;
-    const bool moved = (jump || tile_end) && !range_end;
-    cgt = jump ? gt_rem : (tile_end ? cgt + 1 : cgt);
-    cm = jump ? m_rem : (tile_end ? 0 : cm + 1);
-    seg0 = jump ? m_rem : (tile_end ? 0 : seg0);
-    cls = nls;
-    issue_advance();
-    rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
-    if (moved) {
-      const int pj = cj;
-      tnw_locate_tile(g, cgt, cj, ctile);
-      if (g.job[cj].wide_n != g.job[pj].wide_n) set_wave_layout(g.job[cj].wide_n);   // next step reads with the new wave layout
-    }
-  };
-  for (int gc = 0; gc < total; ++gc) step();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-__global__ __launch_bounds__(256) void tnw_reduce_kernel(TnwGroup g, const float* __restrict__ slabs, int G) {
-  const int c = blockIdx.x + 1;
-  const int S = g.S;
-  const int b = (int)((long)c * g.RS / G);
-  if (b >= g.RS) return;
-  const int mstep = b % S;
-  if (mstep == 0) return;
-  const int tile_start = b - mstep;
-  if ((int)((long)(c - 1) * g.RS / G) > tile_start) return;
-  int j, tile;
-  tnw_locate_tile(g, g.W * G + b / S, j, tile);
-  const TnwJob& jb = g.job[j];
-  const int tile_endg = tile_start + S;
-  int clast = c;
-  while (clast + 1 < G && (int)((long)(clast + 1) * g.RS / G) < tile_endg) ++clast;
-  const int TNn = jb.wide_n ? 256 : 128, TNk = jb.wide_n ? 128 : 256;
-  const int tk = tile % jb.tiles_k, tn = tile / jb.tiles_k;
-  const int per = (TNW_SLOT_FLOATS / 4) / (int)gridDim.y;
-  const int kq = TNk / 4;                                   // float4 per slab row
-  for (int v = blockIdx.y * per + threadIdx.x; v < (blockIdx.y + 1) * per; v += 256) {
-    const int nl = v / kq, kl = (v - nl * kq) * 4;
-    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + ((long)(c - 1) * 2 + 1) * TNW_SLOT_FLOATS + v * 4);
-#pragma unroll 4
-    for (int cc = c; cc <= clast; ++cc) s += *reinterpret_cast<const f32x4*>(slabs + ((long)cc * 2 + 0) * TNW_SLOT_FLOATS + v * 4);
-    const int n = tn * TNn + nl, k = tk * TNk + kl;
-    if (n < jb.N && k < jb.K) {
-      float* d = jb.dW + (long)n * jb.ldw + k;
-      *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + s;
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// gemm_tn_wide_pp_kernel: the macro-tile grouped wgrad kernel above with the two-group schedule of conv_halo.hip.  Waves 0-3 and 4-7 run
-// the same program ONE barrier apart: while one group issues its 32-MFMA cluster, the other issues the next step's 32 transpose reads
-// and its 6 LDS-DMA pieces, so the matrix pipe never waits for a wave's own loads (the kernel above reads, fills and multiplies in
-// every wave at once: its fill pipeline alone took as long as the whole step).  Step = 64 rows of M; stage = three [64][128] sub-tiles
-// (48 KiB) as above, 3 stages: step s multiplies slot s % 3 while the pieces of step s + 2 go to slot (s + 2) % 3, the slot read one
-// phase earlier (every wave's reads have returned -- lgkmcnt(0) -- before the barrier that precedes the issue).  vmcnt(6) after the
-// issue retires step s + 1's pieces (this wave's; the barrier publishes everyone's).  The cursor / address arithmetic of the next
-// step sits in the gaps of the MFMA cluster, pinned by empty volatile asm statements (conv_halo.hip).  A finished tile leaves in the
-// NEXT step's issue segment (dW read-modify-write for whole tiles, slab stores for partial ones): schedule, slabs and reduce as above.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm_tn_wide_pp_kernel(TnwGroup g, float* __restrict__ slabs, unsigned slab_bytes) {
-  static_assert(sizeof(T) == 2, "bf16 only");
-  using F = TnFrag<T>;
-  constexpr int MSTEP = 64, STAGES = 3, SUB_B = 16384, STAGE_B = 3 * SUB_B;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;
-  const int G = (int)gridDim.x;
-  const int c = xcd_remap(blockIdx.x, G);
-  const int S = g.S;
-  const int WS = g.W * S;
-  const int rb = (int)((long)c * g.RS / G), re = (int)((long)(c + 1) * g.RS / G);
-  const int total = WS + (re - rb);
-  if (total <= 0) return;
-  const int gt_first = WS > 0 ? c * g.W : g.W * G + rb / S;
-  const int m_first = WS > 0 ? 0 : rb % S;
-  const int gt_rem = g.W * G + rb / S, m_rem = rb % S;
-  const __amdgpu_buffer_rsrc_t sr = make_rsrc(slabs, slab_bytes);
-  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
-
-  // ---- DMA issue stream (two steps ahead of the multiplication): a wave moves pieces {wave, wave + 8} of each of the three sub-tiles
-  const int lrow = lane >> 4, lpc = lane & 15;
-  const int prow0 = wave * 4 + lrow;
-  const int fcol = ((((lpc >> 1) ^ tnd_swz(prow0)) << 1) | (lpc & 1)) * 8;
-  int is_job = -1, is_gt = gt_first, is_tile, is_mstep = m_first, is_ls = 0, is_slot = 0, is_ndy = 1;
-  bool is_live = true;
-  bool sin[3] = {false, false, false};           // the sub-tile's 8 columns of this lane are inside the matrix
-  unsigned soff[3] = {0u, 0u, 0u}, sstride[3] = {0u, 0u, 0u}, s32[3] = {0u, 0u, 0u};
-  rsrc_words_t yr, xr;
-  auto is_enter_tile = [&]() __attribute__((always_inline)) {
-    int j;
-    tnw_locate_tile(g, is_gt, j, is_tile);
-    const TnwJob& jb = g.job[j];
-    if (j != is_job) {
-      is_job = j;
-      yr = make_rsrc_words(jb.dY, (unsigned)((long)g.M * jb.ldy * 2));
-      xr = make_rsrc_words(jb.X, (unsigned)((long)g.M * jb.ldx * 2));
-      is_ndy = jb.wide_n ? 2 : 1;
-    }
-    const int tk = is_tile % jb.tiles_k, tn = is_tile / jb.tiles_k;
-    const int n0 = tn * (jb.wide_n ? 256 : 128), k0 = tk * (jb.wide_n ? 128 : 256);
-    const long m0 = (long)is_mstep * MSTEP + prow0;
-#pragma unroll
-    for (int sb = 0; sb < 3; ++sb) {
-      const bool isy = sb < is_ndy;
-      const int col = (isy ? n0 + 128 * sb : k0 + 128 * (sb - is_ndy)) + fcol;
-      const int ld = isy ? jb.ldy : jb.ldx;
-      soff[sb] = (unsigned)((m0 * ld + col) * 2);
-      sstride[sb] = (unsigned)(MSTEP * ld * 2);
-      s32[sb] = (unsigned)(32 * ld * 2);
-      sin[sb] = col < (isy ? jb.N : jb.K);
-    }
-  };
-  is_enter_tile();
-  unsigned dof[3][2];          // prepared source offsets of the six pieces of the stream's current step
-  unsigned d_slot = 0;         // ... and the stage they go to (byte offset)
-  int d_ndy = 1;
-  rsrc_words_t d_yr, d_xr;
-  auto dma_prepare = [&]() __attribute__((always_inline)) {   // rows past M fall outside the descriptors: hardware zero fill
-#pragma unroll
-    for (int sb = 0; sb < 3; ++sb) {
-      dof[sb][0] = (is_live && sin[sb]) ? soff[sb] : OOB;
-      dof[sb][1] = (is_live && sin[sb]) ? soff[sb] + s32[sb] : OOB;
-    }
-    d_slot = (unsigned)(is_slot * STAGE_B);
-    d_ndy = is_ndy; d_yr = yr; d_xr = xr;
-  };
-  auto dma_issue = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int sb = 0; sb < 3; ++sb)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const unsigned st = smem_base + d_slot + sb * SUB_B + (h * 8 + wave) * 1024;
-        if (sb < d_ndy) dma16_asm(d_yr, st, dof[sb][h]); else dma16_asm(d_xr, st, dof[sb][h]);
-      }
-  };
-  auto issue_advance = [&]() __attribute__((always_inline)) {
-    is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
-#pragma unroll
-    for (int sb = 0; sb < 3; ++sb) soff[sb] += sstride[sb];
-    ++is_ls;
-    const bool tile_end = is_mstep + 1 == S;
-    if (is_ls >= total) is_live = false;
-    else if (is_ls == WS) { is_gt = gt_rem; is_mstep = m_rem; is_enter_tile(); }
-    else if (tile_end) { is_gt = is_gt + 1; is_mstep = 0; is_enter_tile(); }
-    else is_mstep = is_mstep + 1;
-  };
-
-  // ---- fragments: a = dY (n) blocks, b = X (k) blocks of this wave's 64 x 64 tile; one byte offset per fragment
-  int oa[4], ob[4];
-  int wn = 0, wk = 0;
-  auto set_wave_layout = [&](int wide_n) __attribute__((always_inline)) {
-    wn = wide_n ? (wave & 3) : (wave & 1);
-    wk = wide_n ? (wave >> 2) : (wave >> 1);
-    const int ndy = wide_n ? 2 : 1;
-    const int ncol = 64 * wn, kcol = 64 * wk;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int o0, o1;
-      F::offsets(0, (ncol & 127) + i * 16, lane, o0, o1);
-      oa[i] = (ncol >> 7) * SUB_B + o0;
-      F::offsets(0, (kcol & 127) + i * 16, lane, o0, o1);
-      ob[i] = (ndy + (kcol >> 7)) * SUB_B + o0;
-    }
-  };
-  typename F::Frag fa[2][4], fb[2][4];
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
-  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
-  const int r15 = lane & 15, q = lane >> 4;
-
-  // ---- compute cursor (the step being multiplied) and the finished tile waiting for its stores
-  int cgt = gt_first, cm = m_first, seg0 = m_first, cls = 0;
-  int cj, ctile;
-  tnw_locate_tile(g, cgt, cj, ctile);
-  set_wave_layout(g.job[cj].wide_n);
-  bool ep_pending = false, ep_whole = false, ep_bias = false;
-  int ep_j = 0, ep_tile = 0, ep_slot = 0, ep_wn = 0, ep_wk = 0;
-  auto flush = [&]() __attribute__((always_inline)) {   // the finished (part of a) tile leaves: accumulators restart at zero
-    const TnwJob& jb = g.job[ep_j];
-    const int tk = ep_tile % jb.tiles_k, tn = ep_tile / jb.tiles_k;
-    const int TNn = jb.wide_n ? 256 : 128, TNk = jb.wide_n ? 128 : 256;
-    const int n0 = tn * TNn + ep_wn * 64, k0 = tk * TNk + ep_wk * 64;
-    if (ep_whole) {
-      const __amdgpu_buffer_rsrc_t wr = make_rsrc(jb.dW, (unsigned)((long)jb.N * jb.ldw * 4));
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {       // one n block at a time: 4 loads in flight, 16 VGPRs
-        u32x4 old[4];
-        unsigned o[4];
-#pragma unroll
-        for (int ki = 0; ki < 4; ++ki) {
-          const int n = n0 + ni * 16 + r15, k = k0 + ki * 16 + q * 4;
-          o[ki] = (n < jb.N && k < jb.K) ? (unsigned)(((long)n * jb.ldw + k) * 4) : OOB;
-          old[ki] = bload16(wr, o[ki]);
-        }
-#pragma unroll
-        for (int ki = 0; ki < 4; ++ki) {
-          const f32x4 v = acc[ni][ki] + f32x4{__uint_as_float(old[ki].x), __uint_as_float(old[ki].y), __uint_as_float(old[ki].z),
-                                              __uint_as_float(old[ki].w)};
-          bstore16(wr, o[ki], u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
-          acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    } else {
-      const unsigned base = (unsigned)(((long)c * 2 + ep_slot) * TNW_SLOT_FLOATS * 4);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int ki = 0; ki < 4; ++ki) {
-          const int nl = ep_wn * 64 + ni * 16 + r15, kl = ep_wk * 64 + ki * 16 + q * 4;
-          bstore16(sr, base + (unsigned)((nl * TNk + kl) * 4), u32x4{__float_as_uint(acc[ni][ki][0]), __float_as_uint(acc[ni][ki][1]),
-                                                                     __float_as_uint(acc[ni][ki][2]), __float_as_uint(acc[ni][ki][3])});
-          acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    if (ep_bias) {
-      const bool two = jb.wide_n != 0;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (h == 0 || two) {
-          float b = bsum[h];
-          b += __shfl_xor(b, 16, 64);
-          b += __shfl_xor(b, 32, 64);
-          const int n = n0 + (two ? 2 * ep_wk + h : ep_wk) * 16 + r15;
-          if (q == 0 && n < jb.N) atomicAdd(jb.dbias + n, b);
-        }
-      }
-    }
-    bsum[0] = 0.f; bsum[1] = 0.f;
-    ep_pending = false;
-  };
-
-  // ---- prologue: two groups in flight, the third step's pieces prepared
-  for (int i = 0; i < STAGES - 1; ++i) {
-    dma_prepare();
-    dma_issue();
-    issue_advance();
-  }
-  dma_prepare();
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __syncthreads();
-  if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier interval behind group 0
-
-  int rd_slot = 0;
-  for (int gc = 0; gc < total; ++gc) {
-    const TnwJob& jb = g.job[cj];
-    const bool bias_tile = jb.dbias != nullptr && (ctile % jb.tiles_k) == 0;
-    // ================= issue segment: the step's 32 transpose reads, the 6 pieces of the step after next, a finished tile's stores
-    if (ep_pending) flush();
-    {
-      const char* rst = smem + rd_slot * STAGE_B;
-      if constexpr (DBG != 3) {
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) fb[sx][r] = F::load_at(rst, ob[r] + sx * 8192, ob[r] + sx * 8192 + 1024);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) fa[sx][r] = F::load_at(rst, oa[r] + sx * 8192, oa[r] + sx * 8192 + 1024);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    dma_issue();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ================= MFMA segment; the cursors and the next pieces' addresses move in its gaps
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int ms = i >> 4, r = i & 15, ni = r >> 2, ki = r & 3;
-      if constexpr (DBG != 2) acc[ni][ki] = Mma<T>::mma(fb[ms][ki], fa[ms][ni], acc[ni][ki]);     // D[k][n]
-      else asm volatile("" :: "v"(fb[ms][ki]), "v"(fa[ms][ni]));
-      __builtin_amdgcn_sched_barrier(0);
-      if (i == 2) {   // the stream moves one step on
-        asm volatile("" : "+s"(is_ls));
-        issue_advance();
-        asm volatile("" : "+s"(is_ls));
-      }
-      if (i == 6) {
-        dma_prepare();
-#pragma unroll
-        for (int sb = 0; sb < 3; ++sb) { asm volatile("" : "+v"(dof[sb][0])); asm volatile("" : "+v"(dof[sb][1])); }
-      }
-      if (i >= 8 && i < 24 && bias_tile) {   // column sums of dY from the fragments being multiplied: one fragment element pair per gap
-        const bool two = jb.wide_n != 0;
-        const int idx = i - 8, ms_ = idx >> 3, h = (idx >> 2) & 1, e = idx & 3;
-        const int blk = two ? 2 * wk + h : wk;
-        if (h == 0 || two) {
-          const typename F::Frag v = blk == 0 ? fa[ms_][0] : (blk == 1 ? fa[ms_][1] : (blk == 2 ? fa[ms_][2] : fa[ms_][3]));
-          const bf16x2_t pr = {v[2 * e], v[2 * e + 1]};
-          bsum[h] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones2, bsum[h], false);
-        }
-      }
-      if (i == 26) {   // the compute cursor moves on; a finished tile is handed to the next issue segment
-        asm volatile("" : "+s"(cls));
-        const bool tile_end = __builtin_amdgcn_readfirstlane(cm + 1) == S;
-        const bool range_end = cls + 1 == total;
-        if (tile_end || range_end) {
-          ep_pending = true;
-          ep_whole = seg0 == 0 && tile_end;
-          ep_slot = seg0 != 0 ? 0 : 1;
-          ep_j = cj; ep_tile = ctile; ep_wn = wn; ep_wk = wk; ep_bias = bias_tile;
-        }
-        const int nls = cls + 1;
-        const bool jump = nls == WS && nls < total;
-        const bool moved = (jump || tile_end) && !range_end;
-        cgt = jump ? gt_rem : (tile_end ? cgt + 1 : cgt);
-        cm = jump ? m_rem : (tile_end ? 0 : cm + 1);
-        seg0 = jump ? m_rem : (tile_end ? 0 : seg0);
-        cls = nls;
-        rd_slot = rd_slot + 1 == STAGES ? 0 : rd_slot + 1;
-        if (moved) {
-          const int pj = cj;
-          tnw_locate_tile(g, cgt, cj, ctile);
-          if (g.job[cj].wide_n != g.job[pj].wide_n) set_wave_layout(g.job[cj].wide_n);   // the next step reads with the new wave layout
-        }
-        asm volatile("" : "+s"(cls));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-  }
-  if (ep_pending) flush();
-  if (grp == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
+#include "dev/gemm_tn_wide.inc"
 #endif  // SPG_DEV_KERNELS (wide grouped wgrad kernel)
 
 // ------------------------------------------------------------------------------------------------
@@ -3713,179 +2256,7 @@ static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M,
 }
 
 #ifdef SPG_DEV_KERNELS
-template <typename T>
-static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, int N, int K, int ldx, int ldc, int conv,
-                     ConvGeom g, hipStream_t s, int cu_budget) {
-  const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, BM);
-  const int nwg = tiles_n * tiles_m;
-  const long xb = (conv ? (long)M * g.Ci : (long)M * ldx) * (long)sizeof(T), wb = (long)N * K * (long)sizeof(T);
-  if (xb >= 0xFFFFFFF0L || wb >= 0xFFFFFFF0L) {
-    set_error("gemm_nt: operand larger than 4 GiB (X %ld B, W %ld B) is not addressable by one buffer descriptor", xb, wb);
-    return SPG_ERR_UNSUPPORTED;
-  }
-  if constexpr (sizeof(T) == 2) {
-    const int rch = try_conv_halo(X, W, C, epi, N, ldc, conv, g, num_cus(cu_budget), s);
-    if (rch != 1) return rch;
-    const int rcw = try_nt_wide(X, W, C, epi, M, N, K, ldx, ldc, conv, num_cus(cu_budget), s);
-    if (rcw != 1) return rcw;
-    const int rc3 = launch_nt_v3(X, W, C, epi, M, N, K, ldx, ldc, conv, g, s, cu_budget);
-    if (rc3 != NT_V3_NA) return rc3;
-  }
-  if (dev_env("SPG_GEMM_STAGED", 0) == 0) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
-      attr_set = true;
-    }
-    const int grid = nwg < num_cus(cu_budget) ? nwg : num_cus(cu_budget);
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("SPG_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if ((dbg >= 1 && dbg <= 4) && !conv && getenv("SPG_GEMM_PIPE") && atoi(getenv("SPG_GEMM_PIPE")) == 0) {  // ablations of the plain 8-wave DMA kernel
-      constexpr int LDSD = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 1, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
-      if (dbg == 4) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 4, 4, 4>), dim3(grid), dim3(512), LDSD, s, (const T*)X, (const T*)W,
-                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-      } else if (dbg == 3) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, false, 3, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSD);
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 3, 4, 4>), dim3(grid), dim3(512), LDSD, s, (const T*)X, (const T*)W,
-                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-      } else if (dbg == 1)
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 1, 4, 4>), dim3(grid), dim3(512), LDSD, s, (const T*)X, (const T*)W,
-                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-      else
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false, 2, 4, 4>), dim3(grid), dim3(512), LDSD, s, (const T*)X, (const T*)W,
-                           (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-      return check_launch("gemm_nt(dbg)");
-    }
-    static int waves = -1;
-    if (waves < 0) { const char* e = getenv("SPG_GEMM_WAVES"); waves = e ? atoi(e) : 8; }
-    static int pipe = -1;
-    if (pipe < 0) { const char* e = getenv("SPG_GEMM_PIPE"); pipe = e ? atoi(e) : 1; }
-    if constexpr (sizeof(T) == 2) {
-      // pipelined kernel: bf16, >= 2 K steps per tile, 8-element-aligned rows, operands addressable by 32-bit offsets, and an
-      // epilogue it has an instance for (ReLU, or GELU together with gelu_h, go to the plain DMA kernel below)
-      const long cb = ((long)(M - 1) * ldc + N) * 2;
-      const int pact = epi.gelu_h ? (epi.act == SPG_ACT_MUL_H ? PIPE_ACT_MULH : PIPE_ACT_HH)
-                                 : (epi.act == SPG_ACT_GELU ? PIPE_ACT_GELU : (epi.act == SPG_ACT_GELU_SAVE_GRAD ? PIPE_ACT_GELU_D : PIPE_ACT_NONE));
-      const bool epi_ok = epi.act != SPG_ACT_RELU && !(epi.gelu_h && epi.act != SPG_ACT_NONE && epi.act != SPG_ACT_MUL_H) &&
-                      (epi.C2 == nullptr || pact == PIPE_ACT_GELU || pact == PIPE_ACT_GELU_D) && (pact != PIPE_ACT_GELU_D || epi.C2 != nullptr) &&
-                          !(conv && pact != PIPE_ACT_NONE);
-      if (waves == 8 && pipe && K > ROWB / (int)sizeof(T) && N % 8 == 0 && ldc % 8 == 0 && cb < 0xFFFFFFF0L && epi_ok) {
-        static int force_nb = -1;
-        if (force_nb < 0) { const char* e = getenv("SPG_GEMM_NB"); force_nb = e ? atoi(e) : 0; }
-        int nb = 4;
-        if (force_nb >= 2 && force_nb <= 4) nb = force_nb;
-        else {
-          float best = 1e30f;
-          for (int c = 4; c >= 2; --c) {
-            const long t = (long)cdiv(N, 32 * c) * tiles_m;
-            const float cost = (float)cdiv(t, num_cus(cu_budget)) * ((float)c + 1.5f);
-            if (cost < best * 0.999f) { best = cost; nb = c; }
-          }
-        }
-        const int tn_ = cdiv(N, 32 * nb);
-        const int nwg_ = tn_ * tiles_m;
-        const int gridp = nwg_ < num_cus(cu_budget) ? nwg_ : num_cus(cu_budget);
-        PipeEpi pe;
-        pe.c_bytes = (unsigned)cb;
-        pe.c2_bytes = epi.C2 ? (unsigned)cb : 0u;
-        pe.r_bytes = epi.residual ? (unsigned)cb : 0u;
-        pe.h_bytes = epi.gelu_h ? (unsigned)cb : 0u;
-        pe.bias_bytes = epi.bias ? (unsigned)N * 4u : 0u;
-#define SPG_LAUNCHP(C_, A_, NB_, F_, D_)                                                                                                      \
-  do {                                                                                                                                     \
-    static bool attr_ = false;                                                                                                             \
-    if (!attr_) {                                                                                                                          \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pipe_kernel<T, C_, A_, NB_, F_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          PIPE_LDS_BYTES);                                                                                                 \
-      attr_ = true;                                                                                                                        \
-    }                                                                                                                                      \
-    hipLaunchKernelGGL((gemm_nt_pipe_kernel<T, C_, A_, NB_, F_, D_>), dim3(gridp), dim3(512), PIPE_LDS_BYTES, s, (const T*)X, (const T*)W,     \
-                       (T*)C, epi, pe, M, N, K, ldx, ldc, g, tn_, nwg_, (unsigned)xb, (unsigned)wb);                                       \
-  } while (0)
-#define SPG_LAUNCHP_NB(C_, A_, F_)                                                                                  \
-  do {                                                                                                              \
-    if (nb == 4) SPG_LAUNCHP(C_, A_, 4, F_, 0); else if (nb == 3) SPG_LAUNCHP(C_, A_, 3, F_, 0); else SPG_LAUNCHP(C_, A_, 2, F_, 0); \
-  } while (0)
-        // deferred epilogue (experimental, SPG_GEMM_DEFER=1; needs >= 3 K steps per tile): measured slower than the immediate one --
-        // the LDS it parks tiles in costs a fill stage, and the shallower lookahead loses more than the hidden epilogue gains
-        static int defer_on = -1;
-        if (defer_on < 0) { const char* e = getenv("SPG_GEMM_DEFER"); defer_on = e ? atoi(e) : 0; }
-        const bool defer = defer_on && K > 2 * (ROWB / (int)sizeof(T));
-        if ((dbg == 1 || dbg == 2 || dbg == 3 || dbg == 4 || dbg == 8 || dbg == 9) && !conv && nb == 4 && pact == PIPE_ACT_NONE) {
-          if (dbg == 1) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 1); else if (dbg == 3) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 3);
-          else if (dbg == 2) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 2);
-          else if (dbg == 8) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 8); else if (dbg == 9) SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 9);
-          else SPG_LAUNCHP(false, PIPE_ACT_NONE, 4, false, 4);
-        } else if (conv) { if (defer) SPG_LAUNCHP_NB(true, PIPE_ACT_NONE, true); else SPG_LAUNCHP_NB(true, PIPE_ACT_NONE, false); }
-        else if (pact == PIPE_ACT_GELU) { if (defer) SPG_LAUNCHP_NB(false, PIPE_ACT_GELU, true); else SPG_LAUNCHP_NB(false, PIPE_ACT_GELU, false); }
-        else if (pact == PIPE_ACT_HH) {   // the 128-wide gelu' instance would spill with the deferred epilogue's live operands
-          if (defer && nb == 3) SPG_LAUNCHP(false, PIPE_ACT_HH, 3, true, 0);
-          else if (defer && nb == 2) SPG_LAUNCHP(false, PIPE_ACT_HH, 2, true, 0);
-          else SPG_LAUNCHP_NB(false, PIPE_ACT_HH, false);
-        }
-        else if (pact == PIPE_ACT_GELU_D) SPG_LAUNCHP_NB(false, PIPE_ACT_GELU_D, false);
-        else if (pact == PIPE_ACT_MULH) SPG_LAUNCHP_NB(false, PIPE_ACT_MULH, false);
-        else { if (defer) SPG_LAUNCHP_NB(false, PIPE_ACT_NONE, true); else SPG_LAUNCHP_NB(false, PIPE_ACT_NONE, false); }
-#undef SPG_LAUNCHP_NB
-#undef SPG_LAUNCHP
-        return check_launch("gemm_nt(pipe)");
-      }
-    }
-    if (waves == 8) {
-      constexpr int LDS8 = 3 * DMA_STAGE_BYTES + 8 * 16 * 68 * 4;
-      static bool attr8 = false;
-      if (!attr8) {
-#define SPG_SET_ATTR(C_, NB_) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<T, C_, 0, 4, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8)
-        SPG_SET_ATTR(true, 4); SPG_SET_ATTR(false, 4); SPG_SET_ATTR(true, 3); SPG_SET_ATTR(false, 3); SPG_SET_ATTR(true, 2); SPG_SET_ATTR(false, 2);
-#undef SPG_SET_ATTR
-        attr8 = true;
-      }
-      // tile width: minimise rounds(tiles / CUs) x per-tile cost (MFMA work ~ NB, X fill + fixed cost ~ 1.5)
-      static int force_nb = -1;
-      if (force_nb < 0) { const char* e = getenv("SPG_GEMM_NB"); force_nb = e ? atoi(e) : 0; }
-      int nb = 4;
-      if (force_nb >= 2 && force_nb <= 4) nb = force_nb;
-      else {
-        float best = 1e30f;
-        for (int c = 4; c >= 2; --c) {
-          const long t = (long)cdiv(N, 32 * c) * tiles_m;
-          const float cost = (float)cdiv(t, num_cus(cu_budget)) * ((float)c + 1.5f);
-          if (cost < best * 0.999f) { best = cost; nb = c; }
-        }
-      }
-      const int tn_ = cdiv(N, 32 * nb);
-      const int nwg_ = tn_ * tiles_m;
-      const int grid8 = nwg_ < num_cus(cu_budget) ? nwg_ : num_cus(cu_budget);
-#define SPG_LAUNCH8(C_, NB_) hipLaunchKernelGGL((gemm_nt_dma_kernel<T, C_, 0, 4, NB_>), dim3(grid8), dim3(512), LDS8, s, (const T*)X, (const T*)W, \
-                           (T*)C, epi, M, N, K, ldx, ldc, g, tn_, nwg_, (unsigned)xb, (unsigned)wb)
-      if (conv) { if (nb == 4) SPG_LAUNCH8(true, 4); else if (nb == 3) SPG_LAUNCH8(true, 3); else SPG_LAUNCH8(true, 2); }
-      else { if (nb == 4) SPG_LAUNCH8(false, 4); else if (nb == 3) SPG_LAUNCH8(false, 3); else SPG_LAUNCH8(false, 2); }
-#undef SPG_LAUNCH8
-      return check_launch("gemm_nt(dma8)");
-    }
-    if (conv)
-      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, true>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
-                         (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-    else
-      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, false>), dim3(grid), dim3(NT_THREADS), DMA_LDS_BYTES, s, (const T*)X, (const T*)W,
-                         (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-    return check_launch("gemm_nt(dma)");
-  }
-  const size_t lds = 4 * 128 * ROWB;
-  if (conv)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(nwg), dim3(NT_THREADS), lds, s, (const T*)X, (const T*)W, (T*)C,
-                       epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(nwg), dim3(NT_THREADS), lds, s, (const T*)X, (const T*)W,
-                       (T*)C, epi, M, N, K, ldx, ldc, g, tiles_n, nwg, (unsigned)xb, (unsigned)wb);
-  return check_launch("gemm_nt");
-}
-
+#include "dev/launch_nt_dev.inc"
 #else
 // Product dispatch: the pipelined persistent kernel for bf16 problems it has an instance for, the 8-wave LDS-DMA kernel for everything
 // else (fp32 parity mode; bf16 with ReLU, one K step, or rows that are not 8-element aligned).
@@ -4158,67 +2529,7 @@ extern "C" int spg_gemm_tn_group(int dtype, int njobs, const void* const* dY, co
   }
 #endif
 #ifdef SPG_DEV_KERNELS
-  // opt-in (SPG_TN_GROUP_WIDE=1): measured no faster than the 128 x 128 grouped kernel on the stage-3 / stage-4 blocks (97.1 vs 96.5,
-  // 96.7 vs 92.6 us), better only at stage 1 (139 vs 157 us) -- see the kernel's header and DESIGN.md 3.1
-  if (dev_env("SPG_TN_GROUP_WIDE", 0)) {
-    TnwGroup gw;
-    long wtiles = 0;
-    for (int i = 0; i < njobs; ++i) {
-      SPG_REQUIRE(N[i] > 0 && K[i] > 0, "gemm_tn_group: empty problem %d", i);
-      SPG_REQUIRE(N[i] % 8 == 0 && K[i] % 8 == 0 && ldy[i] % 8 == 0 && ldx[i] % 8 == 0 && ldw[i] % 4 == 0 && ldy[i] >= N[i] && ldx[i] >= K[i] &&
-                      ldw[i] >= K[i],
-                  "gemm_tn_group: problem %d: N, K, ldy, ldx must be multiples of 8 (ldw of 4) and leading dimensions >= extents", i);
-      SPG_REQUIRE((long)M * ldy[i] * 2 < 0xFFFFFFF0L && (long)M * ldx[i] * 2 < 0xFFFFFFF0L && (long)N[i] * ldw[i] * 4 < 0xFFFFFFF0L,
-                  "gemm_tn_group: problem %d: operand larger than 4 GiB", i);
-      TnwJob& jb = gw.job[i];
-      jb.dY = dY[i]; jb.X = X[i]; jb.dW = dW[i]; jb.dbias = dbias ? dbias[i] : nullptr;
-      jb.N = N[i]; jb.K = K[i]; jb.ldy = ldy[i]; jb.ldx = ldx[i]; jb.ldw = ldw[i];
-      const long tn_ = (long)cdiv(N[i], 256) * cdiv(K[i], 128), tk_ = (long)cdiv(N[i], 128) * cdiv(K[i], 256);
-      jb.wide_n = (tn_ < tk_ || (tn_ == tk_ && N[i] >= K[i])) ? 1 : 0;     // the orientation with fewer (less padded) macro-tiles
-      jb.tiles_k = jb.wide_n ? cdiv(K[i], 128) : cdiv(K[i], 256);
-      jb.tiles = (int)(jb.wide_n ? tn_ : tk_);
-      jb.tile0 = (int)wtiles;
-      wtiles += jb.tiles;
-    }
-    for (int i = njobs; i < TN_GROUP_MAX; ++i) gw.job[i] = gw.job[njobs - 1];
-    const int S = cdiv(M, 64);
-    SPG_REQUIRE(wtiles * S < 0x7FFFFFFFL, "gemm_tn_group: too many steps");
-    gw.njobs = njobs; gw.M = M; gw.S = S; gw.T = (int)wtiles;
-    const long total_steps = wtiles * S;
-    const int G = total_steps < num_cus(cu_budget) ? (int)total_steps : num_cus(cu_budget);
-    gw.W = (int)(wtiles / G);
-    gw.RS = (int)((wtiles - (long)gw.W * G) * S);
-    const long need = (long)G * 2 * TNW_SLOT_FLOATS * (long)sizeof(float);
-    SPG_REQUIRE(workspace && workspace_bytes >= need, "gemm_tn_group: workspace of %ld bytes needed (got %ld)", need, workspace_bytes);
-    hipStream_t s = (hipStream_t)stream;
-    constexpr int LDSW = 3 * 3 * 16384;
-    static const int dbgw = dev_env("SPG_TN_GROUP_DEBUG", 0);
-    static bool attrw = false;
-    if (!attrw) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<bf16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
-      attrw = true;
-    }
-    static const int widemode = dev_env("SPG_TN_GROUP_WIDE", 0);
-    if (widemode == 2) {
-      static bool attrp = false;
-      if (!attrp) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_pp_kernel<bf16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_pp_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_pp_kernel<bf16_t, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
-        attrp = true;
-      }
-      if (dbgw == 2) hipLaunchKernelGGL((gemm_tn_wide_pp_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
-      else if (dbgw == 3) hipLaunchKernelGGL((gemm_tn_wide_pp_kernel<bf16_t, 3>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
-      else hipLaunchKernelGGL((gemm_tn_wide_pp_kernel<bf16_t, 0>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
-    } else if (dbgw == 2) hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 2>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
-    else hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t, 0>), dim3(G), dim3(512), LDSW, s, gw, (float*)workspace, (unsigned)need);
-    int rc = check_launch("gemm_tn_group(wide)");
-    if (reduce_desc_out) { TnReduceDesc d; memset(&d, 0, sizeof(d)); memcpy(reduce_desc_out, &d, sizeof(d)); }   // reduced right here
-    if (rc || G < 2 || gw.RS == 0) return rc;
-    hipLaunchKernelGGL(tnw_reduce_kernel, dim3(G - 1, 16), dim3(256), 0, s, gw, (const float*)workspace, G);
-    return check_launch("gemm_tn_group(wide reduce)");
-  }
+#include "dev/tn_group_wide_dispatch.inc"
 #endif  // SPG_DEV_KERNELS
   TnGroup g;
   long tiles = 0;

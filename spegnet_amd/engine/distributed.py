@@ -30,7 +30,7 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
         # collective overlaps the backward pass: RCCL is capped to 16 channels here and the trainer sizes the GEMM grids that run
         # beside a collective to COMM_CU_BUDGET CUs (engine/trainer.py; the cu_budget argument of the GEMM entry points).  The step's
         # gradients (431 MB as bf16, 862 MB as fp32: GradSync's payload type) have > 15 ms of backward to hide in, so 16 channels are plenty.
-        # Both numbers are defaults chosen without an 8-GPU measurement (none was available): set the variable to override.  A default only (set the variable to override).
+        # Both numbers are defaults chosen without an 8-GPU measurement (none was available): set the variable to override.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         # "nccl" IS RCCL on ROCm.  SPG_DIST_BACKEND=gloo exists only to rehearse the N>1 code path with several ranks on ONE GPU
         backend = os.environ.get("SPG_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")

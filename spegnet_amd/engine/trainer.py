@@ -349,7 +349,8 @@ class Trainer:
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             # payload type of the gradient all-reduce: the compute dtype unless `training.grad_allreduce_dtype` says otherwise (fp32
             # parity mode must not round its gradients to bf16 on the wire)
-            wire = str(self.config.get('grad_allreduce_dtype', self.model_config['compute_dtype'])).lower()
+            wire = str(self.config.get('grad_allreduce_dtype', self.model_config.get('compute_dtype', 'bf16'))).lower()
+            wire = {'bfloat16': 'bf16', 'float32': 'fp32', 'float': 'fp32'}.get(wire, wire)     # (the spellings SPEGNet._DTYPES accepts)
             if wire not in ('bf16', 'fp32'):
                 raise ValueError(f"training.grad_allreduce_dtype must be 'bf16' or 'fp32', got {wire!r}")
             self.sync = GradSync(self.arena.g, self.arena.unit_ends, compress_bf16=(wire == 'bf16'))
@@ -493,7 +494,10 @@ class Trainer:
         driven by the validation weighted F-measure when validation computes it (Evaluator metrics), by -loss otherwise."""
         train_loader, val_loader = self._loaders(dataset_dirs)
         logger.info("Training samples: %d", len(train_loader.dataset))
-        best, bad = getattr(self, "_resume_best", 0.0), getattr(self, "_resume_bad", 0)   # (restored by resume())
+        resumed = hasattr(self, "_resume_best")
+        # (restored by resume(); a fresh run starts below every possible score, so the first validated epoch always becomes the best,
+        # also when validation falls back to -loss)
+        best, bad = (self._resume_best, getattr(self, "_resume_bad", 0)) if resumed else (-float("inf"), 0)
         min_delta = self.config.get('min_delta', 1e-4)
         start = getattr(self, "_start_epoch", 0)
         for epoch in range(start, self.num_epochs):
@@ -507,8 +511,9 @@ class Trainer:
                 va = self.validate(self._batches(val_loader))
                 score = va['weighted_f'] if 'weighted_f' in va else -va['loss']
                 self.scheduler_step(score)
-                if score - best > min_delta or (epoch == start and 'weighted_f' not in va):
+                if score - best > min_delta:
                     best, bad = score, 0
+                    self._epoch_state = (best, bad)      # (before the save: model_best.pth must carry THIS epoch's early-stop state)
                     if self.monitor.check_best_model(va):
                         self._save_checkpoint(epoch, va, is_best=True)
                 else:

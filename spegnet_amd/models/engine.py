@@ -482,7 +482,8 @@ class Engine:
     # gradient all-reduce of finished ranges between them (engine/trainer.py, multi-GPU graph mode).
     def trunk_bwd_begin(self, ctx, dfeats: List[Optional[Tensor]]):
         self._bw = dict(ctx=ctx, dfeats=dfeats, dx=None, stage=len(dfeats) - 1, unit=0)
-        self._wg_pending = {}     # (a backward that raised half-way must not leave its deferred weight gradients to the next one)
+        # (a backward that raised half-way must not leave its deferred weight gradients / LayerNorm jobs / slab reduces to the next one)
+        self._wg_pending, self._tn_defer, self._ln_jobs = {}, [], []
         if self.unit_cb is not None:
             self.unit_cb(0)   # head gradients are final once trunk backward starts
 
@@ -505,6 +506,8 @@ class Engine:
                 self.unit_cb(st["unit"])
         self.join_wgrad()          # (before the deferred slab reduces: they read what forked launches wrote)
         self.flush_ln_params()
+        # every gradient of the blocks walked so far is complete here: a caller (the multi-GPU segmented step) all-reduces their range next
+        assert not self._wg_pending and not self._ln_jobs, "trunk_bwd_blocks must end with every deferred weight gradient issued"
 
     def trunk_bwd_end(self):
         e = "encoder.encoder."

@@ -95,13 +95,35 @@ def _processor_params(model_config: Dict) -> Dict:
     return {'target_size': ip['target_size'], 'normalize_mean': tuple(ip['normalize_mean']), 'normalize_std': tuple(ip['normalize_std'])}
 
 
+class _StridedShard(torch.utils.data.Sampler):
+    """Unshuffled rank shard WITHOUT padding: indices rank, rank + world, ...  (DistributedSampler pads a shard with repeated samples so
+    that all ranks get the same count; the all-reduced validation sums would then count up to world - 1 samples twice.)  Shards may
+    differ in length by one: the validation loop has no collective per batch, only the all-reduce of the totals at its end."""
+
+    def __init__(self, n: int, rank: int, world: int):
+        self.idx = list(range(rank, n, world))
+
+    def __iter__(self):
+        return iter(self.idx)
+
+    def __len__(self):
+        return len(self.idx)
+
+    def set_epoch(self, epoch: int) -> None:   # (same interface as DistributedSampler; nothing to reshuffle)
+        pass
+
+
 def _loader(ds, batch_size, shuffle, num_workers, rank: int = 0, world: int = 1, drop_last: bool = False) -> DataLoader:
-    """world > 1: each rank iterates its own shard (DistributedSampler: the reference's loader, utils/data_loader.py:287-301, is
-    single-GPU; this is SURVEY 8(e)'s addition to it).  The caller calls `loader.sampler.set_epoch(epoch)` once per epoch."""
+    """world > 1: each rank iterates its own shard (the reference's loader, utils/data_loader.py:287-301, is single-GPU; this is SURVEY
+    8(e)'s addition to it): training = DistributedSampler (seed 42; the caller calls `loader.sampler.set_epoch(epoch)` once per epoch),
+    validation / test (shuffle False) = an unpadded strided shard, so that job-wide sums count every sample exactly once."""
     sampler = None
     if world > 1:
-        from torch.utils.data.distributed import DistributedSampler
-        sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=42, drop_last=drop_last)
+        if shuffle:
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=42, drop_last=drop_last)
+        else:
+            sampler = _StridedShard(len(ds), rank, world)
         shuffle = False
     return DataLoader(ds, batch_size=batch_size, shuffle=shuffle, sampler=sampler, num_workers=num_workers, collate_fn=collate_fn,
                       pin_memory=torch.cuda.is_available(), persistent_workers=num_workers > 0, drop_last=drop_last)

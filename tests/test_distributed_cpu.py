@@ -221,3 +221,20 @@ def test_lib_refuses_a_stale_abi(monkeypatch):
     monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
     with pytest.raises(RuntimeError, match="ABI revision"):
         _lib.load()
+
+
+def test_validation_shards_are_unpadded_and_complete():
+    """Validation / test shards count every sample exactly once job-wide (DistributedSampler would pad each shard to equal length with
+    repeated samples, which the all-reduced validation mean then counts twice)."""
+    from spegnet_amd.utils.data_loader import _StridedShard, _loader
+    for n, world in ((10, 4), (7, 2), (3, 8), (64, 8)):
+        shards = [list(_StridedShard(n, r, world)) for r in range(world)]
+        flat = sorted(i for s_ in shards for i in s_)
+        assert flat == list(range(n)), (n, world, shards)
+        assert max(len(s_) for s_ in shards) - min(len(s_) for s_ in shards) <= 1
+    ds = list(range(10))
+    ld = _loader(ds, 4, False, 0, rank=1, world=4)
+    assert isinstance(ld.sampler, _StridedShard) and list(ld.sampler) == [1, 5, 9]
+    tr = _loader(ds, 4, True, 0, rank=1, world=4, drop_last=True)
+    from torch.utils.data.distributed import DistributedSampler
+    assert isinstance(tr.sampler, DistributedSampler)

@@ -463,8 +463,8 @@ def test_batchnorm_eval(ops, dt):
 
 # ------------------------------------------------------------------------------------------- CFI pieces
 @pytest.mark.parametrize("dt", DT)
-def test_se_block(ops, dt):
-    B, HW, C, R = 3, 36, 64, 32
+@pytest.mark.parametrize("B,HW,C,R", [(3, 36, 64, 32), (16, 144, 512, 32), (42, 64, 512, 32)])   # (batches beyond one 64 KiB staging chunk)
+def test_se_block(ops, dt, B, HW, C, R):
     x = rnd(B, HW, C, seed=1).to(dt)
     w1, w2 = rnd(R, C, seed=2, scale=0.2), rnd(C, R, seed=3, scale=0.3)
     xf = x.float().requires_grad_(True)

@@ -93,3 +93,25 @@ def test_small_row_counts_and_leftovers_fall_back(eng):
     assert len(log) == 1
     e.flush_block_wgrads()
     assert [x[0] for x in log[1:]] == ["tiles", "tiles"] and e._wg_pending == {}
+
+
+def test_trunk_bwd_blocks_tail_leaves_nothing_pending(eng):
+    """The segmented multi-GPU step all-reduces a segment's gradient range right after trunk_bwd_blocks() returns: its tail must have
+    issued every deferred weight gradient (pending whole-block sets, slab reduces, batched LayerNorm parameter gradients)."""
+    e, log, fake = eng
+    fake.layernorm_param_grads_batch = lambda jobs: log.append(("ln", len(jobs), None))
+    fake.gemm_tn_group_reduce = lambda d: (log.append(("reduce", len(d), None)), d.clear())
+    e._ln_jobs, e._forked, e.blocks = [("dy", "x", "m", "r", "dg", "db")] * 2, False, []
+    e._bw = dict(ctx=dict(B=8, blocks=[]), dfeats=[], dx=None, stage=-1, unit=0)
+    for _ in range(2):                                               # two stage-3 blocks pending: 168 of 256 slots, below the 0.9 go-now rule
+        e.queue_block_wgrads(_block(4608, S3))
+    assert e._wg_pending
+    e._tn_defer.append(("desc", "ws"))
+    e.trunk_bwd_blocks(0, 0)                                         # (an empty block range: only the tail runs)
+    assert e._wg_pending == {} and e._ln_jobs == [] and e._tn_defer == []
+    assert [x[0] for x in log if x[0] != "tiles"] == ["ln", "reduce"] or [x[0] for x in log][:1] == ["ln"]
+    # a backward that raised half-way leaves nothing behind for the next one
+    e._wg_pending, e._tn_defer, e._ln_jobs = {4608: [([], 1)]}, [1], [1]
+    e.unit_cb = None
+    e.trunk_bwd_begin(dict(B=8), [None])
+    assert e._wg_pending == {} and e._tn_defer == [] and e._ln_jobs == []

@@ -37,7 +37,8 @@ BENCH_KEYS = {
     "gemm_nt<bf16,conv3x3>": lambda n: (n.startswith("conv3x3_halo_kernel") or n.startswith("gemm_nt_pipe_kernel<unsigned short, true")
                                         or n.startswith("gemm_nt_v3_kernel<true")),
     "gemm_tn_group<bf16> (one trunk block's wgrads)": lambda n: n.startswith("gemm_tn_group_kernel") or n.startswith("gemm_tn_group4_kernel"),
-    "gemm_tn<bf16,conv3x3> (+reduce)": lambda n: n.startswith("gemm_tn_pipe_kernel<unsigned short, true") or n.startswith("gemm_tn_pipe4_kernel<unsigned short, true"),
+    "gemm_tn<bf16,conv3x3> (+reduce)": lambda n: (n.startswith("conv3x3_wgrad_halo_kernel") or n.startswith("gemm_tn_pipe_kernel<unsigned short, true")
+                                                  or n.startswith("gemm_tn_pipe4_kernel<unsigned short, true")),
 }
 
 
