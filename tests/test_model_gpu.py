@@ -385,14 +385,15 @@ def test_head_backward_bf16_per_parameter_matches_fp32_oracle():
         e_h, e_y = float((a_ - b_).norm() / b_.norm()), float((y_ - b_).norm() / b_.norm())
         c_h = float(torch.dot(a_, b_) / (a_.norm() * b_.norm()))
         print(f"  {nm}: relative L2 {e_h:.4f} (yardstick {e_y:.4f}), cosine {c_h:.5f}")
-        assert e_h < 4 * e_y + 0.03 and c_h > 0.9, (nm, e_h, e_y, c_h)
+        assert e_h < 2 * e_y + 0.03 and c_h > 0.96, (nm, e_h, e_y, c_h)      # measured: 0.17-0.19 against a yardstick of 0.165-0.18
     # Per parameter: within a small multiple of what rounding the weights and inputs alone costs.  (Every BatchNorm backward removes the
     # coherent part of the gradient, so the yardstick itself grows from ~0.002 at the prediction heads to ~0.2 at the CFI fusion.)  A wrong
     # kernel leaves its parameter -- and everything upstream of it -- at relative error ~1 / cosine ~0.
-    assert med(rn_h) < 4 * med(rn_y) + 0.02, rep
-    assert min(cos_h.values()) > 0.85 and med(cos_h) > 0.98, rep
+    # (measured on the round-4 tree: median 0.083 against a yardstick of 0.065, cosine minimum 0.973 / median 0.9966)
+    assert med(rn_h) < 2.5 * med(rn_y) + 0.01, rep
+    assert min(cos_h.values()) > 0.93 and med(cos_h) > 0.99, rep
     for k, v in rn_h.items():
-        assert v < 5 * rn_y[k] + 0.05, (k, v, rn_y[k], cos_h[k])
+        assert v < 3 * rn_y[k] + 0.04, (k, v, rn_y[k], cos_h[k])
 
 
 def test_deferred_block_wgrads_equal_per_block_wgrads():
