@@ -110,7 +110,19 @@ QUERIES = {
     "spg_easpp_fuse_bn_bwd_counters": ("i", "ii"),
     "spg_bn_bwd_head_counters": ("i", "ii"),
 }
-_OPTIONAL = {}
+# dev library only (python spegnet_amd/build.py --dev; csrc/dev/nt_chain_host.inc): the chained-launch experiment of tools/chain_bench.py
+_OPTIONAL = {"spg_nt_chain": "ii" "p" "pl" "p" "i" "p"}
+_OPTIONAL_QUERIES = {"spg_nt_chain_counter_words": ("l", "ip")}
+
+
+class ChainPhase(ctypes.Structure):
+    """spg_chain_phase_t of include/spegnet_hip.h (one phase of spg_nt_chain)"""
+    _fields_ = [("kind", _I), ("act", _I), ("depends", _I), ("M", _I), ("N", _I), ("K", _I),
+                ("x", _P), ("w", _P), ("c", _P), ("c2", _P), ("bias", _P), ("residual", _P), ("gelu_h", _P)]
+
+
+CHAIN_GEMM = 0
+CHAIN_MAX_PHASES = 6
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F}
 
 _lib = None
@@ -139,6 +151,10 @@ def load() -> ctypes.CDLL:
     for name, (res, sig) in QUERIES.items():   # size queries: return a count, not a status
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = _CT[res], [_CT[c] for c in sig]
+    for name, (res, sig) in _OPTIONAL_QUERIES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = _CT[res], [_CT[c] for c in sig]
     for table, required in ((SIGNATURES, True), (_OPTIONAL, False)):
         for name, sig in table.items():
             try:

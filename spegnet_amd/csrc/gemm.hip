@@ -443,6 +443,13 @@ __device__ __forceinline__ void wait_vm(int n) {  // s_waitcnt vmcnt(<= n), n wa
 __device__ __forceinline__ void bstore16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const u32x4& v) {
   __builtin_amdgcn_raw_buffer_store_b128(bufvec_t{v.x, v.y, v.z, v.w}, r, byte_off, 0, 0);
 }
+template <int AUX> __device__ __forceinline__ void bstore16_aux(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const u32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(bufvec_t{v.x, v.y, v.z, v.w}, r, byte_off, 0, AUX);
+}
+template <int AUX> __device__ __forceinline__ u32x4 bload16_aux(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  bufvec_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AUX);
+  return u32x4{v[0], v[1], v[2], v[3]};
+}
 
 template <typename T, int NB> struct NtFrags {
   typename Mma<T>::Frag a[Mma<T>::SUB][NB], b[Mma<T>::SUB][2];
@@ -470,11 +477,54 @@ struct PipeEpi {   // byte sizes of the optional epilogue operands (0 = absent)
   unsigned c_bytes, c2_bytes, r_bytes, h_bytes, bias_bytes;
 };
 
-template <typename T, bool CONV, int ACT, int NB, bool DEFER = false, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ C,
-                                                            NtEpi epi, PipeEpi pe, int M, int N, int K, int ldx, int ldc,
-                                                            ConvGeom g, int tiles_n, int ntiles, unsigned xbytes, unsigned wbytes) {
+// One problem of the persistent pipelined kernel, and the cross-workgroup dependencies of a phase of nt_chain_kernel (below): the body is
+// shared by the plain kernel (one problem per launch, CH = 0: nothing of the chain machinery is compiled in) and the chain kernel.
+struct PipeProb {
+  const void* X; const void* W; void* C;
+  NtEpi epi; PipeEpi pe;
+  int M, N, K, ldx, ldc;
+  int tiles_n, ntiles;
+  unsigned xbytes, wbytes;
+};
+struct ChainSync {
+  const unsigned* wait;     // CH & 1: per 128-row block, arrivals of the producing phase (tiles / row items that wrote rows of this block)
+  unsigned wait_target;     //         ... that make the block complete
+  unsigned* sig;            // CH & 2: per 128-row block, this phase's arrival counter (one arrival per finished tile)
+  unsigned* err;            // set to 1 when a bounded wait gave up (the launch then finishes with wrong results instead of hanging)
+};
+constexpr int CHAIN_SPIN_LIMIT = 1 << 17;    // polls of ~0.5-1 us each before a wait gives up
+constexpr int CH_SC1 = 16;                   // cache-policy bit sc1 of the buffer instructions (agent scope: write-through stores, L1-bypassing loads)
+
+// Waits until row block `tm` of the producing phase is complete (every lane polls the same word; relaxed agent-scope loads, s_sleep
+// between polls: MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility").  The data itself is read by
+// sc1 loads afterwards (X through LDS-DMA, residual / gelu_h to registers), the producers stored it sc1 and drained their stores before
+// their arrival.
+__device__ __forceinline__ void chain_wait_block(const ChainSync& cs, int tm) {
+  if (cs.wait == nullptr) return;          // (a chain's first phase: its rows were written before the launch)
+  int spins = 0;
+  while (__hip_atomic_load(cs.wait + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cs.wait_target) {
+    if (++spins >= CHAIN_SPIN_LIMIT) {
+      if ((threadIdx.x & 63) == 0) __hip_atomic_store(cs.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+template <typename T, bool CONV, int ACT, int NB, bool DEFER = false, int DBG = 0, int CH = 0>
+__device__ __forceinline__ void nt_pipe_body(const PipeProb& pb, const ChainSync& cs, const ConvGeom& g, char* __restrict__ smem,
+                                             const int first, const int G) {
   static_assert(sizeof(T) == 2, "bf16 only");
+  static_assert(CH == 0 || (!CONV && !DEFER), "chain phases are dense problems on the plain epilogue");
+  const T* __restrict__ X = (const T*)pb.X;
+  const T* __restrict__ W = (const T*)pb.W;
+  T* __restrict__ C = (T*)pb.C;
+  const NtEpi epi = pb.epi;
+  const PipeEpi pe = pb.pe;
+  const int M = pb.M, N = pb.N, K = pb.K, ldx = pb.ldx, ldc = pb.ldc, tiles_n = pb.tiles_n, ntiles = pb.ntiles;
+  const unsigned xbytes = pb.xbytes, wbytes = pb.wbytes;
+  constexpr int X_AUX = (CH & 1) ? CH_SC1 : 0;      // operands another workgroup of this launch wrote: L1-bypassing loads
+  constexpr int C_AUX = (CH & 2) ? CH_SC1 : 0;      // results another workgroup of this launch reads: write-through stores
   using M_ = Mma<T>;
   constexpr int VEC = ST<T>::VEC;
   constexpr int BK = ROWB / (int)sizeof(T);
@@ -484,13 +534,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
   constexpr int SLAB_BYTES = DEFER ? 2 * PIPE_SLAB_BYTES : PIPE_SLAB_BYTES;
   constexpr int BN_ = 32 * NB;
   constexpr bool NO_DMA = DBG == 1 || DBG == 3;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;
   const int nkt = (K + BK - 1) / BK;
-  const int G = (int)gridDim.x;
-  const int first = xcd_remap(blockIdx.x, G);
   if (first >= ntiles) return;
   const int my_tiles = (ntiles - first + G - 1) / G;
   const int total = my_tiles * nkt;
@@ -507,6 +554,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
   auto enter_tile = [&]() __attribute__((always_inline)) {
     const int tn = is_tile % tiles_n, tm = is_tile / tiles_n;
     is_m0 = tm * BM; is_n0 = tn * BN_;
+    if constexpr ((CH & 1) != 0) chain_wait_block(cs, tm);     // the rows this tile reads (X; residual rows follow transitively)
     if constexpr (CONV) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -537,7 +585,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
     char* st = smem + is_slot * DMA_STAGE_BYTES;
     const int prow = 64 * i + wave * 8;
     if constexpr (!NO_DMA) {
-      if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + prow * ROWB), 16, dxo[i], 0, 0, 0);
+      if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + prow * ROWB), 16, dxo[i], 0, 0, X_AUX);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(st + BM * ROWB + prow * ROWB), 16, dwo[i], 0, 0, 0);
     } else {
       asm volatile("" :: "v"(dxo[i]), "v"(dwo[i]));
@@ -584,7 +632,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
       for (int jj = 0; jj < 2; ++jj) {
         const int m = pm0 + wm * 32 + qt * 16 + erow + 8 * jj;
         eo[qt][jj] = (nin && m < M) ? (unsigned)(((long)m * ldc + n) * 2) : OOB;
-        er[qt][jj] = bload16(rr, eo[qt][jj]);
+        er[qt][jj] = bload16_aux<X_AUX>(rr, eo[qt][jj]);
         if constexpr (ACT == PIPE_ACT_HH || ACT == PIPE_ACT_MULH) eh[qt][jj] = bload16(hr, eo[qt][jj]);
       }
   };
@@ -640,7 +688,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
         unpack16<T>(er[qt][jj], rres);
 #pragma unroll
         for (int e = 0; e < 8; ++e) ev[e] += rres[e];
-        if constexpr (DBG != 4) bstore16(cr, eo[qt][jj], pack16<T>(ev));
+        if constexpr (DBG != 4) bstore16_aux<C_AUX>(cr, eo[qt][jj], pack16<T>(ev));
         else asm volatile("" :: "v"(ev[0]), "v"(ev[1]), "v"(ev[2]), "v"(ev[3]), "v"(ev[4]), "v"(ev[5]), "v"(ev[6]), "v"(ev[7]));
       }
     }
@@ -688,7 +736,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
       unpack16<T>(er[qt][jj], rres);
 #pragma unroll
       for (int e = 0; e < 8; ++e) cv[e] += rres[e];
-      bstore16(cr, eo[qt][jj], pack16<T>(cv));
+      bstore16_aux<C_AUX>(cr, eo[qt][jj], pack16<T>(cv));
     }
   };
   constexpr int stores_per_chunk = ((ACT == PIPE_ACT_GELU || ACT == PIPE_ACT_GELU_D) ? 4 : 2);
@@ -711,6 +759,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
   int kt = 0, rd_slot = 1;   // rd_slot: the stage whose fragments the current step reads ahead
   int pend = 0;              // DEFER: chunks of the parked tile still to drain (2 -> rows 0..15 next, 1 -> rows 16..31)
   int st1 = 0, st2 = 0;      // epilogue stores issued during the previous step and the one before
+  // CH & 2: a finished tile's arrival.  Its epilogue stores (issued in the tile's last step s) are older than the eight youngest
+  // operations the wait at the top of step s + 3 leaves outstanding (st1 = st2 = 0 there: tiles have >= 4 steps), so after that step's
+  // barrier every wave's stores of the tile have completed (sc1: written through) and one lane adds 1 to the row block's counter.
+  // (The waits themselves only get stricter by the extra operations -- polls, arrivals -- a chain phase puts into the queue.)
+  int sig_cd = 0, sig_tm = 0;
+  auto chain_signal = [&]() __attribute__((always_inline)) {
+    if (tid == 0 && cs.sig != nullptr) __hip_atomic_fetch_add(cs.sig + sig_tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   // the pinned block: MFMA i, then in its shadow fragment read i of the next step and a slice of the DMA issue (addresses after
   // MFMAs 0 and 3, the four pieces after MFMAs 1, 2, 4, 5); on a tile's last step the epilogue operand requests ride in shadow 0
   auto mma_block = [&](NtFrags<T, NB>& cur, NtFrags<T, NB>& nxt, auto MODE_) __attribute__((always_inline)) {
@@ -783,6 +839,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
     __builtin_amdgcn_s_barrier();                       // ... and everyone's
     __builtin_amdgcn_sched_barrier(0);
     st2 = st1; st1 = 0;
+    if constexpr ((CH & 2) != 0) {
+      if (sig_cd > 0 && --sig_cd == 0) chain_signal();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // (the counters are updated by value selects after the branch: symmetric "+=" in both arms gets merged into one store through a
     // selected pointer, which pins both variables in scratch memory and puts a vmcnt(0) reload at the top of every step)
     const bool last = __builtin_amdgcn_readfirstlane(kt + 1) == nkt;
@@ -812,6 +872,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
       } else {
         epi_run();
         st1 = stores_per_tile;
+        if constexpr ((CH & 2) != 0) { sig_cd = 3; sig_tm = pm0 / BM; }
       }
     } else {
       mma_block(cur, nxt, std::integral_constant<int, 0>{});
@@ -842,7 +903,26 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing no-op pieces
+  if constexpr ((CH & 2) != 0) {                      // the last tile's arrival (and, at the phase seam, every store of this workgroup is out)
+    __builtin_amdgcn_s_barrier();
+    if (sig_cd > 0) chain_signal();
+  }
 }
+
+template <typename T, bool CONV, int ACT, int NB, bool DEFER = false, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ C,
+                                                            NtEpi epi, PipeEpi pe, int M, int N, int K, int ldx, int ldc,
+                                                            ConvGeom g, int tiles_n, int ntiles, unsigned xbytes, unsigned wbytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const PipeProb pb{X, W, C, epi, pe, M, N, K, ldx, ldc, tiles_n, ntiles, xbytes, wbytes};
+  const ChainSync cs{nullptr, 0u, nullptr, nullptr};
+  const int G = (int)gridDim.x;
+  nt_pipe_body<T, CONV, ACT, NB, DEFER, DBG, 0>(pb, cs, g, smem, xcd_remap(blockIdx.x, G), G);
+}
+
+#ifdef SPG_DEV_KERNELS
+#include "dev/nt_chain_kernel.inc"
+#endif
 
 // LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS).  A template (on the pointer type) so that the device-only 16-byte form of the builtin is
 // checked only at instantiation: in a non-dependent statement hipcc's host pass fails the check silently and drops the kernel's stub.
@@ -2194,7 +2274,11 @@ static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M,
       pe.h_bytes = epi.gelu_h ? (unsigned)cb : 0u;
       pe.bias_bytes = epi.bias ? (unsigned)N * 4u : 0u;
       // tile width: columns of work (incl. the zero columns of the last tile) x per-column-tile fixed cost (X fill, prologue, epilogue)
+#ifdef SPG_V3_FORCE_NB     // (tools/ A/B builds)
+      const int nb3 = SPG_V3_FORCE_NB;
+#else
       const int nb3 = cdiv(N, 128) * 5 <= cdiv(N, 64) * 3 ? 4 : 2;
+#endif
       const int tn3 = cdiv(N, 32 * nb3);
       const int grid3 = tn3 * tiles_m;
       // Measured (tools/nt_check.py, hipGraph timing): with two workgroups on most CUs and a short K loop this kernel beats the
@@ -2498,6 +2582,9 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
                            : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget);
 }
 
+#ifdef SPG_DEV_KERNELS
+#include "dev/nt_chain_host.inc"
+#endif
 #ifdef SPG_DEV_KERNELS
 extern "C" long spg_gemm_tn_group_workspace_bytes(void) {   // covers every kernel of the family
   const long a_ = (long)num_cus() * 2 * TNW_SLOT_FLOATS * (long)sizeof(float), b_ = tn_block_workspace_bytes(num_cus());

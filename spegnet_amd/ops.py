@@ -201,6 +201,67 @@ def gemm_tn(dy: Tensor, x: Tensor, dw: Tensor, conv: Optional[tuple] = None, dbi
                   1 if conv else 0, B, H, W, Ci, cu_budget_now(), _stream())
 
 
+# ---- chained launches (DEV library only: csrc/dev/nt_chain_*.inc; a measured experiment, tools/chain_bench.py -- the product path never calls it) -----------------------------------------------------------------------
+_CHAIN_ERR = {}
+
+
+def chain_err_word(device) -> Tensor:
+    """The device word spg_nt_chain sets when a dependency wait gave up (one per device, checked by chain_check())."""
+    dev = torch.device(device)
+    t = _CHAIN_ERR.get(dev.index)
+    if t is None:
+        t = _CHAIN_ERR[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+def chain_check(device) -> None:
+    """Host-side check (synchronises): raises if any chained launch on this device reported a timed-out wait."""
+    t = _CHAIN_ERR.get(torch.device(device).index)
+    if t is not None and int(t.item()) != 0:
+        t.zero_()
+        raise RuntimeError("spg_nt_chain: a dependency wait timed out (results of that launch are wrong)")
+
+
+def gemm_chain(phases) -> list:
+    """DEV library only (SPG_LIBRARY=spegnet_amd/libspegnet_hip_dev.so).  Dependent dense GEMMs over the same M rows in ONE persistent launch (spg_nt_chain).  phases: list of dicts with keys
+    x (None = the previous phase's output), w [N,K], bias, act, residual, gelu_h, preact_out (c2), out (optional).  Returns the outputs.
+    Bit-identical to running the phases as separate gemm_nt calls on the persistent pipelined kernel."""
+    import ctypes
+    n = len(phases)
+    assert 1 <= n <= _lib.CHAIN_MAX_PHASES
+    arr = (_lib.ChainPhase * n)()
+    outs, keep = [], []
+    x0 = phases[0]["x"]
+    M = x0.numel() // x0.shape[-1]
+    flops = 0.0
+    for i, ph in enumerate(phases):
+        x = ph.get("x")
+        dep = x is None
+        if dep:
+            assert i > 0
+            x = outs[-1]
+        w = ph["w"]
+        N, K = w.shape
+        assert x.numel() == M * K and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16, (x.shape, w.shape)
+        out = ph.get("out")
+        if out is None:
+            out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        q = arr[i]
+        q.kind, q.act, q.depends, q.M, q.N, q.K = _lib.CHAIN_GEMM, int(ph.get("act", ACT_NONE)), 1 if dep else 0, M, N, K
+        q.x, q.w, q.c, q.c2 = _p(_c(x)), _p(_c(w)), _p(_c(out)), _p(ph.get("preact_out"))
+        q.bias, q.residual, q.gelu_h = _p(ph.get("bias")), _p(ph.get("residual")), _p(ph.get("gelu_h"))
+        outs.append(out)
+        keep.append((x, w, out))
+        flops += 2.0 * M * N * K
+    lib = _lib.load()
+    words = lib.spg_nt_chain_counter_words(n, ctypes.cast(arr, ctypes.c_void_p))
+    cnt = zeros_f32((words,), x0.device)          # (from the step's zero pool when one is open: one fill per step)
+    with _prof("gemm_nt<bf16,dense>", "mfma", flops):
+        _lib.call("spg_nt_chain", SPG_BF16, n, ctypes.cast(arr, ctypes.c_void_p), cnt.data_ptr(), words, chain_err_word(x0.device).data_ptr(),
+                  cu_budget_now(), _stream())
+    return outs
+
+
 # CUs the persistent GEMM grids are sized for (0 = all): a per-call argument of the C ABI; this thread-local only carries the caller's
 # choice (the multi-GPU trainer lowers it around the graph segments that run beside a collective) down to the calls made inside it.
 import contextlib
