@@ -247,14 +247,16 @@ def test_train_backward_bf16_gradients_close_to_oracle():
     assert rs[len(rs) // 2] < 0.6 and rs[-1] < 0.9, rep
 
 
-def test_trunk_backward_bf16_per_parameter_matches_fp32_oracle():
-    """Well-conditioned check of the bf16 backward kernels composed at Hiera-L shapes (gemm_nt v3 / pipe with the saved GELU derivative,
+@pytest.mark.parametrize("B,S", [(4, 128), (1, 768)])
+def test_trunk_backward_bf16_per_parameter_matches_fp32_oracle(B, S):
+    """(B = 1 @768: config #5's resolution -- 2304-token global attention, 48 x 48 / 24 x 24 stage-3 / stage-4 maps with their padded
+    windows -- in the bf16 BACKWARD, ~40 s of CPU oracle.)
+    Well-conditioned check of the bf16 backward kernels composed at Hiera-L shapes (gemm_nt v3 / pipe with the saved GELU derivative,
     grouped wgrad, resident / tiled attention backward, LayerNorm backward, pooling, position embeddings): the trunk alone -- LayerNorm
     only, no train-mode BatchNorm over a handful of samples -- driven by fixed upstream gradients on its four stage maps, against the
     fp32 CPU oracle's gradients PER PARAMETER.  A wrong kernel moves the parameters downstream of it far outside these bounds; the
     five worst parameters are printed."""
     m, sd, cfg = make_model("large", "bf16", train=True)
-    B, S = 4, 128
     g = torch.Generator().manual_seed(41)
     x = torch.randn(B, 3, S, S, generator=g)
     eng = m.engine
@@ -435,6 +437,35 @@ def test_deferred_block_wgrads_equal_per_block_wgrads():
     assert worst[1] < 2e-5, worst
 
 
+def _grad_report(m, g_ref, tag, med_cos, p05_cos, group_tol, group_cos=0.9):
+    """bf16 gradients of a whole train step against the fp32 oracle's: per-parameter cosine (median / 5th percentile), and the gradient
+    NORM of every parameter group (head modules; trunk blocks in runs of six) within group_tol -- a wrong kernel at one size class
+    (the 768 px windows, a PED stage) shows up as its group's norm or cosine, whatever the rest of the model does."""
+    import re
+    P = dict(m.named_parameters())
+    gmax = max(float(v.abs().max()) for v in g_ref.values())
+    cos, groups = [], {}
+    for k, r in g_ref.items():
+        a_, b_ = P[k].grad.detach().cpu().double().flatten(), r.double().flatten()
+        mm = re.search(r"blocks\.(\d+)\.", k)
+        gname = f"trunk blocks {6 * (int(mm.group(1)) // 6)}-{6 * (int(mm.group(1)) // 6) + 5}" if mm else (k.split(".")[0] + "." + k.split(".")[1] if not k.startswith("encoder") else "trunk embeddings")
+        gg = groups.setdefault(gname, [0.0, 0.0, 0.0])
+        gg[0] += float(a_.dot(a_)); gg[1] += float(b_.dot(b_)); gg[2] += float(a_.dot(b_))
+        if float(r.abs().max()) >= 1e-3 * gmax:
+            cos.append(float(torch.dot(a_, b_) / (a_.norm() * b_.norm()).clamp_min(1e-30)))
+    cos.sort()
+    print(f"{tag}: {len(cos)} parameters, cosine min {cos[0]:.4f} p05 {cos[int(0.05 * len(cos))]:.4f} median {cos[len(cos) // 2]:.4f}")
+    worst = None
+    for gname, (aa, bb, ab) in sorted(groups.items()):
+        ratio, c = (aa / bb) ** 0.5, ab / (aa * bb) ** 0.5
+        print(f"  {gname:28s} |g| ratio {ratio:.3f}  cosine {c:.4f}")
+        if worst is None or abs(ratio - 1) > abs(worst[1] - 1):
+            worst = (gname, ratio, c)
+    assert cos[len(cos) // 2] > med_cos and cos[int(0.05 * len(cos))] > p05_cos, (tag, cos[len(cos) // 2], cos[int(0.05 * len(cos))])
+    for gname, (aa, bb, ab) in groups.items():
+        assert abs((aa / bb) ** 0.5 - 1) < group_tol and ab / (aa * bb) ** 0.5 > group_cos, (tag, gname, (aa / bb) ** 0.5, ab / (aa * bb) ** 0.5)
+
+
 def test_config2_train_step_matches_oracle():
     """BASELINE config #2 at full size: batch 8 @384x384, bf16, hipGraph-captured step (what bench.py times).  Loss and global gradient
     norm of the first step against the fp32 CPU oracle on the same batch and weights (the oracle step takes ~30 s of CPU)."""
@@ -449,7 +480,7 @@ def test_config2_train_step_matches_oracle():
     step = TrainStep(m, crit, arena, grad_clip=1.0, capture=True)
     x, masks, edges = O.synthetic_batch(8, 384, seed=70)
     osd = {k: v.clone() for k, v in sd.items()}
-    ref_l, ref_norm, _ = O.train_step(osd, {}, x, masks, edges, base_lr=1e-4, wd=1e-5, enc_ratio=0.05, clip=1.0, cfg=cfg)
+    ref_l, ref_norm, ref_grads = O.train_step(osd, {}, x, masks, edges, base_lr=1e-4, wd=1e-5, enc_ratio=0.05, clip=1.0, cfg=cfg)
     got = step(x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda())
     torch.cuda.synchronize()
     loss, gn = float(got["loss"]), float(arena.gnorm_sq.sqrt())
@@ -461,6 +492,15 @@ def test_config2_train_step_matches_oracle():
     x2, m2, e2 = O.synthetic_batch(8, 384, seed=71)
     l2 = float(step(x2.cuda(), torch.stack(m2).cuda(), torch.stack(e2).cuda())["loss"])
     assert l2 == l2
+    # the gradients themselves at this size (the captured step clears them): an eager forward + backward of a fresh model on the same
+    # batch, per parameter and per parameter group against the oracle's
+    m2_, _, _ = make_model("large", "bf16", seed=3, train=True)
+    _train_once(m2_, crit, x.cuda(), torch.stack(masks).cuda(), torch.stack(edges).cuda())
+    _grad_report(m2_, dict(zip([k for k in sd if not O.is_buffer_key(k)], ref_grads)), "config #2 (B = 8 @384)", med_cos=0.78, p05_cos=0.70, group_tol=0.2, group_cos=0.75)
+    # (measured: everything downstream of the e-ASPP global branch -- decoder, EFE, context.expand / fusion / branches -- cosine 0.95-1.00 and
+    # norm ratio 0.96-1.01; the global branch itself, whose train-mode BatchNorm normalises over the B = 8 per-image means, 0.79 / 0.82, and
+    # everything upstream of it (CFI fusion, the whole trunk) inherits cosine 0.81-0.85 / ratio 0.87-0.90: the model's conditioning at
+    # random initialisation, DESIGN.md 4, not a kernel's -- the well-conditioned per-parameter checks are the trunk-only and head-only tests)
 
 
 @pytest.mark.parametrize("capture", [False, True])
