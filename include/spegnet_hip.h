@@ -35,7 +35,7 @@ enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
 
 /* ABI revision: bumped with every change of an exported signature.  Bindings must compare spg_version() with the SPG_ABI_VERSION they
  * were written against and refuse to run on a mismatch (spegnet_amd/_lib.py does).  300 = round 3. */
-#define SPG_ABI_VERSION 305
+#define SPG_ABI_VERSION 306
 int spg_version(void);
 const char* spg_last_error(void);
 
@@ -82,9 +82,13 @@ long spg_gemm_tn_group_workspace_bytes(void);
  * it can defer the wgrads of consecutive trunk blocks until their blocks fill whole rounds (stage 3 of Hiera-L: 84 blocks per trunk
  * block, three trunk blocks = 252 per launch; stage 4: 330 per trunk block, three = 990 = 3.87 rounds of 256).  Same reference op as spg_gemm_tn_group: autograd of the nn.Linear layers of sam2's MultiScaleBlock
  * (models/feature_encoding.py:236).  The caller keeps every dY / X alive until the launch.                                           */
+/* overwrite != 0: dW is STORED, not added to (valid when it holds zeros -- the start of a step -- and no other launch of the step writes
+ * it): the exit skips the cold read of the old values; dbias is always added to.  sq_part != NULL: f32 [spg_gemm_tn_blocks_count()] -- element i receives
+ * the sum of squares of everything block i's owner wrote (the final gradient values of that block, bias sums included), so the optimizer's
+ * global-norm clip (engine/trainer.py:404-406, clip_grad_norm_) need not read these gradients again: spg_sumsq_fold.                    */
 int spg_gemm_tn_blocks(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias,
-                       int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, int cu_budget,
-                       spg_stream_t stream);
+                       int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, int overwrite, float* sq_part,
+                       int cu_budget, spg_stream_t stream);
 long spg_gemm_tn_blocks_count(int njobs, int M, const int* N, const int* K);
 int spg_num_cus(int cu_budget);   /* CUs the persistent grids are sized for under this budget (0 = all) */
 /* ---- weight packing (per optimizer step): f32 master -> T copies -----------------------------------
@@ -357,6 +361,13 @@ int spg_loss_grad(int dtype, const void* pred, const float* target, const float*
  * scheduler can change them without re-capturing a hipGraph).  Every parameter starts on a 256-element boundary.
  * zero_grad != 0 clears g after use (the next step's kernels accumulate into it), saving a separate memset pass.      */
 int spg_sumsq(const float* x, float* out, long n, float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream);
+/* The same norm when spg_gemm_tn_blocks has already produced the sums of squares of the gradients it wrote: out[0] = sum of squares over
+ * `chunks` -- a DEVICE array of nchunks records struct { long off; int n4; int pad; } (16 bytes): n4 <= 4096 groups of four floats at
+ * x + off, disjoint, together the gradients NOT covered by the extras -- plus the sums of the nextras (<= 32) arrays extra_ptr[i][0 .. extra_n[i])
+ * (HOST arrays of device pointers / lengths: the sq_part outputs of the step's spg_gemm_tn_blocks launches).  Fixed summation order:
+ * deterministic.  red_ws: >= nchunks floats.                                                                                          */
+int spg_sumsq_fold(const float* x, const void* chunks, int nchunks, int nextras, const float* const* extra_ptr, const int* extra_n,
+                   float* out, float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream);
 int spg_adamw(float* p, float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,
               const float* wd, const float* gnorm_sq, float* step_f, float clip, float beta1, float beta2, float eps,
               float grad_scale, int zero_grad, long n, spg_stream_t stream);

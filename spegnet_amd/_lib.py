@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPG_LIBRARY") or os.path.join(_HERE, "libspegnet_hip.so")
 
 SPG_F32, SPG_BF16 = 0, 1
-ABI_VERSION = 305   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
+ABI_VERSION = 306   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 ACT_GELU_SAVE_GRAD, ACT_MUL_H = 3, 4   # bf16: C2 = gelu'(pre) saved by the forward GEMM | C = acc * gelu_h in the backward GEMM
 
@@ -26,7 +26,7 @@ SIGNATURES = {
     "spg_gemm_tn": "ipppppliiiiiiiiiiiip",
     "spg_gemm_tn_group": "ii" "pppp" "i" "ppppp" "plp" "i" "p",
     "spg_gemm_tn_group_reduce_batch": "ippp",
-    "spg_gemm_tn_blocks": "ii" "pppp" "i" "ppppp" "i" "p",
+    "spg_gemm_tn_blocks": "ii" "pppp" "i" "ppppp" "ip" "i" "p",
     "spg_pack_matrix": "ippiiip",
     "spg_pack_batch": "ipiip",
     "spg_pack_conv3x3": "ipppiip",
@@ -88,6 +88,7 @@ SIGNATURES = {
     "spg_loss_finalize": "pppp" "iiffffffp",
     "spg_loss_grad": "ippppppp" "iiiiifffff" "pp",
     "spg_sumsq": "pp" "l" "plp" "p",
+    "spg_sumsq_fold": "ppii" "pp" "p" "plp" "p",
     "spg_adamw": "ppppppppp" "fffff" "ilp",
     "spg_adamw_pack": "i" "ppppppppp" "fffff" "i" "pii" "p",
 }

@@ -67,7 +67,7 @@ int launch_conv3x3_halo(const void* X, const void* Wp, void* C, const float* bia
 // tn_block.hip: the weight gradients of several trunk blocks as whole 256 x 192 blocks of dW, one per workgroup, added straight into dW
 // (every N, K a multiple of 192, at most `cus` blocks); 1 = outside the domain.  tn_blocks_count: blocks a problem set makes (-1: outside)
 int launch_tn_blocks_direct(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
-                            const int* K, const int* ldy, const int* ldx, const int* ldw, int cus, hipStream_t s);
+                            const int* K, const int* ldy, const int* ldx, const int* ldw, int cus, hipStream_t s, int overwrite, float* sq_part);
 long tn_blocks_count(int njobs, int M, const int* N, const int* K);
 #ifdef SPG_DEV_KERNELS
 // nt_wide.hip (dev builds): dense bf16 NT GEMM on 192-column tiles of variable height (act = PIPE_ACT_* code); returns 1 when the problem is outside its domain
@@ -2729,11 +2729,12 @@ extern "C" long spg_gemm_tn_blocks_count(int njobs, int M, const int* N, const i
 extern "C" int spg_num_cus(int cu_budget) { return num_cus(cu_budget); }
 
 extern "C" int spg_gemm_tn_blocks(int dtype, int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias,
-                                  int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, int cu_budget,
-                                  spg_stream_t stream) {
+                                  int M, const int* N, const int* K, const int* ldy, const int* ldx, const int* ldw, int overwrite,
+                                  float* sq_part, int cu_budget, spg_stream_t stream) {
   SPG_REQUIRE(dtype == SPG_BF16, "gemm_tn_blocks: bf16 only (dtype %d)", dtype);
   SPG_REQUIRE(M > 0 && njobs >= 1, "gemm_tn_blocks: empty problem set");
-  const int rc = launch_tn_blocks_direct(njobs, dY, X, dW, dbias, M, N, K, ldy, ldx, ldw, num_cus(cu_budget), (hipStream_t)stream);
+  const int rc = launch_tn_blocks_direct(njobs, dY, X, dW, dbias, M, N, K, ldy, ldx, ldw, num_cus(cu_budget), (hipStream_t)stream, overwrite != 0,
+                                         sq_part);
   SPG_REQUIRE(rc != 1, "gemm_tn_blocks: outside the kernel's domain (1..16 problems, M >= 256, every N and K a multiple of 192, leading "
                        "dimensions multiples of 8 (ldw: 4): ask spg_gemm_tn_blocks_count first)");
   return rc;

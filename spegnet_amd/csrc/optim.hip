@@ -31,6 +31,42 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   }
 }
 
+// Global gradient norm when part of the gradients' sums of squares already exists: out[0] = sum over `chunks` (disjoint ranges of x, each
+// <= 16384 floats, a multiple of 4, one workgroup each) + sum over the `extras` arrays (per-block sums written by spg_gemm_tn_blocks'
+// owners), all in a fixed order: per-chunk partials and every extra array are summed by the workgroup that arrives last, thread t
+// taking elements t, t + 256, ... of the concatenated list, then the 256 sums in index order.  Deterministic.
+struct SqChunk { long off; int n4; int pad; };
+constexpr int SQ_MAX_EXTRAS = 32;
+struct SqExtras { const float* ptr[SQ_MAX_EXTRAS]; int n[SQ_MAX_EXTRAS]; int count; };
+
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* __restrict__ x, const SqChunk* __restrict__ chunks, SqExtras ex,
+                                                         float* __restrict__ out, float* __restrict__ part, unsigned* __restrict__ counter) {
+  const SqChunk c = chunks[blockIdx.x];
+  const float* p = x + c.off;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < c.n4; i += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + i * 4L);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  __shared__ float red[4];
+  __shared__ float scratch[256];
+  __shared__ unsigned s_last;
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) st_part(part + blockIdx.x, s);
+  if (!arrive_last(counter, gridDim.x, &s_last)) return;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += part[i];
+  for (int e = 0; e < ex.count; ++e)
+    for (int i = threadIdx.x; i < ex.n[e]; i += 256) t += ex.ptr[e][i];
+  scratch[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 256; ++i) tot += scratch[i];
+    out[0] = tot;
+  }
+}
+
 // One AdamW element update with the arithmetic pinned (explicit fused / unfused operations, so the plain and the fused-pack kernel
 // -- and any future variant -- produce bit-identical parameters whatever the compiler's contraction choices around the call).
 struct AdamC { float coef, b1, b2, eps, bc1, bc2s; };
@@ -256,6 +292,20 @@ extern "C" int spg_sumsq(const float* x, float* out, long n, float* red_ws, long
   if (g < 1) g = 1;
   hipLaunchKernelGGL(sumsq_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, out, n / 4, red_ws, red_counter);
   return check_launch("sumsq");
+}
+
+extern "C" int spg_sumsq_fold(const float* x, const void* chunks, int nchunks, int nextras, const float* const* extra_ptr, const int* extra_n,
+                              float* out, float* red_ws, long red_ws_floats, unsigned* red_counter, spg_stream_t stream) {
+  SPG_REQUIRE(x && chunks && nchunks >= 1 && out, "sumsq_fold: needs at least one chunk of the gradient arena");
+  SPG_REQUIRE(nextras >= 0 && nextras <= SQ_MAX_EXTRAS && (nextras == 0 || (extra_ptr && extra_n)), "sumsq_fold: 0..%d extra arrays, got %d", SQ_MAX_EXTRAS, nextras);
+  SPG_REQUIRE(red_ws && red_counter && red_ws_floats >= nchunks, "sumsq_fold: needs %d floats of scratch and one zeroed counter", nchunks);
+  static_assert(sizeof(SqChunk) == 16, "SqChunk layout is part of the ABI");
+  SqExtras ex;
+  ex.count = nextras;
+  for (int i = 0; i < SQ_MAX_EXTRAS; ++i) { ex.ptr[i] = i < nextras ? extra_ptr[i] : nullptr; ex.n[i] = i < nextras ? extra_n[i] : 0; }
+  for (int i = 0; i < nextras; ++i) SPG_REQUIRE(ex.ptr[i] && ex.n[i] > 0, "sumsq_fold: extra array %d is empty", i);
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, x, (const SqChunk*)chunks, ex, out, red_ws, red_counter);
+  return check_launch("sumsq_fold");
 }
 
 extern "C" int spg_adamw(float* p, float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,

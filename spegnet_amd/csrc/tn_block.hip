@@ -81,12 +81,19 @@ struct TbJob {
 struct TbGroup {
   TbJob job[TB_MAX_JOBS];
   int njobs, M, T, NB, S;    // T = 32-row slices of M, NB blocks in all, S splits of M per block
+  // DIRECT form only.  overwrite: dW holds nothing worth keeping (the caller's gradients are zero at the start of a step and every block is
+  // written exactly once): the block is stored, not added -- no cold read of the old values at the exit.  dbias is always added to (128 to
+  // 256 floats per block; the qkv bias also receives the attention backward's padded-key gradient earlier in the step).  sq_part (or null): one
+  // float per block = the sum of squares of everything the block's owner wrote (the FINAL gradient values, bias sums included), so that
+  // the optimizer's global-norm clip need not read these gradients again (spg_sumsq_fold adds the partials in block order).
+  int overwrite;
+  float* sq_part;
 };
 
 // DIRECT: the workgroup owns the block over all of M (S == 1) and adds into dW / dbias itself; otherwise its partial block goes to `slab`
 template <bool WIDE_N, bool DIRECT>
 __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int ta, int tb, int split, char* smem, float* __restrict__ slab,
-                                        float* __restrict__ bslab, bool bias_blk) {
+                                        float* __restrict__ bslab, bool bias_blk, float* __restrict__ sq_out = nullptr) {
   constexpr int KA = WIDE_N ? 6 : 4;           // k blocks (16) per wave
   constexpr int NBk = WIDE_N ? 4 : 6;          // n blocks per wave
   constexpr int NYS = WIDE_N ? 4 : 3;          // dY sub-tiles of a slice (X: 7 - NYS)
@@ -269,6 +276,8 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
     constexpr int NV = (NE / 2) * VR / 512;        // pieces per thread and half (12)
     static_assert((NE / 2) * RS * 4 <= TB_LDS_BYTES && (NE / 2) * VR % (512 * 6) == 0, "half a block fits the ring");
     float* stage = reinterpret_cast<float*>(smem);
+    const bool keep_old = g.overwrite == 0;
+    float ssq = 0.f;                               // sum of squares of the values this thread stores
     const int myhalf = WIDE_N ? (wn >> 1) : wn;
     const int nloc = (WIDE_N ? (wn & 1) * (NBk * 16) : 0) + (lane & 15);    // this lane's row inside its half, for nb = 0
     __syncthreads();                               // every wave's LDS-DMA has landed (vmcnt(0) above) and every fragment read is done
@@ -298,7 +307,7 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
         for (int i = 0; i < CH; ++i) {
           int row, c4;
           const float* d = piece(c + i, row, c4);
-          old[i] = d ? *reinterpret_cast<const f32x4*>(d) : f32x4{0.f, 0.f, 0.f, 0.f};
+          old[i] = (d && keep_old) ? *reinterpret_cast<const f32x4*>(d) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -306,7 +315,11 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
           int row, c4;
           float* d = piece(c + i, row, c4);
           const f32x4 part = *reinterpret_cast<const f32x4*>(stage + row * RS + c4 * 4);
-          if (d) *reinterpret_cast<f32x4*>(d) = old[i] + part;
+          if (d) {
+            const f32x4 v = old[i] + part;
+            *reinterpret_cast<f32x4*>(d) = v;
+            ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+          }
         }
       }
       if (h == 0) __syncthreads();                 // the second half overwrites the staged rows
@@ -318,7 +331,23 @@ __device__ __forceinline__ void tb_body(const TbGroup& g, const TbJob& jb, int t
         b += __shfl_xor(b, 16, 64);
         b += __shfl_xor(b, 32, 64);
         const int n = n0 + wn * (NBk * 16) + nb * 16 + (lane & 15);
-        if (q == 0 && n < jb.N) jb.dbias[n] += b;
+        if (q == 0 && n < jb.N) {
+          const float v = jb.dbias[n] + b;          // (always added: the qkv bias also receives the attention backward's padded-key gradient)
+          jb.dbias[n] = v;
+          ssq += v * v;
+        }
+      }
+    }
+    if (sq_out) {                                  // (wave-uniform) the block's sum of squares, summed in a fixed order
+      __syncthreads();                             // every thread is done with the staged rows
+      ssq = wave_sum(ssq);
+      if (lane == 0) stage[wave] = ssq;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += stage[i];
+        *sq_out = t;
       }
     }
   } else {
@@ -603,8 +632,9 @@ __global__ __launch_bounds__(512) void tn_block_direct_kernel(TbGroup g) {
     if (jb.wide_n) tb_body32<true>(g, jb, ta, tb, smem, bias_blk);
     else tb_body32<false>(g, jb, ta, tb, smem, bias_blk);
 #else
-    if (jb.wide_n) tb_body<true, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
-    else tb_body<false, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk);
+    float* sq_out = g.sq_part ? g.sq_part + blk : nullptr;
+    if (jb.wide_n) tb_body<true, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk, sq_out);
+    else tb_body<false, true>(g, jb, ta, tb, 0, smem, nullptr, nullptr, bias_blk, sq_out);
 #endif
     __syncthreads();          // every wave has left the ring before the next block's prologue refills it
   }
@@ -694,11 +724,15 @@ long tn_blocks_count(int njobs, int M, const int* N, const int* K) {
 // DIRECT form; returns SPG_OK / an error, or 1 when the problem set is outside the domain.  More blocks than `cus`: several per workgroup,
 // one after the other (the caller sizes its sets so that the rounds are full: models/engine.py)
 int launch_tn_blocks_direct(int njobs, const void* const* dY, const void* const* X, float* const* dW, float* const* dbias, int M, const int* N,
-                            const int* K, const int* ldy, const int* ldx, const int* ldw, int cus, hipStream_t s) {
+                            const int* K, const int* ldy, const int* ldx, const int* ldw, int cus, hipStream_t s, int overwrite, float* sq_part) {
   TbGroup g;
   const long nb = tb_plan(g, njobs, dY, X, dW, dbias, M, N, K, ldy, ldx, ldw);
   if (nb < 1) return 1;
   g.njobs = njobs; g.M = M; g.T = cdiv(M, 32); g.NB = (int)nb; g.S = 1;
+  g.overwrite = overwrite; g.sq_part = sq_part;
+#if TB_MFMA32
+  if (overwrite || sq_part) return 1;     // (the 32 x 32 x 16 A/B body keeps the plain exit)
+#endif
   static bool attr_ = false;
   if (!attr_) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tn_block_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES);
@@ -721,6 +755,7 @@ int launch_tn_block_group(int njobs, const void* const* dY, const void* const* X
   if (S > T / 16) S = T / 16;                   // at least 16 slices per workgroup
   if (S < 1) return 1;
   g.njobs = njobs; g.M = M; g.T = T; g.NB = (int)nb; g.S = S;
+  g.overwrite = 0; g.sq_part = nullptr;
   const long need = nb * S * (long)(TB_SLAB_FLOATS + 256) * 4L;
   if (!workspace || workspace_bytes < need) return 1;
   float* slabs = (float*)workspace;

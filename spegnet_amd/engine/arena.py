@@ -96,9 +96,35 @@ class Arena:
             self.g.zero_()
         self._clean = False
 
-    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, packer=None):
+    def _fold_plan(self, cover):
+        """Chunk table (device) of the gradient arena MINUS the tensors in `cover` (views of self.g written by spg_gemm_tn_blocks launches
+        that also produced their sums of squares): records struct { long off; int n4; int pad; }, <= 16384 floats each.  Cached per set."""
+        import struct
+        base = self.g.data_ptr()
+        rng = sorted(((t.data_ptr() - base) // 4, t.numel()) for t in cover)
+        key = tuple(rng)
+        if getattr(self, "_fold_key", None) == key:
+            return self._fold_blob, self._fold_n
+        recs, pos = [], 0
+        for off, n in rng + [(self.size, 0)]:
+            if off < pos or off % 4 or n % 4:
+                raise RuntimeError("fold plan: covered gradient ranges overlap or are not 16-byte aligned")
+            a = pos
+            while a < off:                       # the uncovered stretch [pos, off), in chunks of <= 16384 floats
+                m = min(16384, off - a)
+                recs.append(struct.pack("<qii", a, m // 4, 0))
+                a += m
+            pos = off + n
+        if not recs:
+            recs.append(struct.pack("<qii", 0, 0, 0))
+        self._fold_blob = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(self.p.device)
+        self._fold_key, self._fold_n = key, len(recs)
+        return self._fold_blob, self._fold_n
+
+    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, packer=None, fold=None):
         """Global-norm clip + AdamW.  packer (the model's Engine): the update kernel also writes the compute-dtype weight copies of the
-        next forward (spg_adamw_pack) instead of leaving them to a separate re-pack pass."""
+        next forward (spg_adamw_pack) instead of leaving them to a separate re-pack pass.  fold = (sums of squares, covered gradient
+        tensors) from Engine.take_sq(): the norm pass then reads only the uncovered gradients (spg_sumsq_fold)."""
         if self.m is None:
             self.m = torch.zeros_like(self.p)
             self.v = torch.zeros_like(self.p)
@@ -110,8 +136,19 @@ class Arena:
         # algorithmic bytes: sumsq reads g; adamw reads p, g, m, v and writes p, m, v, g (cleared) (+ the two compute-dtype copies)
         with ops._prof("sumsq + adamw_pack (clip + AdamW + weight re-pack)" if packer is not None else "sumsq + adamw", "hbm",
                        self.size * (4 + 32 + (2 * es if packer is not None else 0))):
-            _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, self._red_ws.data_ptr(), 2048,
-                      ops.red_counters(self.p.device, 1), s)
+            if fold is not None and fold[0] and len(fold[0]) <= 32:
+                import ctypes
+                blob, nchunks = self._fold_plan(fold[1])
+                if self._red_ws.numel() < nchunks:
+                    self._red_ws = torch.empty(max(nchunks, 2048), dtype=torch.float32, device=self.p.device)
+                ne = len(fold[0])
+                EP, EI = ctypes.c_void_p * ne, ctypes.c_int * ne
+                _lib.call("spg_sumsq_fold", self.g.data_ptr(), blob.data_ptr(), nchunks, ne, EP(*[t.data_ptr() for t in fold[0]]),
+                          EI(*[t.numel() for t in fold[0]]), self.gnorm_sq.data_ptr(), self._red_ws.data_ptr(), self._red_ws.numel(),
+                          ops.red_counters(self.p.device, 1), s)
+            else:
+                _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, self._red_ws.data_ptr(), 2048,
+                          ops.red_counters(self.p.device, 1), s)
             if packer is not None:
                 blob, njobs, items = packer.opt_jobs(self)
                 dt = _lib.SPG_BF16 if packer.dtype == torch.bfloat16 else _lib.SPG_F32

@@ -54,6 +54,7 @@ class TrainStep:
         self.static = None
         self.losses = None
         self.world = sync.world if sync is not None else 1
+        self.fold_sumsq = os.environ.get("SPG_FOLD_SUMSQ", "1") != "0"     # (A/B runs: tools/ab_env.sh)
         # forked weight-gradient stream (models/engine.py; `TrainStep(..., wgrad_async=True)` for A/B runs): measured SLOWER on one MI355X
         # (226.0 vs 232.2 img/s on the B=8@384 graph step) -- both branches are chip-sized persistent kernels, so they contend
         model.engine.wgrad_async = ((sync is None) or capture) and bool(wgrad_async)
@@ -66,6 +67,10 @@ class TrainStep:
     def _fwd_bwd(self, images, masks, edges):
         ops.begin_zero_pool(images.device)   # one fill for the step's zero-initialised scratch (ops.zeros_f32)
         self.arena.zero_grad()
+        # single GPU: the gradients are zero here and the norm is taken right after the backward, so the whole-block weight-gradient
+        # launches may store instead of add and hand their sums of squares to the clip (models/engine.py: fold_sumsq).  With a GradSync
+        # the norm is that of the all-reduced gradients: no fold.
+        self.model.engine.fold_sumsq = self.sync is None and self.fold_sumsq
         out = self.model(images)
         losses = self.criterion.forward_batched(out['predictions'], out['edge'], masks, edges)
         losses['loss'].backward()
@@ -73,7 +78,10 @@ class TrainStep:
 
     def _opt(self, scale: float):
         # AdamW writes the compute-dtype weight copies of the next forward itself (spg_adamw_pack): no separate re-pack pass
-        self.arena.step(self.clip, grad_scale=scale, packer=self.model._engine)
+        eng = self.model._engine
+        fold = eng.take_sq() if eng.fold_sumsq else None
+        eng.fold_sumsq = False
+        self.arena.step(self.clip, grad_scale=scale, packer=eng, fold=fold)
 
     def _eager(self, images, masks, edges):
         losses = self._fwd_bwd(images, masks, edges)

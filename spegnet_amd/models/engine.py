@@ -56,6 +56,12 @@ class Engine:
         # referenced by the pending list until then.  Not used while a per-unit gradient callback needs finished ranges mid-backward.
         self.block_wgrads = os.environ.get("SPG_BLOCK_WGRADS", "1") != "0"
         self._wg_pending = {}       # M -> [(jobs of one trunk block with that row count, their block count)]
+        # Inside a single-GPU TrainStep (gradients are zero when the backward starts, the clip's norm is taken right after it): the
+        # whole-block launches STORE their blocks instead of adding (no cold read of the old values at the exit) and leave the sum of
+        # squares of what they wrote, so that the optimizer's global-norm pass reads only the gradients no such launch covered
+        # (Arena.step(fold=...), spg_sumsq_fold).  Set and cleared by TrainStep around each step; never on for plain autograd use.
+        self.fold_sumsq = False
+        self._sq_parts, self._sq_cover = [], []
         self.batch_ln_params = True  # trunk: LayerNorm dgamma / dbeta in batched launches
         self._ln_jobs = []
         self._tn_defer = []
@@ -319,10 +325,21 @@ class Engine:
         if not pend:
             return
         if self._round_fill(sum(c for _, c in pend), ops.num_cus()) >= 0.75:
-            ops.gemm_tn_blocks([j for jobs, _ in pend for j in jobs])
+            jobs = [j for jobs, _ in pend for j in jobs]
+            if self.fold_sumsq:
+                self._sq_parts.append(ops.gemm_tn_blocks(jobs, overwrite=True, want_sq=True))
+                self._sq_cover.extend(t for j in jobs for t in (j[2], j[3]) if t is not None)
+            else:
+                ops.gemm_tn_blocks(jobs)
         else:
             for jobs, _ in pend:
                 self._issue_block_wgrads(jobs)
+
+    def take_sq(self):
+        """(per-launch sums of squares, the gradient tensors they cover) of this backward's whole-block launches; empties the record."""
+        r = (self._sq_parts, self._sq_cover)
+        self._sq_parts, self._sq_cover = [], []
+        return r
 
     def flush_block_wgrads(self) -> None:
         for M in list(self._wg_pending.keys()):
@@ -484,6 +501,7 @@ class Engine:
         self._bw = dict(ctx=ctx, dfeats=dfeats, dx=None, stage=len(dfeats) - 1, unit=0)
         # (a backward that raised half-way must not leave its deferred weight gradients / LayerNorm jobs / slab reduces to the next one)
         self._wg_pending, self._tn_defer, self._ln_jobs = {}, [], []
+        self._sq_parts, self._sq_cover = [], []
         if self.unit_cb is not None:
             self.unit_cb(0)   # head gradients are final once trunk backward starts
 

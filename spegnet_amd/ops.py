@@ -370,19 +370,22 @@ def conv3x3_wgrad_direct(dy: Tensor, x: Tensor, gw: Tensor, dbias: Optional[Tens
     return True
 
 
-def gemm_tn_blocks(jobs) -> None:
+def gemm_tn_blocks(jobs, overwrite: bool = False, want_sq: bool = False) -> Optional[Tensor]:
     """The weight gradients of several trunk blocks in ONE launch: every workgroup owns a whole 256 x 192 block of some dw over all of M and
     adds it straight into dw / dbias (no slabs, no reduce kernel, deterministic).  jobs as in gemm_tn_group with tn_blocks_count(jobs) >= 1;
-    more blocks than num_cus() run in rounds."""
+    more blocks than num_cus() run in rounds.  overwrite: dw is stored, not added to (it holds zeros and nothing else writes it this step; dbias is always
+    added to).  want_sq: returns f32 [blocks], the sum of squares of what each block's owner wrote (for spg_sumsq_fold)."""
     import ctypes
     n = len(jobs)
     M = jobs[0][0].numel() // jobs[0][0].shape[-1]
     P, I = ctypes.c_void_p * n, ctypes.c_int * n
     Ns, Ks = I(*[j[0].shape[-1] for j in jobs]), I(*[j[1].shape[-1] for j in jobs])
+    sq = torch.empty(tn_blocks_count(jobs), dtype=torch.float32, device=jobs[0][0].device) if want_sq else None
     with _prof("gemm_tn_blocks<bf16> (wgrads of several trunk blocks, whole 256x192 blocks)", "mfma",
                sum(2.0 * M * j[0].shape[-1] * j[1].shape[-1] for j in jobs)):
         _lib.call("spg_gemm_tn_blocks", SPG_BF16, n, P(*[_p(j[0]) for j in jobs]), P(*[_p(j[1]) for j in jobs]), P(*[_p(j[2]) for j in jobs]),
-                  P(*[_p(j[3]) for j in jobs]), M, Ns, Ks, Ns, Ks, Ks, cu_budget_now(), _stream())
+                  P(*[_p(j[3]) for j in jobs]), M, Ns, Ks, Ns, Ks, Ks, 1 if overwrite else 0, _p(sq), cu_budget_now(), _stream())
+    return sq
 
 
 def gemm_tn_group_reduce(deferred: list) -> None:

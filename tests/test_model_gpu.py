@@ -503,6 +503,66 @@ def test_config2_train_step_matches_oracle():
     # random initialisation, DESIGN.md 4, not a kernel's -- the well-conditioned per-parameter checks are the trunk-only and head-only tests)
 
 
+def test_folded_gradient_norm_equals_plain_step():
+    """Single-GPU TrainStep: the whole-block weight-gradient launches store their blocks (overwrite) and hand their sums of squares to the
+    clip (spg_sumsq_fold reads only the uncovered gradients).  Hiera-L bf16 at B = 2 @384 (stage 3: M = 1152 rows, three trunk blocks per
+    spg_gemm_tn_blocks launch).  (i) Step 1 of two identical models, fold on / off: every gradient that is bit-reproducible at all (everything
+    but the atomically summed biases) must be BIT-identical -- storing a block into zeros equals adding it -- and the norms agree to
+    summation-order level.  (ii) Two steps with the fold on, eager and captured: the folded norm equals the norm of the gradient arena read
+    back on the host before the optimizer ran -- a block missed by the fold, counted twice, or a gradient left stale by an overwriting
+    launch would move it by percents.  (Norms of SECOND steps cannot be compared across models: Adam turns last-bit differences of the
+    atomically summed bias gradients into sign flips of near-zero updates, and the bf16 forward amplifies those to ~1 %.)"""
+    from spegnet_amd.engine.arena import Arena
+    from spegnet_amd.engine.trainer import TrainStep
+    from spegnet_amd.utils.loss_functions import CODLoss
+
+    def make(fold, capture=False):
+        m, sd, cfg = make_model("large", "bf16", seed=3, train=True)
+        arena = Arena(m)
+        m.mark_params_changed()
+        arena.set_hyper(1e-4, 1e-5, 0.05)
+        step = TrainStep(m, CODLoss().cuda(), arena, grad_clip=1.0, capture=capture)
+        step.fold_sumsq = fold
+        return m, arena, step
+    batches = [O.synthetic_batch(2, 384, seed=90 + it) for it in range(2)]
+    dev = lambda b: (b[0].cuda(), torch.stack(b[1]).cuda(), torch.stack(b[2]).cuda())
+    grads, norms, taken = {}, {}, {}
+    for fold in (True, False):
+        m, arena, step = make(fold)
+        seen = []
+        orig = arena.step
+        arena.step = lambda *a, _o=orig, _s=seen, **k: (_s.append(0 if k.get("fold") is None else len(k["fold"][0])), _o(*a, **k))[1]
+        ns = []
+        for it in range(2):
+            step._fwd_bwd(*dev(batches[it]))
+            torch.cuda.synchronize()
+            if it == 0:
+                grads[fold] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            host = float(arena.g.double().pow(2).sum())
+            step._opt(1.0)
+            torch.cuda.synchronize()
+            got = float(arena.gnorm_sq)
+            assert abs(got - host) < 2e-5 * host, (fold, it, got, host)
+            ns.append(got)
+        norms[fold], taken[fold] = ns, seen
+    assert min(taken[True]) >= 10 and max(taken[False]) == 0, taken          # the fold was really taken (12+ whole-block launches) / really off
+    assert abs(norms[True][0] - norms[False][0]) < 2e-5 * norms[False][0], norms
+    same = diff = 0
+    for k in grads[True]:
+        if torch.equal(grads[True][k], grads[False][k]):
+            same += 1
+        else:
+            assert k.endswith(".bias"), f"{k}: gradient differs between the storing and the adding launch"
+            diff += 1
+    print(f"fold on / off, step 1: {same} gradients bit-identical, {diff} atomically summed biases differ in the last bits")
+    assert same > 500
+    # captured step: the same norm as the eager fold-on step on the first batch
+    m, arena, step = make(True, capture=True)
+    step(*dev(batches[0]))
+    torch.cuda.synchronize()
+    assert abs(float(arena.gnorm_sq) - norms[True][0]) < 2e-5 * norms[True][0], (float(arena.gnorm_sq), norms[True][0])
+
+
 @pytest.mark.parametrize("capture", [False, True])
 def test_train_steps_match_oracle(capture):
     """Two optimizer steps of the fp32 path == two oracle steps (clip + AdamW with the reference's groups)."""
