@@ -129,7 +129,9 @@ struct OptJob {
   int item0;       // first work item of this job
   int kind;        // 0 flat, 1 matrix, 2 conv3x3 [Co][Ci][3][3]
 };
-enum { OPT_FLAT = 0, OPT_MATRIX = 1, OPT_CONV = 2 };
+enum { OPT_FLAT = 0, OPT_MATRIX = 1, OPT_CONV = 2,
+       OPT_KEEP_G = 256 };   // flag on a matrix job's kind: its gradients are NOT cleared (the caller's next backward stores them whole:
+                             // spg_gemm_tn_blocks with overwrite)
 
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_pack_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(float* __restrict__ p, 
     const int ti = it - jb.item0;
     T* dst = reinterpret_cast<T*>(jb.dst);
     T* dst_t = reinterpret_cast<T*>(jb.dst_t);
-    if (jb.kind == OPT_MATRIX) {
+    if ((jb.kind & 255) == OPT_MATRIX) {
+      const bool clear_g = zero_grad != 0 && (jb.kind & OPT_KEEP_G) == 0;
       const int R = jb.R, C = jb.C;
       const int tiles_c = (C + 63) >> 6;
       const int r0 = (ti / tiles_c) * 64, c0 = (ti % tiles_c) * 64;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(float* __restrict__ p, 
             __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p + i));
             __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + i));
             __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + i));
-            if (zero_grad) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(g + i));
+            if (clear_g) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(g + i));
             if (dst) {
               T* d = dst + (long)r * jb.ldd + c;
               if constexpr (sizeof(T) == 2) *reinterpret_cast<u32x2*>(d) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(float* __restrict__ p, 
             float pv = p[i], mv = m[i], vv = v[i];
             adam1(pv, g[i], mv, vv, lr[grp], wd[grp], a);
             p[i] = pv; m[i] = mv; v[i] = vv;
-            if (zero_grad) g[i] = 0.f;
+            if (clear_g) g[i] = 0.f;
             if (dst) ST<T>::st(dst + (long)r * jb.ldd + c, pv);
             tile[rl][cl] = pv;
           }
@@ -321,7 +324,8 @@ extern "C" int spg_adamw(float* p, float* g, float* m, float* v, const unsigned 
 }
 
 /* AdamW + weight re-pack in one pass (see adamw_pack_kernel).  jobs: DEVICE array of njobs records
- *   struct { long off; void* dst; void* dst_t; int R, C, lds, ldd, item0, kind; }   (48 bytes, kind 0 flat / 1 matrix / 2 conv3x3)
+ *   struct { long off; void* dst; void* dst_t; int R, C, lds, ldd, item0, kind; }   (48 bytes, kind 0 flat / 1 matrix / 2 conv3x3;
+ *   kind | 256 on a matrix job: zero_grad leaves that job's gradients as they are -- the caller's next backward overwrites them)
  * that together cover every parameter of the arena exactly once; total_items = sum of the jobs' work items (matrix: 64 x 64 tiles,
  * flat / conv: 4096-element chunks).  dtype is the compute dtype of the copies.                                                    */
 extern "C" int spg_adamw_pack(int dtype, float* p, float* g, float* m, float* v, const unsigned char* group_of_chunk, const float* lr,

@@ -72,6 +72,7 @@ class Arena:
         self.unit_ends.append(off)
         self.m = self.v = None
         self._clean = True   # arena.g is all zeros
+        self._unzeroed = frozenset()   # ... except the matrices at these offsets (left uncleared by the last optimizer step, see zero_grad)
         self.step_f = torch.zeros(1, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.lr = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -90,10 +91,14 @@ class Arena:
     def scale_lr(self, factor: float, min_lr: float):
         self.lr.copy_(torch.clamp(self.lr * factor, min=min_lr))
 
-    def zero_grad(self):
-        """Clears the gradient arena unless the previous optimizer step already did (adamw zero_grad=1)."""
-        if not self._clean:
+    def zero_grad(self, expect_overwrite=None):
+        """Clears the gradient arena unless the previous optimizer step already did (adamw zero_grad=1).  The previous step may have left
+        the gradients of some matrices uncleared (`_unzeroed`: arena offsets) on the caller's promise that the next backward stores them
+        whole; expect_overwrite repeats that promise for this backward (TrainStep: same shapes, same switches) -- without it they are
+        cleared here."""
+        if not self._clean or (self._unzeroed and expect_overwrite != self._unzeroed):
             self.g.zero_()
+            self._unzeroed = frozenset()
         self._clean = False
 
     def _fold_plan(self, cover):
@@ -121,10 +126,11 @@ class Arena:
         self._fold_key, self._fold_n = key, len(recs)
         return self._fold_blob, self._fold_n
 
-    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, packer=None, fold=None):
+    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, packer=None, fold=None, keep_g: bool = False):
         """Global-norm clip + AdamW.  packer (the model's Engine): the update kernel also writes the compute-dtype weight copies of the
         next forward (spg_adamw_pack) instead of leaving them to a separate re-pack pass.  fold = (sums of squares, covered gradient
-        tensors) from Engine.take_sq(): the norm pass then reads only the uncovered gradients (spg_sumsq_fold)."""
+        tensors) from Engine.take_sq(): the norm pass then reads only the uncovered gradients (spg_sumsq_fold).  keep_g (with fold): the covered
+        matrices' gradients are not cleared either -- the caller promises that its next backward stores them whole (zero_grad(expect_overwrite))."""
         if self.m is None:
             self.m = torch.zeros_like(self.p)
             self.v = torch.zeros_like(self.p)
@@ -136,8 +142,11 @@ class Arena:
         # algorithmic bytes: sumsq reads g; adamw reads p, g, m, v and writes p, m, v, g (cleared) (+ the two compute-dtype copies)
         with ops._prof("sumsq + adamw_pack (clip + AdamW + weight re-pack)" if packer is not None else "sumsq + adamw", "hbm",
                        self.size * (4 + 32 + (2 * es if packer is not None else 0))):
+            keep = frozenset()
             if fold is not None and fold[0] and len(fold[0]) <= 32:
                 import ctypes
+                if keep_g:       # the covered MATRICES stay uncleared: the same launches store them whole next step (biases are added to)
+                    keep = frozenset((t.data_ptr() - self.g.data_ptr()) // 4 for t in fold[1] if t.dim() == 2)
                 blob, nchunks = self._fold_plan(fold[1])
                 if self._red_ws.numel() < nchunks:
                     self._red_ws = torch.empty(max(nchunks, 2048), dtype=torch.float32, device=self.p.device)
@@ -149,8 +158,10 @@ class Arena:
             else:
                 _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, self._red_ws.data_ptr(), 2048,
                           ops.red_counters(self.p.device, 1), s)
+            if self._unzeroed and not self._unzeroed <= (frozenset((t.data_ptr() - self.g.data_ptr()) // 4 for t in fold[1]) if fold is not None else frozenset()):
+                raise RuntimeError("gradients left uncleared by the previous optimizer step were not overwritten by this backward (stale values)")
             if packer is not None:
-                blob, njobs, items = packer.opt_jobs(self)
+                blob, njobs, items = packer.opt_jobs(self, keep)
                 dt = _lib.SPG_BF16 if packer.dtype == torch.bfloat16 else _lib.SPG_F32
                 _lib.call("spg_adamw_pack", dt, self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                           self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
@@ -160,6 +171,7 @@ class Arena:
                           self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
                           self.step_f.data_ptr(), float(clip), betas[0], betas[1], eps, float(grad_scale), 1, self.size, s)
         self._clean = True
+        self._unzeroed = keep if packer is not None else frozenset()
 
     def state_dict(self):
         """Optimizer state of the flat arena: Adam moments (arena layout), step counter, per-group lr / weight decay, and the name ->

@@ -66,7 +66,11 @@ class TrainStep:
     # ---- pieces -------------------------------------------------------------------------------------------
     def _fwd_bwd(self, images, masks, edges):
         ops.begin_zero_pool(images.device)   # one fill for the step's zero-initialised scratch (ops.zeros_f32)
-        self.arena.zero_grad()
+        # (the matrices the previous step left uncleared are stored whole again by this backward IF it makes the same launches: same input
+        # shapes, same switches -- otherwise they are cleared now; Arena.step refuses a backward that broke the promise)
+        sig = (tuple(images.shape), self.sync is None and self.fold_sumsq)
+        self.arena.zero_grad(expect_overwrite=self.arena._unzeroed if sig == getattr(self, "_fold_sig", None) else None)
+        self._fold_sig = sig
         # single GPU: the gradients are zero here and the norm is taken right after the backward, so the whole-block weight-gradient
         # launches may store instead of add and hand their sums of squares to the clip (models/engine.py: fold_sumsq).  With a GradSync
         # the norm is that of the all-reduced gradients: no fold.
@@ -81,7 +85,7 @@ class TrainStep:
         eng = self.model._engine
         fold = eng.take_sq() if eng.fold_sumsq else None
         eng.fold_sumsq = False
-        self.arena.step(self.clip, grad_scale=scale, packer=eng, fold=fold)
+        self.arena.step(self.clip, grad_scale=scale, packer=eng, fold=fold, keep_g=fold is not None)
 
     def _eager(self, images, masks, edges):
         losses = self._fwd_bwd(images, masks, edges)

@@ -137,14 +137,16 @@ class Engine:
         c2, c3, c4 = 2 * d, 4 * d, 8 * d
         return {":s2": (0, c2), ":s3": (c2, c2 + c3), ":s4": (c2 + c3, c2 + c3 + c4)}
 
-    def opt_jobs(self, arena):
+    def opt_jobs(self, arena, keep_offsets=frozenset()):
         """Job table of spg_adamw_pack (AdamW fused with this re-pack): (device blob, jobs, work items).  Covers every parameter of
         the arena once: matrices as 64 x 64 tiles with their [N,K] / [K,N] copies, 3x3 convolutions and everything else as flat
         4096-element chunks (runs of parameters that need no copy are merged into one flat job: the arena is contiguous)."""
         import struct
-        key = (arena.p.data_ptr(), tuple(t.data_ptr() for t in self.W.values()))
+        key = (arena.p.data_ptr(), tuple(t.data_ptr() for t in self.W.values()), keep_offsets)
         if getattr(self, "_opt_jobs_key", None) == key:
             return self._opt_jobs
+        # keep_offsets: arena offsets of the matrices whose gradients the optimizer kernel must NOT clear (kind | 256): the next backward's
+        # whole-block launches store them whole (Arena.step(fold=...), TrainStep)
         if not self.W:
             self.pack()
         P, W = self.P, self.W
@@ -178,7 +180,7 @@ class Engine:
             elif name + ":T" in W:
                 R = p.shape[0]
                 C = n // R
-                rec = (off, W[name].data_ptr(), W[name + ":T"].data_ptr(), R, C, C, C, 1)
+                rec = (off, W[name].data_ptr(), W[name + ":T"].data_ptr(), R, C, C, C, 1 | (256 if off in keep_offsets else 0))
             elif name in W:      # qkv bias: a compute-dtype copy of a vector
                 rec = (off, W[name].data_ptr(), 0, 1, n, n, n, 0)
             if rec is None:
@@ -191,7 +193,7 @@ class Engine:
             flush()
             o, d, dt_, R, C, lds, ldd, kind = rec
             recs.append(struct.pack("<qQQiiiiii", o, d, dt_, R, C, lds, ldd, item0, kind))
-            if kind == 1:
+            if kind & 255 == 1:
                 item0 += ((R + 63) // 64) * ((C + 63) // 64)
             elif kind == 2:
                 item0 += (R * C * 9 + 4095) // 4096
