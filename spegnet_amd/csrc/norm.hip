@@ -10,100 +10,127 @@ namespace spg {
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_MAXCH = 5;
 
-template <typename T, int NI = LN_MAXCH>   // NI = 16-byte chunk slots per lane (ceil(C / (64 VEC))): sized per launch, not for the widest row
+// RW = rows per wave: with many short rows (stages 1 and 2: 73728 x 144, 18432 x 288 at batch 8) one row per wave keeps only 288-576 bytes
+// in flight per wave -- a launch bound by memory latency at a third of the HBM rate.  A wave then takes RW consecutive rows, requests all of
+// them before the first reduction, and works through them one after the other (the arithmetic per row is unchanged: same bits).
+template <typename T, int NI = LN_MAXCH, int RW = 1>   // NI = 16-byte chunk slots per lane (ceil(C / (64 VEC))): sized per launch, not for the widest row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                             int C, float eps) {
   constexpr int VEC = ST<T>::VEC;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= M) return;
   const int nch = C / VEC;
-  float v[NI][VEC];
-  float s = 0.f;
+  float v[RW][NI][VEC];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      unpack16<T>(ld16(x + (long)row * C + ch * VEC), v[i]);
+  for (int r = 0; r < RW; ++r)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) s += v[i][e];
+    for (int i = 0; i < NI; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch && row0 + r < M) unpack16<T>(ld16(x + (long)(row0 + r) * C + ch * VEC), v[r][i]);
     }
-  }
-  const float mu = wave_sum(s) / C;
-  float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { const float d = v[i][e] - mu; ss += d * d; }
+    for (int i = 0; i < NI; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[r][i][e];
+      }
     }
-  }
-  const float rs = rsqrtf(wave_sum(ss) / C + eps);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    const float mu = wave_sum(s) / C;
+    float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      float o[VEC];
+    for (int i = 0; i < NI; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] = (v[i][e] - mu) * rs * gamma[ch * VEC + e] + beta[ch * VEC + e];
-      st16(y + (long)row * C + ch * VEC, pack16<T>(o));
+        for (int e = 0; e < VEC; ++e) { const float d = v[r][i][e] - mu; ss += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(ss) / C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = (v[r][i][e] - mu) * rs * gamma[ch * VEC + e] + beta[ch * VEC + e];
+        st16(y + (long)row * C + ch * VEC, pack16<T>(o));
+      }
     }
   }
 }
 
 // (Round 2, measured and dropped: requesting gamma / beta / dres together with the row as 16-byte loads -- one memory round trip less on
 // paper -- made both kernels ~30 % SLOWER (fwd 6.8 -> 9.3 us, bwd 10.3 -> 13.4 on one box); the late scalar loads are L1 hits.)
-// dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) (+dres).  One wave per row, row held in registers (full
-// thread-level parallelism hides HBM latency); the parameter gradients dgamma = sum_rows dy*xhat, dbeta = sum_rows dy are
-// column reductions done by colreduce_kernel<RED_LN> (a second, bandwidth-bound pass over dy and x).
-template <typename T, int NI = LN_MAXCH>
+// dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) (+dres).  One wave per row (RW rows, one after the other, all requested up front),
+// row held in registers (full thread-level parallelism hides HBM latency); the parameter gradients dgamma = sum_rows dy*xhat, dbeta =
+// sum_rows dy are column reductions done by colreduce_kernel<RED_LN> (a second, bandwidth-bound pass over dy and x).
+template <typename T, int NI = LN_MAXCH, int RW = 1>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
                                                             T* __restrict__ dx, int M, int C) {
   constexpr int VEC = ST<T>::VEC;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= M) return;
   const int nch = C / VEC;
-  const float mu = mean[row], rs = rstd[row];
-  float xh[NI][VEC], gd[NI][VEC];
-  float s1 = 0.f, s2 = 0.f;
+  float xv[RW][NI][VEC], dv[RW][NI][VEC];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      float xv[VEC], dv[VEC];
-      unpack16<T>(ld16(x + (long)row * C + ch * VEC), xv);
-      unpack16<T>(ld16(dy + (long)row * C + ch * VEC), dv);
+  for (int r = 0; r < RW; ++r)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        xh[i][e] = (xv[e] - mu) * rs;
-        gd[i][e] = dv[e] * gamma[ch * VEC + e];
-        s1 += gd[i][e];
-        s2 += gd[i][e] * xh[i][e];
+    for (int i = 0; i < NI; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch && row0 + r < M) {
+        unpack16<T>(ld16(x + (long)(row0 + r) * C + ch * VEC), xv[r][i]);
+        unpack16<T>(ld16(dy + (long)(row0 + r) * C + ch * VEC), dv[r][i]);
       }
     }
-  }
-  s1 = wave_sum(s1) / C;
-  s2 = wave_sum(s2) / C;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      float o[VEC];
-      if (dres) unpack16<T>(ld16(dres + (long)row * C + ch * VEC), o);
-      else {
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NI][VEC], gd[NI][VEC];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+    for (int i = 0; i < NI; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          xh[i][e] = (xv[r][i][e] - mu) * rs;
+          gd[i][e] = dv[r][i][e] * gamma[ch * VEC + e];
+          s1 += gd[i][e];
+          s2 += gd[i][e] * xh[i][e];
+        }
       }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] += rs * (gd[i][e] - s1 - xh[i][e] * s2);
-      st16(dx + (long)row * C + ch * VEC, pack16<T>(o));
+    for (int i = 0; i < NI; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[VEC];
+        if (dres) unpack16<T>(ld16(dres + (long)row * C + ch * VEC), o);
+        else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] += rs * (gd[i][e] - s1 - xh[i][e] * s2);
+        st16(dx + (long)row * C + ch * VEC, pack16<T>(o));
+      }
     }
   }
 }
@@ -445,9 +472,18 @@ extern "C" int spg_layernorm_fwd(int dtype, const void* x, const float* gamma, c
   hipStream_t s = (hipStream_t)stream;
   const int ni = cdiv(C / vec, 64);
 #define SPG_LNF(T_, NI_) hipLaunchKernelGGL((layernorm_fwd_kernel<T_, NI_>), dim3(cdiv(M, 4)), dim3(256), 0, s, (const T_*)x, gamma, beta, (T_*)y, mean, rstd, M, C, eps)
+#define SPG_LNF_RW(T_, RW_) hipLaunchKernelGGL((layernorm_fwd_kernel<T_, 1, RW_>), dim3(cdiv(M, 4 * RW_)), dim3(256), 0, s, (const T_*)x, gamma, beta, (T_*)y, mean, rstd, M, C, eps)
+#ifndef SPG_LN_RW_ROWS
+#define SPG_LN_RW_ROWS 32768     // rows from which a wave takes four rows of a one-slot (C <= 512 bf16) LayerNorm (tools/ A/B builds: a huge value = never)
+#endif
+  if (dtype == SPG_BF16 && ni <= 1 && M >= SPG_LN_RW_ROWS) {      // many short rows (stage 1: 73728 x 144: 24.5 -> 22.2 us; 18432 x 288 gains nothing)
+    SPG_LNF_RW(bf16_t, 4);
+    return check_launch("layernorm_fwd");
+  }
   if (dtype == SPG_BF16) { if (ni <= 1) SPG_LNF(bf16_t, 1); else if (ni == 2) SPG_LNF(bf16_t, 2); else if (ni == 3) SPG_LNF(bf16_t, 3); else SPG_LNF(bf16_t, LN_MAXCH); }
   else { if (ni <= 1) SPG_LNF(float, 1); else if (ni == 2) SPG_LNF(float, 2); else if (ni == 3) SPG_LNF(float, 3); else SPG_LNF(float, LN_MAXCH); }
 #undef SPG_LNF
+#undef SPG_LNF_RW
   return check_launch("layernorm_fwd");
 }
 
@@ -459,6 +495,8 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
   hipStream_t s = (hipStream_t)stream;
   const int ni = cdiv(C / vec, 64);
 #define SPG_LNB(T_, NI_) hipLaunchKernelGGL((layernorm_bwd_kernel<T_, NI_>), dim3(cdiv(M, 4)), dim3(256), 0, s, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (const T_*)dres, (T_*)dx, M, C)
+  // (several rows per wave, as the forward does for many short rows: 73728 x 144 backward 35.3 us with four rows per wave, 26.2 with two,
+  // 26.4 with one; 18432 x 288: 11.4 / 11.6 -- nothing to gain, the one-row kernel stays)
   if (dtype == SPG_BF16) { if (ni <= 1) SPG_LNB(bf16_t, 1); else if (ni == 2) SPG_LNB(bf16_t, 2); else if (ni == 3) SPG_LNB(bf16_t, 3); else SPG_LNB(bf16_t, LN_MAXCH); }
   else { if (ni <= 1) SPG_LNB(float, 1); else if (ni == 2) SPG_LNB(float, 2); else if (ni == 3) SPG_LNB(float, 3); else SPG_LNB(float, LN_MAXCH); }
 #undef SPG_LNB

@@ -262,7 +262,8 @@ def test_pack_matrix(ops):
 
 # ------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M,C", [(100, 144), (37, 1152), (64, 16), (513, 576), (5, 2048), (33, 288)])   # every chunk-slot instance, both dtypes
+@pytest.mark.parametrize("M,C", [(100, 144), (37, 1152), (64, 16), (513, 576), (5, 2048), (33, 288),   # every chunk-slot instance, both dtypes
+                                 (8197, 288), (40003, 144)])   # many short rows: two / four rows per wave (bf16), ragged last waves
 def test_layernorm(ops, dt, M, C):
     if dt == torch.float32 and C > 1280:
         pytest.skip("fp32 rows are limited to 5 x 64 x 4 columns")
