@@ -139,9 +139,11 @@ class Arena:
         if getattr(self, "_red_ws", None) is None:
             self._red_ws = torch.empty(2048, dtype=torch.float32, device=self.p.device)
         es = 2 if (packer is not None and packer.dtype == torch.bfloat16) else 4
-        # algorithmic bytes: sumsq reads g; adamw reads p, g, m, v and writes p, m, v, g (cleared) (+ the two compute-dtype copies)
+        # algorithmic bytes: sumsq reads g; adamw reads p, g, m, v and writes p, m, v, g (cleared) (+ the two compute-dtype copies); with a
+        # fold the covered gradients are neither read by the norm pass nor cleared (8 bytes per covered element less)
+        covered = sum(t.numel() for t in fold[1] if t.dim() == 2) if (fold is not None and fold[0] and len(fold[0]) <= 32) else 0
         with ops._prof("sumsq + adamw_pack (clip + AdamW + weight re-pack)" if packer is not None else "sumsq + adamw", "hbm",
-                       self.size * (4 + 32 + (2 * es if packer is not None else 0))):
+                       self.size * (4 + 32 + (2 * es if packer is not None else 0)) - 8 * covered):
             keep = frozenset()
             if fold is not None and fold[0] and len(fold[0]) <= 32:
                 import ctypes
