@@ -126,11 +126,11 @@ def roofline_table(rec, bracket_s, dtype):
 def committed_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
     FETCH_SIZE x2 per MI355X_MICROARCH.md; bench.py cannot collect counters itself).  Returns (bytes, source) or (None, None)."""
-    path = os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "round4_pmc_traffic.json")
     try:
         d = json.load(open(path))
         e = d["kernels"][kernel_key]
-        return e["fetch_bytes_x2"] + e["write_bytes"], "profiles/round3_pmc_traffic.json: " + d.get("source", "")
+        return e["fetch_bytes_x2"] + e["write_bytes"], "profiles/round4_pmc_traffic.json: " + d.get("source", "")
     except Exception:
         return None, None
 
