@@ -524,7 +524,10 @@ __device__ __forceinline__ void nt_pipe_body(const PipeProb& pb, const ChainSync
   const int M = pb.M, N = pb.N, K = pb.K, ldx = pb.ldx, ldc = pb.ldc, tiles_n = pb.tiles_n, ntiles = pb.ntiles;
   const unsigned xbytes = pb.xbytes, wbytes = pb.wbytes;
   constexpr int X_AUX = (CH & 1) ? CH_SC1 : 0;      // operands another workgroup of this launch wrote: L1-bypassing loads
-  constexpr int C_AUX = (CH & 2) ? CH_SC1 : 0;      // results another workgroup of this launch reads: write-through stores
+#ifndef SPG_PIPE_C_AUX    // (tools/ A/B builds: cache policy of the plain persistent kernel's output stores, see SPG_V3_C_AUX)
+#define SPG_PIPE_C_AUX 0
+#endif
+  constexpr int C_AUX = (CH & 2) ? CH_SC1 : SPG_PIPE_C_AUX;      // results another workgroup of this launch reads: write-through stores
   using M_ = Mma<T>;
   constexpr int VEC = ST<T>::VEC;
   constexpr int BK = ROWB / (int)sizeof(T);
@@ -662,7 +665,7 @@ __device__ __forceinline__ void nt_pipe_body(const PipeProb& pb, const ChainSync
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ev[e] = ea[jj][0][e] + eb0[e]; ev[4 + e] = ea[jj][1][e] + eb1[e]; }
         if constexpr (ACT == PIPE_ACT_GELU) {
-          if constexpr (DBG != 4) bstore16(c2r, eo[qt][jj], pack16<T>(ev));
+          if constexpr (DBG != 4) bstore16_aux<C_AUX>(c2r, eo[qt][jj], pack16<T>(ev));
 #pragma unroll
           for (int e = 0; e < 8; ++e) ev[e] = gelu_f(ev[e]);
         }
@@ -670,7 +673,7 @@ __device__ __forceinline__ void nt_pipe_body(const PipeProb& pb, const ChainSync
           float dv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) gelu_both_f(ev[e], ev[e], dv[e]);
-          bstore16(c2r, eo[qt][jj], pack16<T>(dv));
+          bstore16_aux<C_AUX>(c2r, eo[qt][jj], pack16<T>(dv));
         }
         if constexpr (ACT == PIPE_ACT_HH) {
           float h[8];
@@ -708,7 +711,7 @@ __device__ __forceinline__ void nt_pipe_body(const PipeProb& pb, const ChainSync
 #pragma unroll
       for (int e = 0; e < 4; ++e) { cv[e] = ca[0][e] + eb0[e]; cv[4 + e] = ca[1][e] + eb1[e]; }
       if constexpr (ACT == PIPE_ACT_GELU) {
-        bstore16(c2r, eo[qt][jj], pack16<T>(cv));
+        bstore16_aux<C_AUX>(c2r, eo[qt][jj], pack16<T>(cv));
 #pragma unroll
         for (int e = 0; e < 4; ++e) cv[e] = gelu_f(cv[e]);
       }
@@ -960,6 +963,20 @@ template <int N_> __device__ __forceinline__ void wait_vm_only() { asm volatile(
 // KS = MFMA k-blocks (32 of K) per LDS stage: 2 -> 128-byte rows, chunk c of row r holds logical chunk c ^ (r & 7) (the image of the
 // kernels above); 1 -> 64-byte rows, chunk c of row r holds c ^ (2 ((r >> 3) & 1)).  NS = stages.  (KS, NS) = (2, 2): 64 KiB, one DMA
 // group (32 KiB) in flight behind the stage being read; (1, 4): 64 KiB, three 16 KiB groups in flight, a barrier every 32 of K.
+// Cache policy of the output stores: sc1 = write-through, the line does not stay in the XCD's L2 (MI355X_MICROARCH.md, "stores of each
+// flavour").  The outputs of these launches (21-42 MB at the 2304-wide shapes) are read next by another kernel, on whatever XCD its tile
+// lands -- kept in L2 they only evict the X / W panels that the XCD's other tiles are about to fill from: fc1 23.2 -> 20.7 us, with the
+// GELU epilogue's second output 28.0 -> 25.1, qkv 14.9 -> 12.9 (tools/nt_check.py, one box; nt: 21.0 / 26.2 / 13.2).  (tools/ A/B builds:
+// 0 = plain, 2 = nt)
+#ifndef SPG_V3_C_AUX
+#define SPG_V3_C_AUX 16
+#endif
+#ifndef SPG_V3_C2_AUX
+#define SPG_V3_C2_AUX 16
+#endif
+#ifndef SPG_V3_H_AUX
+#define SPG_V3_H_AUX 0
+#endif
 template <bool CONV, int ACT, int NB, int KS, int NS>
 __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                             NtEpi epi, PipeEpi pe, int M, int N, int K, int ldx, int ldc, ConvGeom g,
@@ -1082,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
       for (int v = 0; v < NV; ++v) {
         const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
         er[mi][v] = bload16(rr, o);
-        if constexpr (ACT == PIPE_ACT_HH || ACT == PIPE_ACT_MULH) eh[mi][v] = bload16(hr, o);
+        if constexpr (ACT == PIPE_ACT_HH || ACT == PIPE_ACT_MULH) eh[mi][v] = bload16_aux<SPG_V3_H_AUX>(hr, o);
       }
     }
   };
@@ -1147,7 +1164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
       }
       const unsigned o = (eo[mi] != OOB && ncol + 32 * v < N) ? eo[mi] + 64u * v : OOB;
       if constexpr (ACT == PIPE_ACT_GELU) {
-        bstore16(c2r, o, pack16<T>(ev));
+        bstore16_aux<SPG_V3_C2_AUX>(c2r, o, pack16<T>(ev));
 #pragma unroll
         for (int e = 0; e < 8; ++e) ev[e] = gelu_f(ev[e]);
       }
@@ -1155,7 +1172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
         float dv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) gelu_both_f(ev[e], ev[e], dv[e]);
-        bstore16(c2r, o, pack16<T>(dv));
+        bstore16_aux<SPG_V3_C2_AUX>(c2r, o, pack16<T>(dv));
       }
       if constexpr (ACT == PIPE_ACT_HH) {
         float h[8];
@@ -1173,7 +1190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
       unpack16<T>(er[mi][v], rres);
 #pragma unroll
       for (int e = 0; e < 8; ++e) ev[e] += rres[e];
-      bstore16(cr, o, pack16<T>(ev));
+      bstore16_aux<SPG_V3_C_AUX>(cr, o, pack16<T>(ev));
     }
   }
 }
