@@ -963,16 +963,14 @@ template <int N_> __device__ __forceinline__ void wait_vm_only() { asm volatile(
 // KS = MFMA k-blocks (32 of K) per LDS stage: 2 -> 128-byte rows, chunk c of row r holds logical chunk c ^ (r & 7) (the image of the
 // kernels above); 1 -> 64-byte rows, chunk c of row r holds c ^ (2 ((r >> 3) & 1)).  NS = stages.  (KS, NS) = (2, 2): 64 KiB, one DMA
 // group (32 KiB) in flight behind the stage being read; (1, 4): 64 KiB, three 16 KiB groups in flight, a barrier every 32 of K.
-// Cache policy of the output stores: sc1 = write-through, the line does not stay in the XCD's L2 (MI355X_MICROARCH.md, "stores of each
-// flavour").  The outputs of these launches (21-42 MB at the 2304-wide shapes) are read next by another kernel, on whatever XCD its tile
-// lands -- kept in L2 they only evict the X / W panels that the XCD's other tiles are about to fill from: fc1 23.2 -> 20.7 us, with the
-// GELU epilogue's second output 28.0 -> 25.1, qkv 14.9 -> 12.9 (tools/nt_check.py, one box; nt: 21.0 / 26.2 / 13.2).  (tools/ A/B builds:
-// 0 = plain, 2 = nt)
+// Cache policy of the output stores (tools/ A/B builds: 16 = sc1, write-through, the line does not stay in the XCD's L2; 2 = nt).  Measured
+// (DESIGN.md 3.1 item 49): sc1 takes 10-15 % off a 2304-wide launch REPLAYED back to back (fc1 23.2 -> 20.7 us, qkv 14.9 -> 12.9), changes
+// nothing in the batch-8 train step and costs the batch-64 inference forward 4 % (1575 -> 1513 img/s): plain stores stay.
 #ifndef SPG_V3_C_AUX
-#define SPG_V3_C_AUX 16
+#define SPG_V3_C_AUX 0
 #endif
 #ifndef SPG_V3_C2_AUX
-#define SPG_V3_C2_AUX 16
+#define SPG_V3_C2_AUX 0
 #endif
 #ifndef SPG_V3_H_AUX
 #define SPG_V3_H_AUX 0
