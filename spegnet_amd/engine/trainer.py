@@ -55,6 +55,7 @@ class TrainStep:
         self.losses = None
         self.world = sync.world if sync is not None else 1
         self.fold_sumsq = os.environ.get("SPG_FOLD_SUMSQ", "1") != "0"     # (A/B runs: tools/ab_env.sh)
+        self._graph_unzeroed = frozenset()
         # forked weight-gradient stream (models/engine.py; `TrainStep(..., wgrad_async=True)` for A/B runs): measured SLOWER on one MI355X
         # (226.0 vs 232.2 img/s on the B=8@384 graph step) -- both branches are chip-sized persistent kernels, so they contend
         model.engine.wgrad_async = ((sync is None) or capture) and bool(wgrad_async)
@@ -262,6 +263,8 @@ class TrainStep:
                     return self._eager(images, masks, edges)
             elif err is not None:
                 raise err
+            if self.graph is not None:
+                self._graph_unzeroed = self.arena._unzeroed      # what the captured optimizer leaves uncleared (and its backward stores whole)
         # the captured graphs are frozen to the shapes of the first batch: anything else (a short last batch, another ground-truth size)
         # runs eagerly instead of being broadcast into / rejected by the static buffers
         if any(dst.shape != src.shape for dst, src in zip(self.static, (images, masks, edges))):
@@ -272,10 +275,17 @@ class TrainStep:
         for dst, src in zip(self.static, (images, masks, edges)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
+        # The captured step neither clears the gradient arena at its start nor the matrices its own whole-block launches store (both decided
+        # at capture time).  If something else ran since the last replay -- an eager step of another shape, a ragged batch -- and left a
+        # different set of matrices uncleared, clear the arena here, outside the graph.
+        ar = self.arena
+        if not ar._clean or ar._unzeroed != self._graph_unzeroed:
+            ar.g.zero_()
         if self.segments is not None:
             self._replay_segmented()
         else:
             self.graph.replay()
+        ar._clean, ar._unzeroed = True, self._graph_unzeroed
         return self.losses
 
 

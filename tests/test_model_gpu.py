@@ -563,6 +563,43 @@ def test_folded_gradient_norm_equals_plain_step():
     assert abs(float(arena.gnorm_sq) - norms[True][0]) < 2e-5 * norms[True][0], (float(arena.gnorm_sq), norms[True][0])
 
 
+def test_captured_folded_step_clears_foreign_uncleared_gradients():
+    """The captured single-GPU step clears nothing at its start and leaves the matrices its own whole-block launches store uncleared (both
+    decided at capture time).  If something else ran since the last replay and left ANOTHER set of matrices uncleared (an eager step of a
+    different batch shape, whose launch sets differ), the next replay must not add to them: TrainStep clears the arena outside the graph
+    when the arena's record differs from the graph's.  Simulated exactly: a matrix the graph does not cover is marked uncleared and its
+    gradient poisoned; the replay's gradient norm must stay at the level of an ordinary step.  (Norms of later steps cannot be compared
+    across runs: they are chaotic at this initialisation -- 305 / 328 / 416 / 436 for one batch over eager / captured x fold off / on.)
+    An eager step of another shape through the same TrainStep in between must run as well."""
+    from spegnet_amd.engine.arena import Arena
+    from spegnet_amd.engine.trainer import TrainStep
+    from spegnet_amd.utils.loss_functions import CODLoss
+    dev = lambda b: (b[0].cuda(), torch.stack(b[1]).cuda(), torch.stack(b[2]).cuda())
+    m, sd, cfg = make_model("large", "bf16", seed=3, train=True)
+    arena = Arena(m)
+    m.mark_params_changed()
+    arena.set_hyper(1e-4, 1e-5, 0.05)
+    step = TrainStep(m, CODLoss().cuda(), arena, grad_clip=1.0, capture=True)
+    step(*dev(O.synthetic_batch(2, 384, seed=95)))
+    torch.cuda.synchronize()
+    n1 = float(arena.gnorm_sq)
+    assert len(step._graph_unzeroed) >= 100 and arena._unzeroed == step._graph_unzeroed
+    step(*dev(O.synthetic_batch(4, 384, seed=96)))          # another shape: runs eagerly, leaves its own record
+    torch.cuda.synchronize()
+    # a matrix outside the graph's set, left 'uncleared' with a stale gradient
+    name = "encoder.encoder.blocks.0.mlp.layers.0.weight"
+    off = arena.offsets[name]
+    assert off not in step._graph_unzeroed
+    arena._unzeroed = frozenset(set(step._graph_unzeroed) | {off})
+    dict(m.named_parameters())[name].grad.fill_(1.0e3)
+    step(*dev(O.synthetic_batch(2, 384, seed=97)))
+    torch.cuda.synchronize()
+    n3 = float(arena.gnorm_sq)
+    print(f"gradient norm^2: first step {n1:.2f}, replay after the foreign state {n3:.2f}")
+    assert n3 < 1e4, n3            # (the poisoned matrix alone would contribute 82944 x 1e6)
+    assert arena._unzeroed == step._graph_unzeroed
+
+
 @pytest.mark.parametrize("capture", [False, True])
 def test_train_steps_match_oracle(capture):
     """Two optimizer steps of the fp32 path == two oracle steps (clip + AdamW with the reference's groups)."""
