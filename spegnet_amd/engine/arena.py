@@ -139,16 +139,22 @@ class Arena:
         if getattr(self, "_red_ws", None) is None:
             self._red_ws = torch.empty(2048, dtype=torch.float32, device=self.p.device)
         es = 2 if (packer is not None and packer.dtype == torch.bfloat16) else 4
+        use_fold = fold is not None and len(fold[0]) > 0 and len(fold[0]) <= 32       # (spg_sumsq_fold takes up to 32 partial arrays)
+        base = self.g.data_ptr()
+        cov_offsets = frozenset((t.data_ptr() - base) // 4 for t in fold[1]) if fold is not None else frozenset()
+        if self._unzeroed and not self._unzeroed <= cov_offsets:
+            raise RuntimeError("gradients left uncleared by the previous optimizer step were not overwritten by this backward (stale values): "
+                               "call zero_grad() without a promise before a backward that makes other launches")
         # algorithmic bytes: sumsq reads g; adamw reads p, g, m, v and writes p, m, v, g (cleared) (+ the two compute-dtype copies); with a
         # fold the covered gradients are neither read by the norm pass nor cleared (8 bytes per covered element less)
-        covered = sum(t.numel() for t in fold[1] if t.dim() == 2) if (fold is not None and fold[0] and len(fold[0]) <= 32) else 0
+        covered = sum(t.numel() for t in fold[1] if t.dim() == 2) if use_fold else 0
         with ops._prof("sumsq + adamw_pack (clip + AdamW + weight re-pack)" if packer is not None else "sumsq + adamw", "hbm",
                        self.size * (4 + 32 + (2 * es if packer is not None else 0)) - 8 * covered):
             keep = frozenset()
-            if fold is not None and fold[0] and len(fold[0]) <= 32:
+            if use_fold:
                 import ctypes
                 if keep_g:       # the covered MATRICES stay uncleared: the same launches store them whole next step (biases are added to)
-                    keep = frozenset((t.data_ptr() - self.g.data_ptr()) // 4 for t in fold[1] if t.dim() == 2)
+                    keep = frozenset((t.data_ptr() - base) // 4 for t in fold[1] if t.dim() == 2)
                 blob, nchunks = self._fold_plan(fold[1])
                 if self._red_ws.numel() < nchunks:
                     self._red_ws = torch.empty(max(nchunks, 2048), dtype=torch.float32, device=self.p.device)
@@ -160,8 +166,6 @@ class Arena:
             else:
                 _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, self._red_ws.data_ptr(), 2048,
                           ops.red_counters(self.p.device, 1), s)
-            if self._unzeroed and not self._unzeroed <= (frozenset((t.data_ptr() - self.g.data_ptr()) // 4 for t in fold[1]) if fold is not None else frozenset()):
-                raise RuntimeError("gradients left uncleared by the previous optimizer step were not overwritten by this backward (stale values)")
             if packer is not None:
                 blob, njobs, items = packer.opt_jobs(self, keep)
                 dt = _lib.SPG_BF16 if packer.dtype == torch.bfloat16 else _lib.SPG_F32
