@@ -98,8 +98,11 @@ def param_specs(cfg) -> List[Tuple[str, Tuple[int, ...], str]]:
 BUFFER_KINDS = ("rmean", "rvar", "nbt")
 
 
-def init_tensor(name: str, shape, kind: str, g: torch.Generator) -> torch.Tensor:
-    """nn-default-style initialisation (head) / trunc-normal(0.02) (trunk); real use loads a checkpoint."""
+def init_tensor(name: str, shape, kind: str, g: torch.Generator, empty: bool = False) -> torch.Tensor:
+    """nn-default-style initialisation (head) / trunc-normal(0.02) (trunk); real use loads a checkpoint.  empty: the random tensors are left
+    uninitialised (config['init'] = 'empty': the caller loads a state_dict next; drawing 215 M normals takes seconds)."""
+    if empty and kind in ("pos", "weight", "bias"):
+        return torch.empty(shape)
     if kind in ("ln_w", "bn_w", "rvar"):
         return torch.ones(shape)
     if kind in ("ln_b", "bn_b", "rmean"):

@@ -119,12 +119,13 @@ class SPEGNet(nn.Module):
         # edge_detector.*, decoder.*
         kinds = {}
         g = torch.Generator().manual_seed(int(config.get('init_seed', 0)))
+        empty = str(config.get('init', 'random')) == 'empty'     # parameters left uninitialised: a load_state_dict follows
         from .params import init_tensor
         for name, shape, kind in param_specs(self.hiera_cfg):
             top, _, rest = name.partition(".")
             if top not in self._modules:
                 self.add_module(top, ParamTree())
-            self._modules[top].insert(rest, init_tensor(name, shape, kind, g), kind in BUFFER_KINDS)
+            self._modules[top].insert(rest, init_tensor(name, shape, kind, g, empty), kind in BUFFER_KINDS)
             kinds[name] = kind
         self._kinds = kinds
         import weakref

@@ -33,7 +33,7 @@ def main():
     sd = O.init_state_dict(seed=3, cfg=cfg)
 
     def fresh():
-        m = SPEGNet({"encoder": {"variant": "large" if large else "test_tiny"}, "compute_dtype": "bf16" if large else "fp32"})
+        m = SPEGNet({"encoder": {"variant": "large" if large else "test_tiny"}, "compute_dtype": "bf16" if large else "fp32", "init": "empty"})
         m.load_state_dict(sd)
         m = m.cuda().train()
         ar = Arena(m)

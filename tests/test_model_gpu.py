@@ -10,11 +10,16 @@ from oracle import spegnet_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+_SD_CACHE = {}
+
+
 def make_model(variant, dtype, seed=3, train=False):
     from spegnet_amd.models import SPEGNet
     cfg = O.HIERA_L if variant == "large" else O.HIERA_TINY_TEST
-    sd = O.init_state_dict(seed=seed, cfg=cfg)
-    m = SPEGNet({"encoder": {"variant": variant if variant == "large" else "test_tiny"}, "compute_dtype": dtype})
+    if (variant, seed) not in _SD_CACHE:       # (drawing the 215 M parameters takes seconds: drawn once per suite run, cloned per test)
+        _SD_CACHE[(variant, seed)] = O.init_state_dict(seed=seed, cfg=cfg)
+    sd = {k: v.clone() for k, v in _SD_CACHE[(variant, seed)].items()}
+    m = SPEGNet({"encoder": {"variant": variant if variant == "large" else "test_tiny"}, "compute_dtype": dtype, "init": "empty"})      # (no random initialisation: the state dict is loaded next)
     m.load_state_dict(sd)
     m = m.cuda()
     m.train(train)
