@@ -250,24 +250,57 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_vec_kernel(const T* __restri
   }
 }
 
-// patch-embed im2col: img f32 NCHW [B,3,H,W] -> cols T [B*(H/4)*(W/4)][Kpad], k = c*49 + ky*7 + kx (conv 7x7 s4 p3)
+// patch-embed im2col: img f32 NCHW [B,3,H,W] -> cols T [B*(H/4)*(W/4)][Kpad], k = c*49 + ky*7 + kx (conv 7x7 s4 p3).
+// One workgroup = one output row segment of <= PI_PX pixels: the 3 x 7 input row segments it reads are staged in LDS with coalesced
+// 16-byte loads (left halo of 4, zero rows outside the image), then every thread assembles 16-byte pieces of the column matrix from a
+// k -> LDS-offset table, consecutive lanes = consecutive pieces (fully coalesced stores).  The element-per-thread version this replaces
+// took 2.3 ms at batch 64 (41 G elements/s: 64-bit div/mod per element, 2-byte stores).
+constexpr int PI_PX = 96;                  // output pixels per workgroup
+constexpr int PI_RS = PI_PX * 4 + 4;       // LDS row: 4 halo floats (3 used) + 4 input pixels per output pixel
 template <typename T>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H, int W, int Kpad) {
+  constexpr int VEC = ST<T>::VEC;
+  __shared__ __attribute__((aligned(16))) float rows[21 * PI_RS + 4];
+  __shared__ int tab[256];
   const int Ho = H / 4, Wo = W / 4;
-  const long total = (long)B * Ho * Wo * Kpad;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int k = (int)(i % Kpad);
-    long p = i / Kpad;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
-    float v = 0.f;
-    if (k < 147) {
-      const int c = k / 49, r = k - c * 49, ky = r / 7, kx = r - ky * 7;
-      const int iy = oy * 4 + ky - 3, ix = ox * 4 + kx - 3;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = img[(((long)b * 3 + c) * H + iy) * W + ix];
+  const int xt = (Wo + PI_PX - 1) / PI_PX;
+  int blk = blockIdx.x;
+  const int tx = blk % xt; blk /= xt;
+  const int oy = blk % Ho;
+  const int b = blk / Ho;
+  const int ox0 = tx * PI_PX;
+  const int npx = min(PI_PX, Wo - ox0);
+  const int tid = threadIdx.x;
+  // k -> offset of (c, ky, kx) in the staged rows (+1: column 4*ox+kx-3 sits at 4*ox+kx+1 behind the 4-float halo); pad columns read the zero slot
+  if (tid < Kpad) {
+    int off = 21 * PI_RS;
+    if (tid < 147) { const int c = tid / 49, r = tid - c * 49, ky = r / 7, kx = r - ky * 7; off = (c * 7 + ky) * PI_RS + kx + 1; }
+    tab[tid] = off;
+  }
+  if (tid < 4) rows[21 * PI_RS + tid] = 0.f;
+  // stage: 21 rows x (1 halo quad + npx quads)
+  const int quads = npx + 1;
+  for (int i = tid; i < 21 * quads; i += 256) {
+    const int r = i / quads, q = i - r * quads;
+    const int c = r / 7, ky = r - c * 7;
+    const int iy = oy * 4 + ky - 3;
+    const int ix = ox0 * 4 + (q - 1) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)H && ix >= 0) v = *reinterpret_cast<const float4*>(img + (((long)b * 3 + c) * H + iy) * W + ix);
+    *reinterpret_cast<float4*>(rows + r * PI_RS + q * 4) = v;
+  }
+  __syncthreads();
+  const int cpp = Kpad / VEC;              // 16-byte pieces per pixel
+  T* out = cols + (((long)b * Ho + oy) * Wo + ox0) * Kpad;
+  for (int i = tid; i < npx * cpp; i += 256) {
+    const int px = i / cpp, j = i - px * cpp;
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int t = tab[j * VEC + e];
+      v[e] = rows[t + (t < 21 * PI_RS ? px * 4 : 0)];
     }
-    ST<T>::st(cols + i, v);
+    st16(out + (long)i * VEC, pack16<T>(v));
   }
 }
 
@@ -755,8 +788,11 @@ extern "C" int spg_maxpool2_bwd(int dtype, const void* dy, const uint8_t* idx, v
   return check_launch("maxpool2_bwd");
 }
 extern "C" int spg_patch_im2col(int dtype, const float* img, void* cols, int B, int H, int W, int Kpad, spg_stream_t stream) {
-  SPG_REQUIRE(H % 4 == 0 && W % 4 == 0 && Kpad >= 147, "patch_im2col: H=%d W=%d Kpad=%d", H, W, Kpad);
-  const int grid = ew_grid((long)B * (H / 4) * (W / 4) * Kpad);
+  SPG_REQUIRE(B > 0 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && Kpad >= 147 && Kpad <= 256 && Kpad % 8 == 0, "patch_im2col: B=%d H=%d W=%d Kpad=%d", B, H, W, Kpad);
+  SPG_REQUIRE(((uintptr_t)img & 15) == 0 && ((uintptr_t)cols & 15) == 0, "patch_im2col: img / cols must be 16-byte aligned");
+  const long nblk = (long)B * (H / 4) * ((W / 4 + PI_PX - 1) / PI_PX);
+  SPG_REQUIRE(nblk < (1L << 31), "patch_im2col: %ld workgroups", nblk);
+  const int grid = (int)nblk;
   if (dtype == SPG_BF16) hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, H, W, Kpad);
   else hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, H, W, Kpad);
   return check_launch("patch_im2col");

@@ -423,6 +423,20 @@ def test_patch_embed(ops, dt):
     check(out.float().permute(0, 3, 1, 2), ref, tol(dt), "patch embed")
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,H,W", [(1, 4, 4), (2, 32, 48), (1, 384, 384), (1, 8, 768), (3, 12, 400)])
+def test_patch_im2col_is_exactly_unfold(ops, dt, B, H, W):
+    """The column matrix is a pure gather: every element must equal F.unfold's (7x7, stride 4, pad 3), rounded once to the compute
+    type, with zero pad columns -- including rows wider than one 96-pixel workgroup segment (W/4 = 192, 100) and the image borders."""
+    KP = 160
+    img = rnd(B, 3, H, W, seed=7)
+    cols = ops.patch_im2col(img, dt, KP)
+    ref = F.unfold(img, 7, padding=3, stride=4).transpose(1, 2).reshape(B * (H // 4) * (W // 4), 147).to(dt)
+    assert cols.shape == (B * (H // 4) * (W // 4), KP)
+    assert torch.equal(cols[:, :147], ref)
+    assert not cols[:, 147:].any()
+
+
 # ------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,C,relu", [(500, 64, True), (2304, 512, True), (4, 128, True), (1000, 16, False)])
