@@ -35,7 +35,7 @@ enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
 
 /* ABI revision: bumped with every change of an exported signature.  Bindings must compare spg_version() with the SPG_ABI_VERSION they
  * were written against and refuse to run on a mismatch (spegnet_amd/_lib.py does).  300 = round 3. */
-#define SPG_ABI_VERSION 306
+#define SPG_ABI_VERSION 307
 int spg_version(void);
 const char* spg_last_error(void);
 
@@ -354,6 +354,21 @@ int spg_loss_finalize(const float* stats, const float* seg_sums, const float* ed
 int spg_loss_grad(int dtype, const void* pred, const float* target, const float* wmap, const float* stats,
                   const float* sums, const float* grad_out, void* dpred, int B, int S, int h, int w, int edge, float coef,
                   float bce_w, float iou_w, float alpha, float gamma, float* dz_ws, spg_stream_t stream);
+
+/* The same reductions / gradients for the loss's four maps in one launch each (preds, hs, ws, dpreds, coefs: HOST arrays of 4 --
+ * [0..2] the segmentation logits against `masks` (seg_sums[3][B][3]), [3] the edge logits against `edge_gt` (edge_sums[B][3]); read
+ * at the call).  Results are bit-identical to four spg_loss_reduce / spg_loss_grad calls (same blocks per map, same fixed-order finish).
+ * reduce_all: red_ws >= spg_loss_reduce_all_workspace_floats(B) floats, red_counters = 4 B zeroed words.
+ * grad_all: dz_ws = 4 * B * S * S floats; coefs[i] = scale weight / B (i < 3), edge weight / B (i = 3); two launches (the derivative per
+ *   full-res pixel of every map -- which IS the gradient of a map already at S x S --, then the bilinear adjoint of the coarser maps). */
+long spg_loss_reduce_all_workspace_floats(int B);
+int spg_loss_reduce_all(int dtype, const void* const* preds, const int* hs, const int* ws, const float* masks, const float* edge_gt,
+                        const float* wmap, const float* stats, float* seg_sums, float* edge_sums, int B, int S, float alpha, float gamma,
+                        float* red_ws, long red_ws_floats, unsigned* red_counters, spg_stream_t stream);
+int spg_loss_grad_all(int dtype, const void* const* preds, void* const* dpreds, const int* hs, const int* ws, const float* coefs,
+                      const float* masks, const float* edge_gt, const float* wmap, const float* stats, const float* seg_sums,
+                      const float* edge_sums, const float* grad_out, int B, int S, float bce_w, float iou_w, float alpha, float gamma,
+                      float* dz_ws, spg_stream_t stream);
 
 /* ---- optimizer (engine/trainer.py:274-306 param groups, :399-409 clip + AdamW step) over a flat f32 arena ---------
  * sumsq: out[0] = sum x^2 (deterministic: 2048 floats of scratch + one zeroed counter, see "Deterministic reductions").  adamw: step_f[0] += 1, then clip coefficient min(1, clip/(sqrt(gnorm_sq)*grad_scale+1e-6))

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPG_LIBRARY") or os.path.join(_HERE, "libspegnet_hip.so")
 
 SPG_F32, SPG_BF16 = 0, 1
-ABI_VERSION = 306   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
+ABI_VERSION = 307   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 ACT_GELU_SAVE_GRAD, ACT_MUL_H = 3, 4   # bf16: C2 = gelu'(pre) saved by the forward GEMM | C = acc * gelu_h in the backward GEMM
 
@@ -87,6 +87,8 @@ SIGNATURES = {
     "spg_loss_reduce": "ippppp" "iiiiiff" "plp" "p",
     "spg_loss_finalize": "pppp" "iiffffffp",
     "spg_loss_grad": "ippppppp" "iiiiifffff" "pp",
+    "spg_loss_reduce_all": "ippp" "pppppp" "iiff" "plp" "p",
+    "spg_loss_grad_all": "ippppp" "ppppppp" "iiffff" "pp",
     "spg_sumsq": "pp" "l" "plp" "p",
     "spg_sumsq_fold": "ppii" "pp" "p" "plp" "p",
     "spg_adamw": "ppppppppp" "fffff" "ilp",
@@ -105,6 +107,7 @@ QUERIES = {
     "spg_reduce_counters": ("i", "iii"),
     "spg_layernorm_param_grads_batch_workspace_floats": ("l", "ip"),
     "spg_loss_workspace_floats": ("l", "ii"),
+    "spg_loss_reduce_all_workspace_floats": ("l", "i"),
     "spg_head1x1_bwd_workspace_floats": ("l", "i"),
     "spg_bn_bwd_head_workspace_floats": ("l", "ii"),
     "spg_easpp_fuse_bn_bwd_workspace_floats": ("l", "ii"),

@@ -45,15 +45,24 @@ __global__ __launch_bounds__(256) void dwconv4_kernel(const T* __restrict__ x, D
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    // The nine taps are loaded UNCONDITIONALLY (a tap outside the image reads the centre pixel and is weighted 0) and all before the
+    // first use: a load inside `if (inside)` is waited for inside that branch, nine dependent memory round trips per pixel -- what these
+    // kernels' time was (forward 31 us, weight gradient 61 us for 24 MB).
+    u32x4 raw[9];
+    bool ok[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int yy = Y + (t / 3 - 1) * dil, xx = X + (t % 3 - 1) * dil;
-      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-        float v[VEC];
-        unpack16<T>(ld16(x + (((long)b * H + yy) * W + xx) * C + ch * VEC), v);
+      ok[t] = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const long q = ok[t] ? (((long)b * H + yy) * W + xx) : pix;
+      raw[t] = ld16(x + q * C + ch * VEC);
+    }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] += wr[t][e] * v[e];
-      }
+    for (int t = 0; t < 9; ++t) {
+      float v[VEC];
+      unpack16<T>(raw[t], v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = ok[t] ? fmaf(wr[t][e], v[e], acc[e]) : acc[e];
     }
     st16(y + pix * 4 * C + br * C + ch * VEC, pack16<T>(acc));
   }
@@ -76,6 +85,7 @@ __global__ __launch_bounds__(256) void dwconv4_dgrad_kernel(const T* __restrict_
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int ch = (int)(i % nch);
     long p = i / nch;
+    const long pix = p;
     const int X = (int)(p % W); p /= W;
     const int Y = (int)(p % H);
     const int b = (int)(p / H);
@@ -85,16 +95,22 @@ __global__ __launch_bounds__(256) void dwconv4_dgrad_kernel(const T* __restrict_
 #pragma unroll
     for (int br = 0; br < 4; ++br) {
       const int dil = d.dil[br];
+      u32x4 raw[9];     // (a branch's nine taps in flight together, see dwconv4_kernel)
+      bool ok[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int yy = Y + (t / 3 - 1) * dil, xx = X + (t % 3 - 1) * dil;
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-          float v[VEC];
-          unpack16<T>(ld16(dy + (((long)b * H + yy) * W + xx) * 4 * C + br * C + ch * VEC), v);
-          const float* wp = wl + (br * 9 + t) * C + ch * VEC;
+        ok[t] = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const long q = ok[t] ? (((long)b * H + yy) * W + xx) : pix;
+        raw[t] = ld16(dy + q * 4 * C + br * C + ch * VEC);
+      }
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) acc[e] += wp[e] * v[e];
-        }
+      for (int t = 0; t < 9; ++t) {
+        float v[VEC];
+        unpack16<T>(raw[t], v);
+        const float* wp = wl + (br * 9 + t) * C + ch * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = ok[t] ? fmaf(wp[e], v[e], acc[e]) : acc[e];
       }
     }
     st16(dx + i * VEC, pack16<T>(acc));
@@ -124,15 +140,21 @@ __global__ __launch_bounds__(256) void dwconv4_wgrad_kernel(const T* __restrict_
       const int Y = (int)((p / W) % H);
       float dv[VEC];
       unpack16<T>(ld16(dy + p * 4 * C + br * C + ch * VEC), dv);
+      u32x4 raw[9];     // (the nine taps in flight together, see dwconv4_kernel)
+      bool ok[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int yy = Y + (t / 3 - 1) * dil, xx = X + (t % 3 - 1) * dil;
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-          float v[VEC];
-          unpack16<T>(ld16(x + (p + (long)(t / 3 - 1) * dil * W + (t % 3 - 1) * dil) * C + ch * VEC), v);
+        ok[t] = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const long q = ok[t] ? p + (long)(t / 3 - 1) * dil * W + (t % 3 - 1) * dil : p;
+        raw[t] = ld16(x + q * C + ch * VEC);
+      }
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) acc[t][e] += dv[e] * v[e];
-        }
+      for (int t = 0; t < 9; ++t) {
+        float v[VEC];
+        unpack16<T>(raw[t], v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[t][e] = ok[t] ? fmaf(dv[e], v[e], acc[t][e]) : acc[t][e];
       }
     }
   }
@@ -307,10 +329,38 @@ __global__ __launch_bounds__(1024) void easpp_global_fwd_kernel(const float* __r
                                                                 float* __restrict__ rvar, long long* __restrict__ nbt, float* __restrict__ gm,
                                                                 float* __restrict__ gl0, float* __restrict__ glob, float* __restrict__ ss,
                                                                 float* __restrict__ mi, int B, int C, float inv_hw, float eps, float momentum,
-                                                                int training) {
-  extern __shared__ float sm[];   // gm [B][C], then gl0 [B][C]
+                                                                int training, int stage_w) {
+  extern __shared__ float sm[];   // gm [B][C], then gl0 [B][C], then (stage_w) Wg as [C][C + 4]
   float* sl = sm + B * C;
+  float* sW = sl + B * C;
   const int nt = (int)blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+  if (stage_w) {
+    // The cold weight matrix arrives with the pooled sums in ONE memory round trip (16-byte loads by every thread), rows padded by four
+    // floats: a thread then owns one output (image, channel) and walks its weight row and the image's pooled vector with 16-byte LDS
+    // reads (rows of consecutive channels start 4 banks apart: conflict-free; the pooled vector is a broadcast) -- no wave reductions.
+    // The wave-per-output form below spent this single-workgroup kernel in them: 8 outputs x 8 images x 6 cross-lane steps per wave,
+    // 16 waves on one LDS pipe, after one memory round trip per output (32 us; 30 with the weights staged but the reductions kept).
+    const int CP = C + 4;
+    for (int i = threadIdx.x * 4; i < C * C; i += nt * 4) {
+      const int o = i / C, k = i - o * C;
+      *reinterpret_cast<float4*>(sW + o * CP + k) = *reinterpret_cast<const float4*>(Wg + i);
+    }
+    for (int i = threadIdx.x; i < B * C; i += nt) { sm[i] = gsum[i] * inv_hw; gm[i] = sm[i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * C; i += nt) {
+      const int b = i / C, o = i - b * C;
+      const float* wr = sW + o * CP;
+      const float* gv = sm + b * C;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int k = 0; k < C; k += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(wr + k);
+        const float4 g = *reinterpret_cast<const float4*>(gv + k);
+        s0 += w.x * g.x; s1 += w.y * g.y; s2 += w.z * g.z; s3 += w.w * g.w;
+      }
+      const float t = (s0 + s1) + (s2 + s3);
+      sl[i] = t; gl0[i] = t;
+    }
+  } else {
   for (int i = threadIdx.x; i < B * C; i += nt) { sm[i] = gsum[i] * inv_hw; gm[i] = sm[i]; }
   __syncthreads();
   // 1x1 conv: a wave per output channel, lanes stride the input channels (coalesced weight rows), 8 images per pass
@@ -330,6 +380,7 @@ __global__ __launch_bounds__(1024) void easpp_global_fwd_kernel(const float* __r
         if (lane == 0 && b0 + j < B) { sl[(b0 + j) * C + o] = t; gl0[(b0 + j) * C + o] = t; }
       }
     }
+  }
   }
   __syncthreads();
   for (int o = threadIdx.x; o < C; o += nt) {
@@ -363,8 +414,10 @@ __global__ __launch_bounds__(1024) void easpp_global_bwd_kernel(const float* __r
                                                                const float* __restrict__ gamma, const float* __restrict__ mi, float* __restrict__ dwf,
                                                                float* __restrict__ dWg, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ gadd, int B, int C, float inv_hw, int training) {
-  extern __shared__ float sm[];   // dgl0 [B][C]
+  extern __shared__ float sm[];   // dgl0 [B][C], then gm [B][C] (staged: the weight-gradient loop below read it from global memory, B loads per element)
   const int C4 = 4 * C, nt = (int)blockDim.x;
+  float* gml = sm + B * C;
+  for (int i = threadIdx.x; i < B * C; i += nt) gml[i] = gm[i];
   for (int ch = threadIdx.x; ch < C; ch += nt) {
     const int cc = C4 + ch, g = cc / 5;
     const float wv = wf[cc];
@@ -389,11 +442,22 @@ __global__ __launch_bounds__(1024) void easpp_global_bwd_kernel(const float* __r
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * C; i += nt) {
-    const int o = i / C, k = i - o * C;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += sm[b * C + o] * gm[b * C + k];
-    dWg[i] += s;
+  // (read-modify-write of the weight gradient, eight elements per thread at a time: the old values are loaded TOGETHER -- written as
+  // `dWg[i] += s` in a loop the sixteen updates of a thread were sixteen dependent memory round trips, half of this kernel's 34 us)
+  for (int i0 = threadIdx.x; i0 < C * C; i0 += nt * 8) {
+    float old[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int i = i0 + j * nt; old[j] = i < C * C ? dWg[i] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j * nt;
+      if (i < C * C) {
+        const int o = i / C, k = i - o * C;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += sm[b * C + o] * gml[b * C + k];
+        dWg[i] = old[j] + s;
+      }
+    }
   }
   for (int i = threadIdx.x; i < B * C; i += nt) {
     const int b = i / C, k = i - b * C;
@@ -530,8 +594,20 @@ extern "C" int spg_easpp_global_fwd(const float* gsum, const float* Wg, const fl
   SPG_REQUIRE(training || (running_mean && running_var), "easpp_global_fwd: eval mode needs running statistics");
   SPG_REQUIRE(!training || B >= 2, "easpp_global_fwd: train-mode BatchNorm over B values needs B >= 2 (Expected more than 1 value per channel)");
   SPG_REQUIRE((long)B * C <= 8192, "easpp_global_fwd: B * C = %ld exceeds the 64 KiB of LDS the kernel stages (8192 values)", (long)B * C);
-  hipLaunchKernelGGL(easpp_global_fwd_kernel, dim3(1), dim3(1024), (size_t)2 * B * C * sizeof(float), (hipStream_t)stream, gsum, Wg, gamma, beta, running_mean,
-                     running_var, num_batches_tracked, gm, gl0, glob, scale_shift, mean_invstd, B, C, 1.f / (float)HW, eps, momentum, training);
+  // the weight matrix is staged in LDS when it fits beside the two [B][C] arrays (C = 128: 64 KiB + 8 KiB at batch 8)
+  const size_t lds_w = (size_t)C * (C + 4) * sizeof(float), lds_base = (size_t)2 * B * C * sizeof(float);
+  const int stage_w = (C % 4 == 0 && ((uintptr_t)Wg & 15) == 0 && lds_base + lds_w <= 128 * 1024) ? 1 : 0;
+  const size_t lds = lds_base + (stage_w ? lds_w : 0);
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      SPG_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&easpp_global_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024) == hipSuccess,
+                  "easpp_global_fwd: cannot raise the dynamic LDS limit");
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(easpp_global_fwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, gsum, Wg, gamma, beta, running_mean,
+                     running_var, num_batches_tracked, gm, gl0, glob, scale_shift, mean_invstd, B, C, 1.f / (float)HW, eps, momentum, training, stage_w);
   return check_launch("easpp_global_fwd");
 }
 
@@ -539,7 +615,8 @@ extern "C" int spg_easpp_global_bwd(const float* S, const float* glob, const flo
                                     const float* gamma, const float* mean_invstd, float* dwf, float* dWg, float* dgamma, float* dbeta, float* gadd,
                                     int B, int C, long HW, int training, spg_stream_t stream) {
   SPG_REQUIRE(B >= 1 && B <= 64 && C >= 1 && C <= 512, "easpp_global_bwd: B=%d (1..64), C=%d (1..512)", B, C);
-  hipLaunchKernelGGL(easpp_global_bwd_kernel, dim3(1), dim3(1024), (size_t)B * C * sizeof(float), (hipStream_t)stream, S, glob, gl0, gm, wf, Wg, gamma,
+  SPG_REQUIRE((long)B * C <= 8192, "easpp_global_bwd: B * C = %ld exceeds the 64 KiB of LDS the kernel stages (8192 values)", (long)B * C);
+  hipLaunchKernelGGL(easpp_global_bwd_kernel, dim3(1), dim3(1024), (size_t)2 * B * C * sizeof(float), (hipStream_t)stream, S, glob, gl0, gm, wf, Wg, gamma,
                      mean_invstd, dwf, dWg, dgamma, dbeta, gadd, B, C, 1.f / (float)HW, training);
   return check_launch("easpp_global_bwd");
 }

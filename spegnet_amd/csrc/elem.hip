@@ -314,16 +314,44 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ ga
   for (int c = threadIdx.x; c < C; c += 256) g[c] = gap[(long)b * C + c] * in_scale;   // (in_scale = 1 / HW: gap holds column SUMS)
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < R; r += 4) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += w1[(long)r * C + c] * g[c];
-    s = wave_sum(s);
-    if (lane == 0) { h[r] = fmaxf(s, 0.f); hidden[(long)b * R + r] = h[r]; }
+  // (both matrices are cold fp32 master weights: the loads of up to 8 rows are issued together, one memory round trip per 32 rows
+  // instead of one per row -- 30 -> ~12 us for C = 512, R = 32)
+  for (int r0 = wave * 8; r0 < R; r0 += 32) {
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if ((C & 3) == 0) {
+      for (int c = lane * 4; c < C; c += 256) {
+        float4 wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = (r0 + j < R) ? *reinterpret_cast<const float4*>(w1 + (long)(r0 + j) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += wv[j].x * g[c] + wv[j].y * g[c + 1] + wv[j].z * g[c + 2] + wv[j].w * g[c + 3];
+      }
+    } else {
+      for (int c = lane; c < C; c += 64)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (r0 + j < R) s[j] += w1[(long)(r0 + j) * C + c] * g[c];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = wave_sum(s[j]);
+      if (lane == 0 && r0 + j < R) { h[r0 + j] = fmaxf(t, 0.f); hidden[(long)b * R + r0 + j] = h[r0 + j]; }
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += w2[(long)c * R + r] * h[r];
+    if ((R & 3) == 0) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int r = 0; r < R; r += 4) {
+        const float4 wv = *reinterpret_cast<const float4*>(w2 + (long)c * R + r);
+        s0 += wv.x * h[r]; s1 += wv.y * h[r + 1]; s2 += wv.z * h[r + 2]; s3 += wv.w * h[r + 3];
+      }
+      s = (s0 + s1) + (s2 + s3);
+    } else {
+      for (int r = 0; r < R; ++r) s += w2[(long)c * R + r] * h[r];
+    }
     scale[(long)b * C + c] = sigmoid_f(s);
   }
 }
@@ -370,17 +398,25 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* __restrict
     for (int i = threadIdx.x; i < nb * C; i += nt) { l_dz[i] = gdz[(long)b0 * C + i]; l_gap[i] = gap[(long)b0 * C + i] * in_scale; }
     for (int i = threadIdx.x; i < nb * R; i += nt) { l_dh[i] = gdh[(long)b0 * R + i]; l_hid[i] = hidden[(long)b0 * R + i]; }
     __syncthreads();
-    for (int i = threadIdx.x; i < C * R; i += nt) {          // dw2 [C][R]: consecutive threads, consecutive r
-      const int c = i / R, r = i - c * R;
-      float s2 = 0.f;
-      for (int bb = 0; bb < nb; ++bb) s2 += l_dz[bb * C + c] * l_hid[bb * R + r];
-      dw2[i] += s2;
-    }
-    for (int i = threadIdx.x; i < C * R; i += nt) {          // dw1 [R][C]: consecutive threads, consecutive c
-      const int r = i / C, c = i - r * C;
-      float s1 = 0.f;
-      for (int bb = 0; bb < nb; ++bb) s1 += l_dh[bb * R + r] * l_gap[bb * C + c];
-      dw1[i] += s1;
+    // (the old gradient values of eight elements per thread are loaded together: `dw[i] += s` in a loop is one memory round trip per element)
+    for (int i0 = threadIdx.x; i0 < C * R; i0 += nt * 8) {   // dw2 [C][R]: consecutive threads, consecutive r
+      float o2[8], o1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int i = i0 + j * nt; o2[j] = i < C * R ? dw2[i] : 0.f; o1[j] = i < C * R ? dw1[i] : 0.f; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * nt;
+        if (i < C * R) {
+          const int c = i / R, r = i - c * R;
+          float s2 = 0.f;
+          for (int bb = 0; bb < nb; ++bb) s2 += l_dz[bb * C + c] * l_hid[bb * R + r];
+          dw2[i] = o2[j] + s2;
+          const int r1 = i / C, c1 = i - r1 * C;             // dw1 [R][C]: consecutive threads, consecutive c
+          float s1 = 0.f;
+          for (int bb = 0; bb < nb; ++bb) s1 += l_dh[bb * R + r1] * l_gap[bb * C + c1];
+          dw1[i] = o1[j] + s1;
+        }
+      }
     }
   }
 }

@@ -9,6 +9,9 @@ namespace spg {
 // LayerNorm: one wave per row, row cached in registers (<= MAXCH 16-byte chunks per lane).
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_MAXCH = 5;
+#ifndef SPG_LN_HOIST      // bit 0: layernorm_bwd requests dres with the row -- measured level (21.90 vs 21.88 ms per step, same box), off
+#define SPG_LN_HOIST 0
+#endif
 
 // RW = rows per wave: with many short rows (stages 1 and 2: 73728 x 144, 18432 x 288 at batch 8) one row per wave keeps only 288-576 bytes
 // in flight per wave -- a launch bound by memory latency at a third of the HBM rate.  A wave then takes RW consecutive rows, requests all of
@@ -85,6 +88,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   if (row0 >= M) return;
   const int nch = C / VEC;
   float xv[RW][NI][VEC], dv[RW][NI][VEC];
+#if SPG_LN_HOIST & 1
+  u32x4 dr[RW][NI];      // the residual gradient requested WITH the row (it is as cold as dy: loaded in the last loop it was one more trip to HBM)
+#endif
 #pragma unroll
   for (int r = 0; r < RW; ++r)
 #pragma unroll
@@ -93,6 +99,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       if (ch < nch && row0 + r < M) {
         unpack16<T>(ld16(x + (long)(row0 + r) * C + ch * VEC), xv[r][i]);
         unpack16<T>(ld16(dy + (long)(row0 + r) * C + ch * VEC), dv[r][i]);
+#if SPG_LN_HOIST & 1
+        if (dres) dr[r][i] = ld16(dres + (long)(row0 + r) * C + ch * VEC);
+#endif
       }
     }
 #pragma unroll
@@ -122,7 +131,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       const int ch = lane + 64 * i;
       if (ch < nch) {
         float o[VEC];
+#if SPG_LN_HOIST & 1
+        if (dres) unpack16<T>(dr[r][i], o);
+#else
         if (dres) unpack16<T>(ld16(dres + (long)row * C + ch * VEC), o);
+#endif
         else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) o[e] = 0.f;
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
 }
 
 struct RedPlan { int nchs, nslabs, gx; long rpb; };
-static inline RedPlan red_plan(long rows, int nch, int nimg, int rows_per_thread = SPG_RED_ROWS_PER_THREAD) {
+static inline RedPlan red_plan_rpt(long rows, int nch, int nimg, int rows_per_thread) {
   RedPlan p;
   p.nchs = nch < RED_SLAB_CHUNKS ? nch : RED_SLAB_CHUNKS;
   p.nslabs = cdiv(nch, p.nchs);
@@ -307,6 +320,19 @@ static inline RedPlan red_plan(long rows, int nch, int nimg, int rows_per_thread
   p.rpb = (rows + want - 1) / want;
   if (p.rpb < rpar) p.rpb = rpar;
   p.gx = cdiv(rows, p.rpb);
+  return p;
+}
+// 32 rows per thread suit the large reductions (few partials: the last workgroup's fixed-order finish stays short).  Halving them until the
+// launch has 512 workgroups was measured on every user: the BatchNorm statistics / backward reductions of the head got SLOWER (58.8 -> 83.5 us
+// over five launches, 202 -> 238 us over seven: the finish grows with the partials), only the per-image product of the SE backward (8 images
+// x 4 slabs x 4 row blocks = 128 workgroups) gained (24.4 -> 15.0 us): `spread` is set for that mode alone.
+static inline RedPlan red_plan(long rows, int nch, int nimg, int rows_per_thread = SPG_RED_ROWS_PER_THREAD, bool spread = false) {
+  RedPlan p = red_plan_rpt(rows, nch, nimg, rows_per_thread);
+  const int ni = nimg > 0 ? nimg : 1;
+  while (spread && rows_per_thread > 4 && (long)p.gx * ni * p.nslabs < 512) {
+    rows_per_thread /= 2;
+    p = red_plan_rpt(rows, nch, nimg, rows_per_thread);
+  }
   return p;
 }
 // upper bounds (any row count) of the scratch a column reduction over C channels / nimg images needs: partial floats, counters
@@ -335,7 +361,7 @@ static int launch_colreduce(const void* a, const void* b, const float* p0, const
   }
   const long rows = img_rows > 0 ? img_rows : M;
   // (partial rows from a producer's epilogue are few -- 1-5 k rows: a short per-thread loop and more blocks, or two blocks would walk them)
-  const RedPlan p = MODE == RED_PRESUM ? red_plan(rows, C / VEC, nimg, 4) : red_plan(rows, C / VEC, nimg);
+  const RedPlan p = MODE == RED_PRESUM ? red_plan(rows, C / VEC, nimg, 4) : red_plan(rows, C / VEC, nimg, SPG_RED_ROWS_PER_THREAD, MODE == RED_PROD);
   const int ni = nimg > 0 ? nimg : 1;
   constexpr bool TWO = (MODE == RED_SUM_SQ || MODE == RED_BN_BWD || MODE == RED_LN || MODE == RED_PRESUM);
   const long need = (long)p.gx * ni * p.nslabs * (TWO ? 2 : 1) * p.nchs * VEC;

@@ -78,7 +78,9 @@ class TrainStep:
         self.model.engine.fold_sumsq = self.sync is None and self.fold_sumsq
         out = self.model(images)
         losses = self.criterion.forward_batched(out['predictions'], out['edge'], masks, edges)
-        losses['loss'].backward()
+        if getattr(self, "_one", None) is None:       # the root gradient, kept: backward() without it fills a fresh ones_like every step
+            self._one = torch.ones((), dtype=torch.float32, device=images.device)
+        losses['loss'].backward(self._one)
         return {k: v.detach() for k, v in losses.items()}
 
     def _opt(self, scale: float):

@@ -11,9 +11,24 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import ctypes
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+# one launch for the four maps' reductions and two for their gradients (csrc/loss.hip: *_all) instead of four and seven; the per-map
+# entry points stay (tests compare the two bit for bit)
+BATCHED_LAUNCHES = os.environ.get("SPG_LOSS_BATCHED", "1") != "0"
+
+
+def _ptrs(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _ints(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
 
 
 class _FusedCODLoss(torch.autograd.Function):
@@ -36,20 +51,27 @@ class _FusedCODLoss(torch.autograd.Function):
         buf = torch.empty(B * 4 + 4 * B * 3 + 3, dtype=torch.float32, device=dev)
         stats, seg_sums, edge_sums, out = buf[:B * 4], buf[B * 4:B * 4 + 9 * B], buf[B * 13:B * 16], buf[B * 16:]
         wmap = torch.empty((B, S, S), dtype=torch.float32, device=dev)
-        nws = _lib.load().spg_loss_workspace_floats(B, S)
-        ws = ops.red_scratch(dev, nws)   # the five launches are stream-ordered: one scratch serves them all
+        lib = _lib.load()
+        nws = max(lib.spg_loss_workspace_floats(B, S), lib.spg_loss_reduce_all_workspace_floats(B))
+        ws = ops.red_scratch(dev, nws)   # the launches are stream-ordered: one scratch serves them all
         _lib.call("spg_loss_weight_map", masks.data_ptr(), edges.data_ptr(), wmap.data_ptr(), stats.data_ptr(), B, S, float(bw),
                   ws.data_ptr(), nws, ops.red_counters(dev, B), st)
-        for i in range(3):
-            h, w = preds[i].shape[-2:]
-            _lib.call("spg_loss_reduce", dt, preds[i].data_ptr(), masks.data_ptr(), wmap.data_ptr(), stats.data_ptr(),
-                      seg_sums[i * 3 * B:].data_ptr(), B, S, h, w, 0, 0.0, 0.0, ws.data_ptr(), nws, ops.red_counters(dev, B), st)
-        h, w = preds[3].shape[-2:]
-        _lib.call("spg_loss_reduce", dt, preds[3].data_ptr(), edges.data_ptr(), None, stats.data_ptr(), edge_sums.data_ptr(), B, S, h, w,
-                  1, float(alpha), float(gamma), ws.data_ptr(), nws, ops.red_counters(dev, B), st)
+        if BATCHED_LAUNCHES:             # the four maps' reductions side by side in one launch (same blocks per map: same sums)
+            _lib.call("spg_loss_reduce_all", dt, _ptrs(preds), _ints([p.shape[-2] for p in preds]), _ints([p.shape[-1] for p in preds]),
+                      masks.data_ptr(), edges.data_ptr(), wmap.data_ptr(), stats.data_ptr(), seg_sums.data_ptr(), edge_sums.data_ptr(), B, S,
+                      float(alpha), float(gamma), ws.data_ptr(), nws, ops.red_counters(dev, 4 * B), st)
+        else:
+            for i in range(3):
+                h, w = preds[i].shape[-2:]
+                _lib.call("spg_loss_reduce", dt, preds[i].data_ptr(), masks.data_ptr(), wmap.data_ptr(), stats.data_ptr(),
+                          seg_sums[i * 3 * B:].data_ptr(), B, S, h, w, 0, 0.0, 0.0, ws.data_ptr(), nws, ops.red_counters(dev, B), st)
+            h, w = preds[3].shape[-2:]
+            _lib.call("spg_loss_reduce", dt, preds[3].data_ptr(), edges.data_ptr(), None, stats.data_ptr(), edge_sums.data_ptr(), B, S, h, w,
+                      1, float(alpha), float(gamma), ws.data_ptr(), nws, ops.red_counters(dev, B), st)
         _lib.call("spg_loss_finalize", stats.data_ptr(), seg_sums.data_ptr(), edge_sums.data_ptr(), out.data_ptr(), B, S, float(sw[0]),
                   float(sw[1]), float(sw[2]), float(bce_w), float(iou_w), float(edge_w), st)
         ctx.saved = (preds, masks, edges, wmap, stats, seg_sums, edge_sums, cfg, dt)
+        ctx.set_materialize_grads(False)     # (seg_loss / edge_loss are reported, not differentiated: no zero-filled gradients for them)
         return out[0], out[1], out[2]
 
     @staticmethod
@@ -60,6 +82,16 @@ class _FusedCODLoss(torch.autograd.Function):
         B, S = masks.shape[0], masks.shape[-1]
         st = torch.cuda.current_stream().cuda_stream
         go = g_loss.float().contiguous() if g_loss is not None else None
+        if g_loss is None:
+            return (None,) * 7
+        if BATCHED_LAUNCHES:             # two launches: dL/dz of every full-res pixel of the four maps, then the bilinear adjoints
+            dz = torch.empty((4, B, S, S), dtype=torch.float32, device=masks.device)
+            grads = [torch.empty_like(p) for p in preds]
+            coefs = (ctypes.c_float * 4)(float(sw[0]) / B, float(sw[1]) / B, float(sw[2]) / B, float(edge_w) / B)
+            _lib.call("spg_loss_grad_all", dt, _ptrs(preds), _ptrs(grads), _ints([p.shape[-2] for p in preds]), _ints([p.shape[-1] for p in preds]),
+                      coefs, masks.data_ptr(), edges.data_ptr(), wmap.data_ptr(), stats.data_ptr(), seg_sums.data_ptr(), edge_sums.data_ptr(),
+                      go.data_ptr(), B, S, float(bce_w), float(iou_w), float(alpha), float(gamma), dz.data_ptr(), st)
+            return grads[0], grads[1], grads[2], grads[3], None, None, None
         dz = torch.empty((B, S, S), dtype=torch.float32, device=masks.device)   # scratch of the two-pass gradient (stream-ordered reuse)
         grads = []
         for i in range(3):

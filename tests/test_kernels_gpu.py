@@ -910,6 +910,38 @@ def test_fused_codloss_matches_torch_formula(dt, case):
         assert abs(float(out["loss"]) - float(o["loss"])) < 2e-5 * max(1.0, abs(float(o["loss"])))
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,S,divs,ediv", [(3, 64, (4, 2, 1), 8), (2, 96, (2, 2, 1), 4), (1, 32, (1, 1, 1), 1), (8, 384, (4, 2, 1), 8)])
+def test_fused_codloss_all_maps_launches_equal_per_map_launches(dt, B, S, divs, ediv, monkeypatch):
+    """spg_loss_reduce_all / spg_loss_grad_all (the four maps of the loss per launch) against the per-map entry points: same blocks per
+    map and the same fixed-order finish, so the loss terms and the gradients of every coarser map must be IDENTICAL; maps already at the
+    target's resolution are written by the first gradient pass (last-bit differences, see below).  Includes the step's own shapes
+    (batch 8 @384)."""
+    from spegnet_amd.utils import loss_functions as LF
+    g = torch.Generator().manual_seed(11)
+    preds = [(torch.randn(B, 1, S // d, S // d, generator=g) * 2).cuda().to(dt) for d in divs]
+    edge = (torch.randn(B, 1, S // ediv, S // ediv, generator=g) * 2).cuda().to(dt)
+    masks = (torch.rand(B, 1, S, S, generator=g) > 0.7).float().cuda()
+    edges = (torch.rand(B, 1, S, S, generator=g) > 0.95).float().cuda()
+    crit = LF.CODLoss().cuda()
+    res = []
+    for batched in (False, True):
+        monkeypatch.setattr(LF, "BATCHED_LAUNCHES", batched)
+        leaves = [p.clone().requires_grad_(True) for p in preds + [edge]]
+        out = crit.forward_batched(leaves[:3], leaves[3], masks, edges)
+        (out["loss"] * 0.75).backward()
+        res.append(([out[k].clone() for k in ("loss", "seg_loss", "edge_loss")], [l.grad.clone() for l in leaves]))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b), (float(a), float(b))
+    for i, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+        if a.shape[-1] == S:     # a map at the target's resolution: the per-map path runs loss_grad_kernel, a different instruction stream for
+            # the same formula (fused multiply-adds contract differently): last-bit differences, at most one rounding step of the type
+            torch.testing.assert_close(a.float(), b.float(), rtol=1e-5 if dt == torch.float32 else 8e-3, atol=1e-12)
+        else:
+            assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 9, 33, 64, 64), (3, 17, 31, 128, 320), (2, 48, 48, 256, 64), (8, 96, 96, 64, 128)])
 def test_conv3x3_fwd_stats_matches_conv_then_bn_stats(ops, B, H, W, Ci, Co):
     """The fused launch (halo-tile convolution whose epilogue writes per-tile BatchNorm partial sums) + bn_stats_finalize_part: the
