@@ -175,7 +175,8 @@ def main():
                 model(images)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            from spegnet_amd.engine.distributed import graph_capture_mode
+            with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):     # (N > 1: RCCL's watchdog thread must stay legal during capture)
                 out = model(images)
             for _ in range(max(args.warmup, 1)):
                 graph.replay()

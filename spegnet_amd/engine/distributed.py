@@ -22,7 +22,9 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # SPG_DIST_FORCE_INIT=1: a process group even for one rank (tests/test_distributed_gpu.py runs the N > 1 step's choreography -- RCCL
+    # collectives between captured graph segments -- on the one GPU a test box has; see GradSync(force=True))
+    if (world > 1 or os.environ.get("SPG_DIST_FORCE_INIT") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -38,6 +40,15 @@ def init_process_group_from_env(device_type: str = "cuda") -> Tuple[int, int, in
             torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def graph_capture_mode() -> str:
+    """capture_error_mode for torch.cuda.graph.  With a process group alive, ProcessGroupNCCL's watchdog THREAD polls the events of
+    outstanding collectives (hipEventQuery); under the default "global" mode any such call by any thread while a stream captures is an
+    error -- the watchdog dies with "operation not permitted when stream is capturing" and takes the process with it (found by the
+    one-rank RCCL rehearsal, tests/test_distributed_gpu.py; gloo has no such thread).  "thread_local" restricts the check to the
+    capturing thread."""
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
 
 
 # CUs left to the GEMM grids while a gradient all-reduce is in flight (the other 16 go to RCCL's channels)
@@ -63,9 +74,12 @@ class GradSync:
     mode never rounds its gradients silently."""
 
     def __init__(self, grad_flat: torch.Tensor, unit_ends: List[int], bucket_mb: float = 48.0, group=None,
-                 compress_bf16: bool = True):
+                 compress_bf16: bool = True, force: bool = False):
         self.g = grad_flat
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # collectives are issued when there is more than one rank -- or when `force` asks for them on a one-rank group (a rehearsal: the
+        # sum over one rank is the identity, but every RCCL call, stream hand-over and staging cast of the N > 1 step executes)
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         self.group = group
         self.buckets = make_buckets(unit_ends, int(bucket_mb * 1024 * 1024 / 4))
         self.compress = compress_bf16
@@ -81,7 +95,7 @@ class GradSync:
 
     def ready(self, upto: int):
         """Gradients in [0, upto) are final: launch every not-yet-launched bucket that ends at or before `upto`."""
-        if self.world == 1:
+        if not self.active:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][1] <= upto:
             s, e = self.buckets[self._next]
@@ -117,7 +131,7 @@ class GradSync:
 
     def finish(self):
         """All buckets launched and complete w.r.t. the current stream; returns the grad scale 1/world."""
-        if self.world > 1:
+        if self.active:
             self.ready(self.buckets[-1][1])
             if self.cuda:
                 torch.cuda.current_stream().wait_stream(self.stream)

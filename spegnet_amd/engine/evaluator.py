@@ -25,6 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from ..models.spegnet import SPEGNet
+from .distributed import graph_capture_mode
 from ..utils.metrics import MetricsProcessor
 
 METRIC_KEYS = ('s_alpha', 'weighted_f', 'mae', 'e_phi', 'mean_f')
@@ -84,7 +85,7 @@ class Evaluator:
                     self.model(self._static_x)
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
+                with torch.cuda.graph(self._graph, capture_error_mode=graph_capture_mode()):
                     self._static_out = self.model(self._static_x)
         self._static_x.copy_(images)
         self._graph.replay()

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from PIL import Image
 
 from ..models.spegnet import SPEGNet
+from .distributed import graph_capture_mode
 from ..utils.image_processor import CODImageProcessor
 
 
@@ -116,7 +117,7 @@ class Predictor:
                     self.model(self._static_x)                 # warm-up off the capture stream (allocator, lazy init)
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
+                with torch.cuda.graph(self._graph, capture_error_mode=graph_capture_mode()):
                     self._static_out = self.model(self._static_x)
         self._static_x.copy_(x)
         self._graph.replay()

@@ -24,7 +24,7 @@ from .. import ops
 from ..models.spegnet import SPEGNet
 from ..utils.loss_functions import CODLoss
 from .arena import Arena
-from .distributed import COMM_CU_BUDGET, GradSync
+from .distributed import COMM_CU_BUDGET, GradSync, graph_capture_mode
 
 logger = logging.getLogger(__name__)
 
@@ -54,6 +54,7 @@ class TrainStep:
         self.static = None
         self.losses = None
         self.world = sync.world if sync is not None else 1
+        self.comm = sync is not None and sync.active     # collectives are issued (more than one rank, or a forced one-rank rehearsal)
         self.fold_sumsq = os.environ.get("SPG_FOLD_SUMSQ", "1") != "0"     # (A/B runs: tools/ab_env.sh)
         self._graph_unzeroed = frozenset()
         # forked weight-gradient stream (models/engine.py; `TrainStep(..., wgrad_async=True)` for A/B runs): measured SLOWER on one MI355X
@@ -101,7 +102,7 @@ class TrainStep:
 
     def _step_split(self, images, masks, edges):
         losses = self._fwd_bwd(images, masks, edges)
-        if self.world > 1:
+        if self.comm:
             self._allreduce_flat()
         self._opt(1.0 / self.world)
         return losses
@@ -151,7 +152,7 @@ class TrainStep:
             for (l2, h2, _) in rest:
                 eng.trunk_bwd_blocks(l2, h2)
             eng.trunk_bwd_end()
-            if self.world > 1:
+            if self.comm:
                 self._allreduce_flat()
             self._opt(1.0 / self.world)
             return losses
@@ -172,21 +173,21 @@ class TrainStep:
         self.segments = []
         # CU budget per segment (grid sizes are frozen at capture): the first segment and the optimizer run with no collective in
         # flight -> all CUs; segments 2.. replay while the previous range is being all-reduced -> leave RCCL its CUs
-        comm_cus = COMM_CU_BUDGET if (self.world > 1 or self.force_segmented) else 0
+        comm_cus = COMM_CU_BUDGET if (self.comm or self.force_segmented) else 0
         g0 = torch.cuda.CUDAGraph()
-        with ops.cu_budget(0), torch.cuda.graph(g0):
+        with ops.cu_budget(0), torch.cuda.graph(g0, capture_error_mode=graph_capture_mode()):
             self.losses = self._seg_first(*self.static, plan[0][0], plan[0][1])
         self.segments.append(g0)
         pool = g0.pool()
         for k, (lo, hi, _) in enumerate(plan[1:], start=1):
             g = torch.cuda.CUDAGraph()
-            with ops.cu_budget(comm_cus), torch.cuda.graph(g, pool=pool):
+            with ops.cu_budget(comm_cus), torch.cuda.graph(g, pool=pool, capture_error_mode=graph_capture_mode()):
                 eng.trunk_bwd_blocks(lo, hi)
                 if k == len(plan) - 1:
                     eng.trunk_bwd_end()
             self.segments.append(g)
         self.graph_b = torch.cuda.CUDAGraph()
-        with ops.cu_budget(0), torch.cuda.graph(self.graph_b, pool=pool):
+        with ops.cu_budget(0), torch.cuda.graph(self.graph_b, pool=pool, capture_error_mode=graph_capture_mode()):
             self._opt(1.0 / self.world)
         self._plan = plan
         self.graph = g0
@@ -200,7 +201,7 @@ class TrainStep:
             ev = torch.cuda.Event()
             ev.record(main)
             self.comm_stream.wait_event(ev)
-            if self.world > 1:
+            if self.comm:
                 with torch.cuda.stream(self.comm_stream):
                     self.sync.reduce_range(start, end)     # bf16 payload by default (GradSync)
             start = end
@@ -228,13 +229,13 @@ class TrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         if self.world == 1:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=graph_capture_mode()):
                 self.losses = self._eager(*self.static)
         else:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=graph_capture_mode()):
                 self.losses = self._fwd_bwd(*self.static)
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode=graph_capture_mode()):
                 self._opt(1.0 / self.world)
 
     def __call__(self, images: torch.Tensor, masks: torch.Tensor, edges: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -246,13 +247,13 @@ class TrainStep:
         if self.graph is None:
             err = None
             try:
-                if self.world > 1 or self.force_segmented:
+                if self.comm or self.force_segmented:
                     self._capture_segmented(images, masks, edges)
                 else:
                     self._capture(images, masks, edges)
             except Exception as e:      # noqa: BLE001 -- re-raised below unless every rank agrees to run eagerly
                 err = e
-            if self.world > 1:
+            if self.comm:
                 # ranks must take the same path: a rank that fell back to eager launches alone would issue bucketed all-reduces while
                 # its peers issue the segment-range ones (a hang, not an error).  Every rank has run the same warm-up collectives by
                 # now, so one MIN all-reduce of the outcome is in step on all of them.

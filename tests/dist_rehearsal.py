@@ -44,12 +44,13 @@ def main():
     batches = [O.synthetic_batch(2, 64, seed=80 + r) if large else O.synthetic_batch(4, 128, seed=80 + r) for r in range(world)]
     dev = lambda b: (b[0].cuda(), torch.stack(b[1]).cuda(), torch.stack(b[2]).cuda())
     m, ar = fresh()
-    sync = GradSync(ar.g, ar.unit_ends, compress_bf16=(payload == "bf16"))
+    # (one rank with a forced process group: the RCCL rehearsal of test_distributed_gpu.py -- every collective of the N > 1 step runs)
+    sync = GradSync(ar.g, ar.unit_ends, compress_bf16=(payload == "bf16"), force=(world == 1))
     step = TrainStep(m, CODLoss().cuda(), ar, grad_clip=1.0, sync=sync, capture=(mode == "graph"))
     out = step(*dev(batches[rank]))
     torch.cuda.synchronize()
     res = {"rank": rank, "mode": mode, "payload": payload, "variant": variant, "loss": float(out["loss"]), "gnorm": float(ar.gnorm_sq.sqrt()),
-           "segments": len(step.segments) if step.segments else 0}
+           "segments": len(step.segments) if step.segments else 0, "backend": dist.get_backend(), "collectives": bool(step.comm)}
     # every rank must hold the same parameters after the step
     p = ar.p.detach().clone()
     allp = [torch.empty_like(p) for _ in range(world)]

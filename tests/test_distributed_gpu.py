@@ -21,12 +21,12 @@ def _free_port():
     return p
 
 
-def _run(mode, payload, world=2, variant="tiny"):
+def _run(mode, payload, world=2, variant="tiny", backend="gloo"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   SPG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   SPG_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", SPG_DIST_FORCE_INIT="1" if world == 1 else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_rehearsal.py"), mode, payload, variant], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -73,3 +73,19 @@ def test_two_rank_step_bf16_compute_hiera_large_block_table():
     assert r0["loss"] == r0["loss"]
     assert r0["frac_updates_differ"] < 0.10, res
     assert abs(r0["gnorm"] / 2 - r0["gnorm_ref"]) < 3e-2 * r0["gnorm_ref"], res
+
+
+@pytest.mark.parametrize("mode,payload,variant", [("graph", "bf16", "large"), ("graph", "fp32", "tiny"), ("eager", "bf16", "tiny")])
+def test_one_rank_rccl_executes_the_multi_gpu_choreography(mode, payload, variant):
+    """RCCL itself (backend "nccl"), on the one GPU a test box has: a ONE-rank process group with GradSync(force=True), so the step
+    issues every collective of the N > 1 path -- the per-segment all-reduces on the communication stream between hipGraph replays, the
+    bf16 staging casts, the capture-outcome agreement -- through RCCL.  The sum over one rank is the identity: the parameters must
+    equal a plain single-GPU step's (within the bf16 payload's rounding)."""
+    res = _run(mode, payload, world=1, variant=variant, backend="nccl")
+    r0 = res[0]
+    assert r0["backend"] == "nccl" and r0["collectives"], r0
+    if mode == "graph":
+        assert r0["segments"] >= 4, r0
+    assert r0["loss"] == r0["loss"]
+    assert r0["frac_updates_differ"] < (0.02 if payload == "fp32" else 0.10), r0
+    assert abs(r0["gnorm"] - r0["gnorm_ref"]) < (2e-3 if payload == "fp32" else 3e-2) * r0["gnorm_ref"], r0
