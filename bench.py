@@ -149,7 +149,13 @@ def main():
     ap.add_argument("--infer", action="store_true",
                     help="BASELINE config 3 instead of the train step: eval-mode forward under one hipGraph (use --batch 64); "
                          "not the headline metric, never the default")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="one GPU, the N > 1 step: a one-rank RCCL process group with every collective of the multi-GPU step issued "
+                         "(segmented hipGraphs, per-range all-reduce on the communication stream, bf16 staging casts); measures what the "
+                         "structure itself costs before any link is involved.  Not the headline metric, never the default")
     args = ap.parse_args()
+    if args.rehearse_comm:
+        os.environ["SPG_DIST_FORCE_INIT"] = "1"
 
     from spegnet_amd.engine.distributed import GradSync, init_process_group_from_env
     rank, world, local = init_process_group_from_env("cuda")
@@ -212,7 +218,7 @@ def main():
     arena.set_hyper(1e-4, 1e-5, 0.05)                      # configs/default.yaml:25-28 of the reference
     crit = CODLoss(scale_weights=[0.2, 0.3, 0.5], boundary_weight=2.0, bce_weight=1.25, iou_weight=1.0, edge_weight=0.75,
                    edge_focal_alpha=0.75, edge_focal_gamma=2.0).to(dev)  # configs/default.yaml:34-43
-    sync = GradSync(arena.g, arena.unit_ends) if world > 1 else None
+    sync = GradSync(arena.g, arena.unit_ends, force=args.rehearse_comm) if (world > 1 or args.rehearse_comm) else None
     step = TrainStep(model, crit, arena, grad_clip=1.0, sync=sync, capture=not args.no_graph)
     images, masks, edges = synthetic(args.batch, args.size, dev, seed=1000 * rank)
 
@@ -253,7 +259,7 @@ def main():
     # ---- roofline leg: the dominant kernel (gemm_nt, bf16 dense MFMA GEMM) timed with HIP events on its own stream over
     #      instrumented eager steps run right after the timed region (hipGraph replays cannot carry per-kernel events).
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not args.rehearse_comm:
         eager = TrainStep(model, crit, arena, grad_clip=1.0, sync=None, capture=False) if world == 1 else None
         if eager is not None:
             # Eager launches are host-bound: without help the GPU idles between kernels and each start event fires long before
@@ -309,7 +315,7 @@ def main():
                     "kernels": rows}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse_comm:
         cpu = cpu_baseline()
 
     if rank == 0:
@@ -322,12 +328,12 @@ def main():
             "config": {"workload": f"SPEGNet (Hiera-L trunk + CFI + EFE + PED) train step: fwd + CODLoss + bwd + clip + AdamW, "
                                    f"batch {args.batch}/GPU @{args.size}x{args.size}, random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
-                       "launch": "eager, bucketed all-reduce overlapped with backward" if args.no_graph else ("hipGraph" if world == 1 else f"hipGraph segments (fwd+loss+bwd in {getattr(step, 'n_segments', 8)} pieces) with RCCL all-reduce (bf16 payload) of finished gradient ranges on a side stream | hipGraph optimizer"),
-                       "final_loss": round(loss_val, 5)},
+                       "launch": "eager, bucketed all-reduce overlapped with backward" if args.no_graph else ("hipGraph" if (world == 1 and not args.rehearse_comm) else f"hipGraph segments (fwd+loss+bwd in {getattr(step, 'n_segments', 8)} pieces) with RCCL all-reduce (bf16 payload) of finished gradient ranges on a side stream | hipGraph optimizer"),
+                       "final_loss": round(loss_val, 5), **({"rehearsal": "one-rank RCCL group, every collective of the N > 1 step issued"} if args.rehearse_comm else {})},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.rehearse_comm:
         torch.distributed.destroy_process_group()
 
 

@@ -294,12 +294,21 @@ class Engine:
         """Share of the (workgroup, round) slots that own a block when `total` blocks run on `cus` CUs."""
         return total / float(-(-total // cus) * cus)
 
+    @staticmethod
+    def _wg_cus():
+        """(CUs a whole-block launch may fill, the round fill a pending set must reach to go out as one)"""
+        budget = ops.cu_budget_now()
+        return (budget, 0.65) if budget else (ops.num_cus(), 0.75)
+
     def queue_block_wgrads(self, jobs) -> None:
         """One trunk block's wgrad jobs.  Problems outside the whole-block kernel's domain go out now (grouped tile kernel); the others
         join the pending set of their row count M and wait until the set fills whole rounds of CUs.  (A transition block has problems
         with two different M: each part joins its own set -- block 44's M = 4608 part rides with the first stage-3 blocks.)"""
-        use = self.block_wgrads and self.unit_cb is None and not self.wgrad_async and ops.cu_budget_now() == 0
-        # (not under a CU budget -- graph segments that replay beside a collective: 84-block sets no longer fill whole rounds of 240 CUs)
+        use = self.block_wgrads and self.unit_cb is None and not self.wgrad_async
+        # Under a CU budget (graph segments that replay beside a collective: 240 of 256 CUs) a stage-3 trunk block's 84 blocks fill whole
+        # rounds worse -- two trunk blocks are 168 of 240 (0.70), three would spill 12 blocks into a second round -- but falling back to the
+        # grouped tile kernel for all of them cost the N > 1 step 1.3 ms (one-rank RCCL rehearsal: 3.08 ms of gemm_tn_group4 in 44 launches
+        # where the single-GPU step has 0.73 in 11, profiles/round4_multi_gpu_rehearsal.md): the fill a set must reach is lowered instead.
         by_m, now = {}, []
         for j in jobs:
             M = j[0].shape[0]
@@ -309,13 +318,13 @@ class Engine:
                 now.append(j)
         if now:
             self._issue_block_wgrads(now)
-        cus = ops.num_cus()
+        cus, need = self._wg_cus()
         for M, part in by_m.items():
             cnt = ops.tn_blocks_count(part)
             pend = self._wg_pending.setdefault(M, [])
             total = sum(c for _, c in pend)
             if pend and (sum(len(j) for j, _ in pend) + len(part) > ops.TN_BLOCKS_MAX or
-                         (self._round_fill(total + cnt, cus) < self._round_fill(total, cus) and self._round_fill(total, cus) >= 0.75)):
+                         (self._round_fill(total + cnt, cus) < self._round_fill(total, cus) and self._round_fill(total, cus) >= need)):
                 self._flush_pending(M)       # the set is as full as it gets: another trunk block would open a nearly empty round
                 pend = self._wg_pending.setdefault(M, [])
             pend.append((part, cnt))
@@ -326,7 +335,8 @@ class Engine:
         pend = self._wg_pending.pop(M, [])
         if not pend:
             return
-        if self._round_fill(sum(c for _, c in pend), ops.num_cus()) >= 0.75:
+        cus, need = self._wg_cus()
+        if self._round_fill(sum(c for _, c in pend), cus) >= need:
             jobs = [j for jobs, _ in pend for j in jobs]
             if self.fold_sumsq:
                 self._sq_parts.append(ops.gemm_tn_blocks(jobs, overwrite=True, want_sq=True))

@@ -73,16 +73,35 @@ def test_hiera_l_batch8_grouping(eng):
     assert sum(n for _, n, _ in log) == 3 * 4 + 5 + 35 * 4 + 5 + 5 * 4
 
 
-def test_no_deferral_under_a_cu_budget_or_callback(eng):
+def test_no_deferral_under_a_callback(eng):
     e, log, fake = eng
-    fake.cu_budget_now = lambda: 240
-    for _ in range(3):
-        e.queue_block_wgrads(_block(4608, S3))
-    assert [x[0] for x in log] == ["tiles"] * 3 and e._wg_pending == {}
-    fake.cu_budget_now = lambda: 0
     e.unit_cb = lambda u: None
     e.queue_block_wgrads(_block(4608, S3))
-    assert [x[0] for x in log] == ["tiles"] * 4 and e._wg_pending == {}
+    assert [x[0] for x in log] == ["tiles"] and e._wg_pending == {}
+
+
+def test_pairs_of_trunk_blocks_under_a_cu_budget(eng):
+    """Graph segments of the N > 1 step replay beside a collective with 240 CUs: the sets are sized for 240 (two stage-3 trunk blocks =
+    168 blocks, 0.70 of one round; a third would spill 12 blocks into a second round) and still go out as whole-block launches -- a
+    segment's six stage-3 blocks are three launches, none falls back to the tile kernel."""
+    e, log, fake = eng
+    fake.cu_budget_now = lambda: 240
+    for _ in range(6):
+        e.queue_block_wgrads(_block(4608, S3))
+    e.flush_block_wgrads()
+    assert log == [("blocks", 8, 168)] * 3 and e._wg_pending == {}
+    # an odd block at a segment's end has nobody to ride with: 84 of 240 -> the tile kernel
+    log.clear()
+    for _ in range(3):
+        e.queue_block_wgrads(_block(4608, S3))
+    e.flush_block_wgrads()
+    assert log == [("blocks", 8, 168), ("tiles", 4, None)] and e._wg_pending == {}
+    # stage 4 (330 blocks per trunk block): 330 = 1.375 rounds of 240 (0.69), two = 2.75 (0.92): pairs as well
+    log.clear()
+    for _ in range(3):
+        e.queue_block_wgrads(_block(1152, S4))
+    e.flush_block_wgrads()
+    assert [x[:2] for x in log] == [("blocks", 8), ("blocks", 4)] and e._wg_pending == {}
 
 
 def test_small_row_counts_and_leftovers_fall_back(eng):
