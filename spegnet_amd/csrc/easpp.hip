@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void easpp_fuse_bn_bwd_reduce_kernel(const T* 
     mu[e] = mi[cc]; is[e] = mi[C4 + cc]; sc[e] = ss[cc]; sh[e] = ss[C4 + cc]; wv[e] = w[cc]; gi[e] = cc / 5;   // w[g][j] == w[cc] (cc = 5g+j)
   }
   if (active) {
+#pragma unroll 4   // (four rows' loads in flight per trip: a thread walks ~16 rows)
     for (long r = r0 + rl; r < r1; r += rpar) {
       float xv[VEC];
       unpack16<T>(ld16(dcat + r * C4 + ch * VEC), xv);
@@ -515,7 +516,8 @@ extern "C" int spg_dwconv4_dgrad(int dtype, const void* dy, const float* const* 
   EA_CHECK_C("dwconv4_dgrad");
   Dw4 d;
   for (int i = 0; i < 4; ++i) { d.w[i] = w4[i]; d.dil[i] = dil4[i]; }
-  const int grid = ea_grid((long)B * H * W * (C / v));
+  // (two items per thread: the 4 x 9 x C weight stage -- 18 scattered loads per thread, a barrier -- is paid once per two pixels)
+  const int grid = ea_grid(((long)B * H * W * (C / v) + 1) / 2);
   const size_t lds = (size_t)4 * 9 * C * sizeof(float);
   if (dtype == SPG_BF16) hipLaunchKernelGGL(dwconv4_dgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, d, gadd, (bf16_t*)dx, B, H, W, C);
   else hipLaunchKernelGGL(dwconv4_dgrad_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float*)dy, d, gadd, (float*)dx, B, H, W, C);
@@ -573,15 +575,17 @@ extern "C" int spg_easpp_fuse_bn_bwd(int dtype, const void* dfu, const void* dca
   for (int i = 0; i < 4; ++i) { bn.gamma[i] = gamma4[i]; bn.dgamma[i] = dgamma4[i]; bn.dbeta[i] = dbeta4[i]; }
   hipStream_t s = (hipStream_t)stream;
   const long total = M * (4 * C / v);
+  // (a thread of the apply kernel first loads ~70 per-channel parameters: at one item per thread that prologue was most of the launch)
+  const int apply_grid = ea_grid(total) > 1024 ? 1024 : ea_grid(total);
   if (dtype == SPG_BF16) {
     hipLaunchKernelGGL(easpp_fuse_bn_bwd_reduce_kernel<bf16_t>, dim3(p.gx, 1, p.nslabs), dim3(256), 0, s, (const bf16_t*)dfu, (const bf16_t*)dcat, w, scale_shift,
                        mean_invstd, sums, M, C, p.rpb, p.nchs, red_ws, red_counters_);
-    hipLaunchKernelGGL(easpp_fuse_bn_bwd_apply_kernel<bf16_t>, dim3(ea_grid(total)), dim3(256), 0, s, (const bf16_t*)dfu, (const bf16_t*)dcat, w, scale_shift,
+    hipLaunchKernelGGL(easpp_fuse_bn_bwd_apply_kernel<bf16_t>, dim3(apply_grid), dim3(256), 0, s, (const bf16_t*)dfu, (const bf16_t*)dcat, w, scale_shift,
                        mean_invstd, bn, sums, (bf16_t*)ddcat, dw, M, C, total);
   } else {
     hipLaunchKernelGGL(easpp_fuse_bn_bwd_reduce_kernel<float>, dim3(p.gx, 1, p.nslabs), dim3(256), 0, s, (const float*)dfu, (const float*)dcat, w, scale_shift,
                        mean_invstd, sums, M, C, p.rpb, p.nchs, red_ws, red_counters_);
-    hipLaunchKernelGGL(easpp_fuse_bn_bwd_apply_kernel<float>, dim3(ea_grid(total)), dim3(256), 0, s, (const float*)dfu, (const float*)dcat, w, scale_shift,
+    hipLaunchKernelGGL(easpp_fuse_bn_bwd_apply_kernel<float>, dim3(apply_grid), dim3(256), 0, s, (const float*)dfu, (const float*)dcat, w, scale_shift,
                        mean_invstd, bn, sums, (float*)ddcat, dw, M, C, total);
   }
   return check_launch("easpp_fuse_bn_bwd");
