@@ -308,7 +308,7 @@ class Engine:
         # Under a CU budget (graph segments that replay beside a collective: 240 of 256 CUs) a stage-3 trunk block's 84 blocks fill whole
         # rounds worse -- two trunk blocks are 168 of 240 (0.70), three would spill 12 blocks into a second round -- but falling back to the
         # grouped tile kernel for all of them cost the N > 1 step 1.3 ms (one-rank RCCL rehearsal: 3.08 ms of gemm_tn_group4 in 44 launches
-        # where the single-GPU step has 0.73 in 11, profiles/round4_multi_gpu_rehearsal.md): the fill a set must reach is lowered instead.
+        # where the single-GPU step has 0.73 in 11, profiles/round4_multi_gpu_rehearsal.md): the fill a set must reach is lowered instead ...
         by_m, now = {}, []
         for j in jobs:
             M = j[0].shape[0]
@@ -319,6 +319,19 @@ class Engine:
         if now:
             self._issue_block_wgrads(now)
         cus, need = self._wg_cus()
+        if ops.cu_budget_now():
+            # ... and the sets are packed matrix by matrix: a launch takes whole matrices until the next one would open a second round of
+            # the budgeted CUs (stage 3: two trunk blocks + fc2, fc1, proj of the third = 231 of 240; the third's qkv starts the next set)
+            for M, part in by_m.items():
+                for j in part:
+                    c = ops.tn_blocks_count([j])
+                    pend = self._wg_pending.setdefault(M, [])
+                    total = sum(n for _, n in pend)
+                    if pend and (len(pend) + 1 > ops.TN_BLOCKS_MAX or (total + c > cus and self._round_fill(total, cus) >= need)):
+                        self._flush_pending(M)
+                        pend = self._wg_pending.setdefault(M, [])
+                    pend.append(([j], c))
+            return
         for M, part in by_m.items():
             cnt = ops.tn_blocks_count(part)
             pend = self._wg_pending.setdefault(M, [])
@@ -343,6 +356,8 @@ class Engine:
                 self._sq_cover.extend(t for j in jobs for t in (j[2], j[3]) if t is not None)
             else:
                 ops.gemm_tn_blocks(jobs)
+        elif ops.cu_budget_now():       # (single matrices pending: one grouped tile launch for all of them)
+            self._issue_block_wgrads([j for jobs, _ in pend for j in jobs])
         else:
             for jobs, _ in pend:
                 self._issue_block_wgrads(jobs)

@@ -80,28 +80,25 @@ def test_no_deferral_under_a_callback(eng):
     assert [x[0] for x in log] == ["tiles"] and e._wg_pending == {}
 
 
-def test_pairs_of_trunk_blocks_under_a_cu_budget(eng):
-    """Graph segments of the N > 1 step replay beside a collective with 240 CUs: the sets are sized for 240 (two stage-3 trunk blocks =
-    168 blocks, 0.70 of one round; a third would spill 12 blocks into a second round) and still go out as whole-block launches -- a
-    segment's six stage-3 blocks are three launches, none falls back to the tile kernel."""
+def test_sets_are_packed_per_matrix_under_a_cu_budget(eng):
+    """Graph segments of the N > 1 step replay beside a collective with 240 CUs: a set takes whole matrices until the next would open a
+    second round -- a segment's six stage-3 blocks (6 x 84 blocks) go out as 231 + 216 blocks in two whole-block launches, the last three
+    matrices (57 blocks: a quarter of a round) in one grouped tile launch; nothing stays pending."""
     e, log, fake = eng
     fake.cu_budget_now = lambda: 240
     for _ in range(6):
         e.queue_block_wgrads(_block(4608, S3))
     e.flush_block_wgrads()
-    assert log == [("blocks", 8, 168)] * 3 and e._wg_pending == {}
-    # an odd block at a segment's end has nobody to ride with: 84 of 240 -> the tile kernel
-    log.clear()
-    for _ in range(3):
-        e.queue_block_wgrads(_block(4608, S3))
-    e.flush_block_wgrads()
-    assert log == [("blocks", 8, 168), ("tiles", 4, None)] and e._wg_pending == {}
-    # stage 4 (330 blocks per trunk block): 330 = 1.375 rounds of 240 (0.69), two = 2.75 (0.92): pairs as well
+    per = [_count([j]) for j in _block(4608, S3)]
+    assert per == [27, 27, 9, 21]
+    assert log == [("blocks", 11, 231), ("blocks", 10, 216), ("tiles", 3, None)] and e._wg_pending == {}
+    assert sum(n for _, n, _ in log) == 24
+    # stage 4 (90 + 90 + 30 + 90 blocks per trunk block): 210 | 210 | ... never more than one round of 240
     log.clear()
     for _ in range(3):
         e.queue_block_wgrads(_block(1152, S4))
     e.flush_block_wgrads()
-    assert [x[:2] for x in log] == [("blocks", 8), ("blocks", 4)] and e._wg_pending == {}
+    assert all(x[0] == "blocks" and x[2] <= 240 for x in log[:-1]) and sum(n for _, n, _ in log) == 12 and e._wg_pending == {}
 
 
 def test_small_row_counts_and_leftovers_fall_back(eng):
