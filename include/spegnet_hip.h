@@ -35,7 +35,7 @@ enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
 
 /* ABI revision: bumped with every change of an exported signature.  Bindings must compare spg_version() with the SPG_ABI_VERSION they
  * were written against and refuse to run on a mismatch (spegnet_amd/_lib.py does).  300 = round 3. */
-#define SPG_ABI_VERSION 307
+#define SPG_ABI_VERSION 308
 int spg_version(void);
 const char* spg_last_error(void);
 
@@ -369,6 +369,13 @@ int spg_loss_grad_all(int dtype, const void* const* preds, void* const* dpreds, 
                       const float* masks, const float* edge_gt, const float* wmap, const float* stats, const float* seg_sums,
                       const float* edge_sums, const float* grad_out, int B, int S, float bce_w, float iou_w, float alpha, float gamma,
                       float* dz_ws, spg_stream_t stream);
+
+/* Warm-up hint for the launch AFTER the next spg_gemm_nt: `bytes` at `next` (typically the weight matrix of the following Linear, which
+ * the step reads from HBM exactly once per pass) are requested -- one load per 128-byte line, never waited for -- by the workgroups of the
+ * spg_gemm_nt call that follows this one on the same host thread, so that they sit in the Infinity Cache when the following launch
+ * starts.  No effect on results; consumed by exactly one spg_gemm_nt call (the bf16 dense / implicit-GEMM kernels honour it, the other
+ * families ignore it); NULL / 0 clears it.  (models/feature_encoding.py:236: the order of a MultiScaleBlock's Linear layers is static.) */
+int spg_prefetch_hint(const void* next, long bytes);
 
 /* ---- optimizer (engine/trainer.py:274-306 param groups, :399-409 clip + AdamW step) over a flat f32 arena ---------
  * sumsq: out[0] = sum x^2 (deterministic: 2048 floats of scratch + one zeroed counter, see "Deterministic reductions").  adamw: step_f[0] += 1, then clip coefficient min(1, clip/(sqrt(gnorm_sq)*grad_scale+1e-6))

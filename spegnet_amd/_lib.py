@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPG_LIBRARY") or os.path.join(_HERE, "libspegnet_hip.so")
 
 SPG_F32, SPG_BF16 = 0, 1
-ABI_VERSION = 307   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
+ABI_VERSION = 308   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 ACT_GELU_SAVE_GRAD, ACT_MUL_H = 3, 4   # bf16: C2 = gelu'(pre) saved by the forward GEMM | C = acc * gelu_h in the backward GEMM
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "spg_loss_reduce": "ippppp" "iiiiiff" "plp" "p",
     "spg_loss_finalize": "pppp" "iiffffffp",
     "spg_loss_grad": "ippppppp" "iiiiifffff" "pp",
+    "spg_prefetch_hint": "pl",
     "spg_loss_reduce_all": "ippp" "pppppp" "iiff" "plp" "p",
     "spg_loss_grad_all": "ippppp" "ppppppp" "iiffff" "pp",
     "spg_sumsq": "pp" "l" "plp" "p",

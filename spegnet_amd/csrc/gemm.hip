@@ -475,7 +475,34 @@ __device__ __forceinline__ void load_frags(const char* __restrict__ st, int wn, 
 
 struct PipeEpi {   // byte sizes of the optional epilogue operands (0 = absent)
   unsigned c_bytes, c2_bytes, r_bytes, h_bytes, bias_bytes;
+  unsigned pf_bytes = 0;        // warm-up hint (spg_prefetch_hint): bytes at pf that the NEXT launch will read cold -- see prefetch_lines()
+  const void* pf = nullptr;
 };
+
+// The warm-up hint of the next launch's weights, consumed by the spg_gemm_nt call that follows spg_prefetch_hint on the same thread.
+static thread_local const void* t_hint_ptr = nullptr;
+static thread_local unsigned t_hint_bytes = 0;
+static thread_local const void* t_cur_pf = nullptr;       // ... and held here for the launchers while that call runs
+static thread_local unsigned t_cur_pf_bytes = 0;
+
+// One 4-byte LDS-DMA load per 64 bytes of [pf, pf + bytes), 4 KiB per wave instruction, issued before the wave's first real piece
+// and never waited for by itself: nothing lands in a VGPR, the data goes to `scratch` (256 bytes of LDS that this same wave overwrites with
+// a later, in-order DMA piece or writes before reading) and is never read.  The point is the side effect: the lines are in the Infinity
+// Cache (and one XCD's L2) when the next launch asks for them.  In the step every bf16 weight matrix is read once per pass from HBM (862 MB
+// of copies against a 256 MB cache), at the head of a launch whose X operand is warm: measured on a chain of 36 stage-3 blocks with their
+// own weights (tools/prefetch_probe.py), weights touched one kernel ahead take 1.4-2.3 us off each GEMM (17.5 -> 15.3 us proj / fc2,
+// 16.3 -> 14.5 qkv, 25.7 -> 24.2 fc1 + GELU).  vmcnt: the hint's loads are the wave's OLDEST outstanding memory operations, so every
+// counted wait `vmcnt(n)` that follows still means "all but the n youngest have landed".
+__device__ __forceinline__ void prefetch_lines(const void* pf, unsigned bytes, char* scratch, unsigned gwave, unsigned nwaves, int lane) {
+  if (bytes == 0u) return;
+  const __amdgpu_buffer_rsrc_t pr = make_rsrc(pf, bytes);
+#ifndef SPG_PF_STRIDE     // bytes between a wave's touches (tools/ A/B builds: 128 -> 21.56 ms per step, 64 -> 21.50, 32 -> 21.47, no hint 21.94 / 21.8)
+#define SPG_PF_STRIDE 64
+#endif
+#pragma unroll 1
+  for (unsigned base = gwave * (64u * SPG_PF_STRIDE); base < bytes; base += nwaves * (64u * SPG_PF_STRIDE))
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (__attribute__((address_space(3))) void*)scratch, 4, base + (unsigned)lane * SPG_PF_STRIDE, 0, 0, 0);
+}
 
 // One problem of the persistent pipelined kernel, and the cross-workgroup dependencies of a phase of nt_chain_kernel (below): the body is
 // shared by the plain kernel (one problem per launch, CH = 0: nothing of the chain machinery is compiled in) and the chain kernel.
@@ -548,6 +575,9 @@ __device__ __forceinline__ void nt_pipe_body(const PipeProb& pb, const ChainSync
   const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, pe.c_bytes), c2r = make_rsrc(epi.C2, pe.c2_bytes);
   const __amdgpu_buffer_rsrc_t rr = make_rsrc(epi.residual, pe.r_bytes), hr = make_rsrc(epi.gelu_h, pe.h_bytes);
   const __amdgpu_buffer_rsrc_t br = make_rsrc(epi.bias, pe.bias_bytes);
+  if constexpr (CH == 0 && !DEFER) {   // the next launch's weights: into this wave's epilogue slab (written before it is read, much later)
+    prefetch_lines(pe.pf, pe.pf_bytes, smem + STAGES * DMA_STAGE_BYTES + wave * SLAB_BYTES, (unsigned)(blockIdx.x * 8 + wave), (unsigned)(G * 8), lane);
+  }
 
   // ---- DMA issue stream (2 steps ahead of the fragment reads, 3 ahead of the MFMAs)
   const int lrow = lane >> 3, lp = lane & 7;
@@ -999,6 +1029,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v3_kernel(const bf16_t* __rest
   const int tn = tile % tiles_n, tm = tile / tiles_n;
   const int m0 = tm * BM, n0 = tn * BN_;
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, xbytes), wr = make_rsrc(W, wbytes);
+  // the next launch's weights (prefetch_lines): into the first 256 bytes of the 1 KiB this wave's own first X piece of stage 0 fills next
+  prefetch_lines(pe.pf, pe.pf_bytes, smem + (wave * 32) * RB, (unsigned)(blockIdx.x * 4 + wave), (unsigned)(gridDim.x * 4), lane);
 
   // ---- fill roles: wave w moves X rows [32 w, 32 w + 32) and W rows [WROWS w, WROWS (w + 1)) of the stage image
   const int lrow = KS == 2 ? lane >> 3 : lane >> 2;                                       // row within a piece
@@ -2288,6 +2320,7 @@ static int launch_nt_v3(const void* X, const void* W, void* C, NtEpi epi, int M,
       pe.r_bytes = epi.residual ? (unsigned)cb : 0u;
       pe.h_bytes = epi.gelu_h ? (unsigned)cb : 0u;
       pe.bias_bytes = epi.bias ? (unsigned)N * 4u : 0u;
+      pe.pf = t_cur_pf; pe.pf_bytes = t_cur_pf_bytes;
       // tile width: columns of work (incl. the zero columns of the last tile) x per-column-tile fixed cost (X fill, prologue, epilogue)
 #ifdef SPG_V3_FORCE_NB     // (tools/ A/B builds)
       const int nb3 = SPG_V3_FORCE_NB;
@@ -2397,6 +2430,7 @@ static int launch_nt(const void* X, const void* W, void* C, NtEpi epi, int M, in
       pe.r_bytes = epi.residual ? (unsigned)cb : 0u;
       pe.h_bytes = epi.gelu_h ? (unsigned)cb : 0u;
       pe.bias_bytes = epi.bias ? (unsigned)N * 4u : 0u;
+      pe.pf = t_cur_pf; pe.pf_bytes = t_cur_pf_bytes;
 #define SPG_LAUNCHP(C_, A_, NB_)                                                                                                             \
   do {                                                                                                                                     \
     static bool attr_ = false;                                                                                                             \
@@ -2603,8 +2637,21 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
   }
   NtEpi epi{bias, residual, gelu_h, C2, act};
   hipStream_t s = (hipStream_t)stream;
-  return dtype == SPG_BF16 ? launch_nt<bf16_t>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget)
-                           : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget);
+  // the hint belongs to THIS launch (whichever kernel it becomes: the families without the warm-up ignore it) and to no later one
+  t_cur_pf = t_hint_ptr; t_cur_pf_bytes = t_hint_bytes;
+  t_hint_ptr = nullptr; t_hint_bytes = 0;
+  const int rc = dtype == SPG_BF16 ? launch_nt<bf16_t>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget)
+                                   : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget);
+  t_cur_pf = nullptr; t_cur_pf_bytes = 0;
+  return rc;
+}
+
+extern "C" int spg_prefetch_hint(const void* next, long bytes) {
+  SPG_REQUIRE(bytes >= 0 && (next != nullptr || bytes == 0), "prefetch_hint: bad range");
+  SPG_REQUIRE(((uintptr_t)next & 3) == 0, "prefetch_hint: the range must start on a 4-byte boundary");
+  t_hint_ptr = bytes > 0 ? next : nullptr;
+  t_hint_bytes = bytes > 0x3FFFFFFFL ? 0x3FFFFFFFu : (unsigned)bytes;      // (a hint: anything beyond 1 GiB is simply not warmed)
+  return SPG_OK;
 }
 
 #ifdef SPG_DEV_KERNELS

@@ -374,7 +374,8 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------ linear helpers
     def lin_bwd(self, name: str, dy: Tensor, x: Tensor, need_dx: bool = True, gelu_h: Optional[Tensor] = None,
-                residual: Optional[Tensor] = None, bias: bool = True, h_is_grad: bool = False) -> Optional[Tensor]:
+                residual: Optional[Tensor] = None, bias: bool = True, h_is_grad: bool = False,
+                prefetch: Optional[str] = None) -> Optional[Tensor]:
         """dW += dy^T x, db += colsum(dy), returns dx = dy W (optionally * gelu'(h), + residual)."""
         gw, gb = self.grad(name + ".weight").view(dy.shape[-1], -1), (self.grad(name + ".bias") if bias else None)
         if self._wg_jobs is not None:
@@ -386,7 +387,9 @@ class Engine:
         if not need_dx:
             return None
         act = ops.ACT_MUL_H if (gelu_h is not None and h_is_grad) else ops.ACT_NONE    # gelu_h: saved derivative | pre-activation
-        return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual, act=act)
+        # prefetch: name of the Linear whose dgrad GEMM comes next -- this launch warms that layer's transposed weight copy
+        return ops.gemm_nt(dy, self.W[name + ".weight:T"], gelu_h=gelu_h, residual=residual, act=act,
+                           prefetch=self.W.get(prefetch + ".weight:T") if prefetch else None)
 
     # ================================================================================================ trunk
     def pos_basis(self, h: int, w: int, B: int) -> Tensor:
@@ -456,13 +459,15 @@ class Engine:
             shortcut, sc_idx = ops.maxpool2_fwd(sc_full, B, H, Wd, do, do, 0)
         else:
             shortcut = x
-        qkv = ops.gemm_nt(ln1, W[p + "attn.qkv.weight"], bias=P[p + "attn.qkv.bias"])
+        # (every GEMM of the block warms the weight matrix of the GEMM after it: the step reads each bf16 weight copy from HBM exactly once
+        # per pass, at the head of a launch whose other operand is warm -- ops.gemm_nt(prefetch=...), csrc/gemm.hip: prefetch_lines)
+        qkv = ops.gemm_nt(ln1, W[p + "attn.qkv.weight"], bias=P[p + "attn.qkv.bias"], prefetch=W[p + "attn.proj.weight"])
         qp = q_idx = None
         if qs:
             qp, q_idx = ops.maxpool2_fwd(qkv, B, H, Wd, do, 3 * do, 0)
         att, lse = ops.attn_fwd(qkv, W[p + "attn.qkv.bias"], B, H, Wd, heads, hd, ws, q_pooled=qp)
         Hq, Wq = (H // 2, Wd // 2) if qs else (H, Wd)
-        x1 = ops.gemm_nt(att, W[p + "attn.proj.weight"], bias=P[p + "attn.proj.bias"], residual=shortcut)
+        x1 = ops.gemm_nt(att, W[p + "attn.proj.weight"], bias=P[p + "attn.proj.bias"], residual=shortcut, prefetch=W[p + "mlp.layers.0.weight"])
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, P[p + "norm2.weight"], P[p + "norm2.bias"], eps)
         hpre = torch.empty((x1.shape[0], 4 * do), dtype=x.dtype, device=x.device) if save else None
         # bf16: the GEMM saves gelu'(pre-activation) instead of the pre-activation (ACT_GELU_SAVE_GRAD; its exponential is the one the erf
@@ -471,8 +476,10 @@ class Engine:
         # (the modes exist in the bf16 pipelined GEMM kernels: K = do > 64, 8-element-aligned -- every Hiera size, not the 16-wide test trunk)
         save_grad = save and self.dtype == torch.bfloat16 and do > 64 and do % 8 == 0
         act = ops.ACT_GELU_SAVE_GRAD if save_grad else ops.ACT_GELU
-        g = ops.gemm_nt(ln2, W[p + "mlp.layers.0.weight"], bias=P[p + "mlp.layers.0.bias"], act=act, preact_out=hpre)
-        x2 = ops.gemm_nt(g, W[p + "mlp.layers.1.weight"], bias=P[p + "mlp.layers.1.bias"], residual=x1)
+        g = ops.gemm_nt(ln2, W[p + "mlp.layers.0.weight"], bias=P[p + "mlp.layers.0.bias"], act=act, preact_out=hpre,
+                        prefetch=W[p + "mlp.layers.1.weight"])
+        x2 = ops.gemm_nt(g, W[p + "mlp.layers.1.weight"], bias=P[p + "mlp.layers.1.bias"], residual=x1,
+                         prefetch=W.get(f"encoder.encoder.blocks.{b['idx'] + 1}.attn.qkv.weight"))
         x2 = x2.view(B, Hq, Wq, do)
         c = None
         if save:
@@ -489,17 +496,18 @@ class Engine:
         dx2 = dx2.reshape(-1, do)
         self._wg_jobs = [] if self.group_wgrads else None
         # MLP
-        dh = self.lin_bwd(p + "mlp.layers.1", dx2, c["g"], gelu_h=c["h"], h_is_grad=c["h_is_grad"])
-        dln2 = self.lin_bwd(p + "mlp.layers.0", dh, c["ln2"])
+        dh = self.lin_bwd(p + "mlp.layers.1", dx2, c["g"], gelu_h=c["h"], h_is_grad=c["h_is_grad"], prefetch=p + "mlp.layers.0")
+        dln2 = self.lin_bwd(p + "mlp.layers.0", dh, c["ln2"], prefetch=p + "attn.proj")
         dx1 = self.ln_bwd(dln2, c["x1"], P[p + "norm2.weight"], c["mean2"], c["rstd2"], G(p + "norm2.weight"),
                           G(p + "norm2.bias"), dres=dx2)
         # attention branch
-        datt = self.lin_bwd(p + "attn.proj", dx1, c["att"])
+        datt = self.lin_bwd(p + "attn.proj", dx1, c["att"], prefetch=p + "attn.qkv")
         dqkv, dqp = ops.attn_bwd(c["qkv"], W[p + "attn.qkv.bias"], c["att"], datt, c["lse"], G(p + "attn.qkv.bias"), B, H, Wd,
                                  heads, hd, ws, q_pooled=c["qp"])
         if qs:
             ops.maxpool2_bwd(dqp, c["q_idx"], dqkv, B, H, Wd, do, 3 * do, 0)
-        dln1 = self.lin_bwd(p + "attn.qkv", dqkv.view(-1, 3 * do), c["ln1"])
+        dln1 = self.lin_bwd(p + "attn.qkv", dqkv.view(-1, 3 * do), c["ln1"],
+                            prefetch=f"encoder.encoder.blocks.{b['idx'] - 1}.mlp.layers.1" if b["idx"] > 0 else None)
         if dim != do:
             dsc = torch.empty((B, H, Wd, do), dtype=dx1.dtype, device=dx1.device)
             ops.maxpool2_bwd(dx1, c["sc_idx"], dsc, B, H, Wd, do, do, 0)

@@ -2,6 +2,7 @@
 HIP kernels on torch's current stream; tensors only provide device memory.  No CPU path exists."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -136,11 +137,16 @@ def _nb(*ts) -> int:
 
 
 # ---- GEMM family ---------------------------------------------------------------------------------------
+# the GEMMs of a trunk block warm the next GEMM's weight matrix (gemm_nt(prefetch=...)); SPG_PREFETCH=0 for A/B runs
+PREFETCH_WEIGHTS = os.environ.get("SPG_PREFETCH", "1") != "0"
+
+
 def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = ACT_NONE, residual: Optional[Tensor] = None,
             gelu_h: Optional[Tensor] = None, out: Optional[Tensor] = None, preact_out: Optional[Tensor] = None,
-            conv: Optional[tuple] = None) -> Tensor:
+            conv: Optional[tuple] = None, prefetch: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = epi(x[M,K] @ w[N,K]^T).  conv=(B,H,W,Ci): x is NHWC and the product is a 3x3/pad-1 convolution
-    with w packed [N, 9*Ci]."""
+    with w packed [N, 9*Ci].  prefetch: a tensor the NEXT launch reads cold (the following layer's weight matrix): this launch's
+    workgroups request its cache lines on their way in (spg_prefetch_hint; no effect on the result)."""
     N, K = w.shape
     if conv is None:
         M = x.numel() // x.shape[-1]
@@ -157,6 +163,8 @@ def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = ACT_
     assert out.numel() == M * N and w.dtype == x.dtype
     tag = "bf16" if x.dtype == torch.bfloat16 else "f32"
     with _prof(f"gemm_nt<{tag},{'conv3x3' if conv else 'dense'}>", "mfma", 2.0 * M * N * K):
+        if prefetch is not None and PREFETCH_WEIGHTS:
+            _lib.call("spg_prefetch_hint", _p(prefetch), prefetch.numel() * prefetch.element_size())
         _lib.call("spg_gemm_nt", dcode(x), _p(_c(x)), _p(_c(w)), _p(_c(out)), _p(preact_out), _p(bias), _p(residual),
                   _p(gelu_h), M, N, K, ldx, N, act, 1 if conv else 0, B, H, W, Ci, cu_budget_now(), _stream())
     return out

@@ -63,6 +63,30 @@ def test_gemm_nt_dense(ops, dt, M, N, K):
     check(out.float(), (xq.float() @ wq.float().t()) * hf.grad, tol(dt), "gelu'")
 
 
+@pytest.mark.parametrize("M,N,K,what", [(4608, 2304, 576, "fc1: 4-wave kernel"), (4608, 576, 2304, "fc2: persistent kernel, 108 tiles"),
+                                         (4608, 1728, 576, "qkv"), (1152, 4608, 1152, "stage 4"), (300, 200, 144, "ragged"),
+                                         (129, 64, 64, "one K step"), (1000, 136, 200, "K tail")])
+@pytest.mark.parametrize("nbytes", [0, 100, 663552, 21233664])
+def test_gemm_nt_prefetch_hint_changes_nothing(ops, M, N, K, what, nbytes):
+    """spg_prefetch_hint makes the next spg_gemm_nt's workgroups request the cache lines of another buffer (the following layer's weights)
+    through LDS-DMA into LDS they overwrite before reading: results must be BIT-identical with and without it -- for both kernel families,
+    ragged tiles, a K tail (whose out-of-range pieces must still overwrite the scratch), hints smaller than a line, of 0.66 MB (a 576 x 576
+    matrix) and of 21 MB (more than one pass of a small grid) -- and the hint must be consumed by exactly one launch."""
+    dt = torch.bfloat16
+    x, w = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2, scale=K ** -0.5).to(dt)
+    b, res = rnd(N, seed=3), rnd(M, N, seed=4).to(dt)
+    nxt = torch.full(((nbytes + 1) // 2 + 8,), 1.0, dtype=dt, device="cuda")[:max((nbytes + 1) // 2, 1)]
+    ref = [ops.gemm_nt(x, w), ops.gemm_nt(x, w, bias=b, residual=res), ops.gemm_nt(x, w, bias=b, act=ops.ACT_GELU)]
+    hint = nxt if nbytes else None
+    got = [ops.gemm_nt(x, w, prefetch=hint), ops.gemm_nt(x, w, bias=b, residual=res, prefetch=hint),
+           ops.gemm_nt(x, w, bias=b, act=ops.ACT_GELU, prefetch=hint)]
+    again = ops.gemm_nt(x, w)                      # no hint may linger
+    torch.cuda.synchronize()
+    for a, r in zip(got + [again], ref + [ref[0]]):
+        assert torch.equal(a, r), what
+    assert bool((nxt == 1.0).all())                # the hinted buffer is only read
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_nt_identity_asymmetric(ops, dt):
     """A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md §3)."""
