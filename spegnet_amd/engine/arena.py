@@ -126,11 +126,13 @@ class Arena:
         self._fold_key, self._fold_n = key, len(recs)
         return self._fold_blob, self._fold_n
 
-    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, packer=None, fold=None, keep_g: bool = False):
+    def step(self, clip: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0, packer=None, fold=None, keep=None):
         """Global-norm clip + AdamW.  packer (the model's Engine): the update kernel also writes the compute-dtype weight copies of the
         next forward (spg_adamw_pack) instead of leaving them to a separate re-pack pass.  fold = (sums of squares, covered gradient
-        tensors) from Engine.take_sq(): the norm pass then reads only the uncovered gradients (spg_sumsq_fold).  keep_g (with fold): the covered
-        matrices' gradients are not cleared either -- the caller promises that its next backward stores them whole (zero_grad(expect_overwrite))."""
+        tensors) from Engine.take_sq(): the norm pass then reads only the uncovered gradients (spg_sumsq_fold).  keep = gradient tensors
+        (views of self.g) this backward STORED whole: the matrices among them are not cleared -- the caller promises that its next
+        backward stores them whole again (zero_grad(expect_overwrite)).  keep works without fold (multi-GPU: the norm is that of the
+        all-reduced gradients, a full pass)."""
         if self.m is None:
             self.m = torch.zeros_like(self.p)
             self.v = torch.zeros_like(self.p)
@@ -141,20 +143,21 @@ class Arena:
         es = 2 if (packer is not None and packer.dtype == torch.bfloat16) else 4
         use_fold = fold is not None and len(fold[0]) > 0 and len(fold[0]) <= 32       # (spg_sumsq_fold takes up to 32 partial arrays)
         base = self.g.data_ptr()
-        cov_offsets = frozenset((t.data_ptr() - base) // 4 for t in fold[1]) if fold is not None else frozenset()
+        stored = keep if keep is not None else (fold[1] if fold is not None else [])
+        cov_offsets = frozenset((t.data_ptr() - base) // 4 for t in stored)
         if self._unzeroed and not self._unzeroed <= cov_offsets:
             raise RuntimeError("gradients left uncleared by the previous optimizer step were not overwritten by this backward (stale values): "
                                "call zero_grad() without a promise before a backward that makes other launches")
         # algorithmic bytes: sumsq reads g; adamw reads p, g, m, v and writes p, m, v, g (cleared) (+ the two compute-dtype copies); with a
         # fold the covered gradients are neither read by the norm pass nor cleared (8 bytes per covered element less)
         covered = sum(t.numel() for t in fold[1] if t.dim() == 2) if use_fold else 0
+        kept = sum(t.numel() for t in keep if t.dim() == 2) if (keep is not None and packer is not None) else 0
         with ops._prof("sumsq + adamw_pack (clip + AdamW + weight re-pack)" if packer is not None else "sumsq + adamw", "hbm",
-                       self.size * (4 + 32 + (2 * es if packer is not None else 0)) - 8 * covered):
-            keep = frozenset()
+                       self.size * (4 + 32 + (2 * es if packer is not None else 0)) - 4 * covered - 4 * kept):
+            # the stored MATRICES stay uncleared: the same launches store them whole next step (biases are added to)
+            keep_offs = frozenset((t.data_ptr() - base) // 4 for t in keep if t.dim() == 2) if (keep is not None and packer is not None) else frozenset()
             if use_fold:
                 import ctypes
-                if keep_g:       # the covered MATRICES stay uncleared: the same launches store them whole next step (biases are added to)
-                    keep = frozenset((t.data_ptr() - base) // 4 for t in fold[1] if t.dim() == 2)
                 blob, nchunks = self._fold_plan(fold[1])
                 if self._red_ws.numel() < nchunks:
                     self._red_ws = torch.empty(max(nchunks, 2048), dtype=torch.float32, device=self.p.device)
@@ -167,7 +170,7 @@ class Arena:
                 _lib.call("spg_sumsq", self.g.data_ptr(), self.gnorm_sq.data_ptr(), self.size, self._red_ws.data_ptr(), 2048,
                           ops.red_counters(self.p.device, 1), s)
             if packer is not None:
-                blob, njobs, items = packer.opt_jobs(self, keep)
+                blob, njobs, items = packer.opt_jobs(self, keep_offs)
                 dt = _lib.SPG_BF16 if packer.dtype == torch.bfloat16 else _lib.SPG_F32
                 _lib.call("spg_adamw_pack", dt, self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                           self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
@@ -177,7 +180,7 @@ class Arena:
                           self.group_of_chunk.data_ptr(), self.lr.data_ptr(), self.wd.data_ptr(), self.gnorm_sq.data_ptr(),
                           self.step_f.data_ptr(), float(clip), betas[0], betas[1], eps, float(grad_scale), 1, self.size, s)
         self._clean = True
-        self._unzeroed = keep if packer is not None else frozenset()
+        self._unzeroed = keep_offs
 
     def state_dict(self):
         """Optimizer state of the flat arena: Adam moments (arena layout), step counter, per-group lr / weight decay, and the name ->

@@ -70,13 +70,7 @@ class TrainStep:
         ops.begin_zero_pool(images.device)   # one fill for the step's zero-initialised scratch (ops.zeros_f32)
         # (the matrices the previous step left uncleared are stored whole again by this backward IF it makes the same launches: same input
         # shapes, same switches -- otherwise they are cleared now; Arena.step refuses a backward that broke the promise)
-        sig = (tuple(images.shape), self.sync is None and self.fold_sumsq)
-        self.arena.zero_grad(expect_overwrite=self.arena._unzeroed if sig == getattr(self, "_fold_sig", None) else None)
-        self._fold_sig = sig
-        # single GPU: the gradients are zero here and the norm is taken right after the backward, so the whole-block weight-gradient
-        # launches may store instead of add and hand their sums of squares to the clip (models/engine.py: fold_sumsq).  With a GradSync
-        # the norm is that of the all-reduced gradients: no fold.
-        self.model.engine.fold_sumsq = self.sync is None and self.fold_sumsq
+        self._begin_grads(images)
         out = self.model(images)
         losses = self.criterion.forward_batched(out['predictions'], out['edge'], masks, edges)
         if getattr(self, "_one", None) is None:       # the root gradient, kept: backward() without it fills a fresh ones_like every step
@@ -84,12 +78,27 @@ class TrainStep:
         losses['loss'].backward(self._one)
         return {k: v.detach() for k, v in losses.items()}
 
+    def _begin_grads(self, images):
+        """Start of a backward's gradient bookkeeping.  The whole-block weight-gradient launches STORE their blocks (the optimizer then
+        leaves those matrices uncleared: they are stored whole again by the next backward IF it makes the same launches -- same input
+        shapes, same switches; otherwise they are cleared now, and Arena.step refuses a backward that broke the promise).  Single GPU: the
+        norm is taken right after the backward, so the launches also hand their sums of squares to the clip (models/engine.py:
+        fold_sumsq).  With a GradSync the norm is that of the all-reduced gradients: stored and kept, but no fold."""
+        sig = (tuple(images.shape), self.fold_sumsq, self.sync is None)
+        self.arena.zero_grad(expect_overwrite=self.arena._unzeroed if sig == getattr(self, "_fold_sig", None) else None)
+        self._fold_sig = sig
+        eng = self.model.engine
+        eng.fold_sumsq = self.sync is None and self.fold_sumsq
+        eng.store_wgrads = self.fold_sumsq
+
     def _opt(self, scale: float):
         # AdamW writes the compute-dtype weight copies of the next forward itself (spg_adamw_pack): no separate re-pack pass
         eng = self.model._engine
-        fold = eng.take_sq() if eng.fold_sumsq else None
-        eng.fold_sumsq = False
-        self.arena.step(self.clip, grad_scale=scale, packer=eng, fold=fold, keep_g=fold is not None)
+        parts, cover = eng.take_sq()
+        fold = (parts, cover) if eng.fold_sumsq else None
+        keep = cover if (eng.fold_sumsq or eng.store_wgrads) else None
+        eng.fold_sumsq = eng.store_wgrads = False
+        self.arena.step(self.clip, grad_scale=scale, packer=eng, fold=fold, keep=keep)
 
     def _eager(self, images, masks, edges):
         losses = self._fwd_bwd(images, masks, edges)
@@ -125,7 +134,7 @@ class TrainStep:
     def _seg_first(self, images, masks, edges, lo, hi):
         model, eng = self.model, self.model.engine
         ops.begin_zero_pool(images.device)
-        self.arena.zero_grad()
+        self._begin_grads(images)
         feats, tctx = eng.trunk_fwd(images, True, True)
         out, hctx = eng.head_fwd(feats[1:4], True, True)
         leaves = [t.detach().requires_grad_(True) for t in out["predictions"] + [out["edge"]]]

@@ -60,7 +60,8 @@ class Engine:
         # whole-block launches STORE their blocks instead of adding (no cold read of the old values at the exit) and leave the sum of
         # squares of what they wrote, so that the optimizer's global-norm pass reads only the gradients no such launch covered
         # (Arena.step(fold=...), spg_sumsq_fold).  Set and cleared by TrainStep around each step; never on for plain autograd use.
-        self.fold_sumsq = False
+        self.fold_sumsq = False      # whole-block wgrad launches also hand back their sums of squares (single GPU: the clip's norm pass skips them)
+        self.store_wgrads = False    # ... and STORE their blocks instead of adding to them (the caller keeps those gradients uncleared: Arena.step(keep=))
         self._sq_parts, self._sq_cover = [], []
         self.batch_ln_params = True  # trunk: LayerNorm dgamma / dbeta in batched launches
         self._ln_jobs = []
@@ -351,8 +352,10 @@ class Engine:
         cus, need = self._wg_cus()
         if self._round_fill(sum(c for _, c in pend), cus) >= need:
             jobs = [j for jobs, _ in pend for j in jobs]
-            if self.fold_sumsq:
-                self._sq_parts.append(ops.gemm_tn_blocks(jobs, overwrite=True, want_sq=True))
+            if self.fold_sumsq or self.store_wgrads:
+                parts = ops.gemm_tn_blocks(jobs, overwrite=True, want_sq=self.fold_sumsq)
+                if self.fold_sumsq:
+                    self._sq_parts.append(parts)
                 self._sq_cover.extend(t for j in jobs for t in (j[2], j[3]) if t is not None)
             else:
                 ops.gemm_tn_blocks(jobs)

@@ -36,7 +36,7 @@ def _block(M, dims):
 def eng(monkeypatch):
     e = E.Engine.__new__(E.Engine)
     e.block_wgrads, e.unit_cb, e.wgrad_async, e._wg_pending, e._tn_defer = True, None, False, {}, []
-    e.fold_sumsq, e._sq_parts, e._sq_cover = False, [], []
+    e.fold_sumsq, e.store_wgrads, e._sq_parts, e._sq_cover = False, False, [], []
     log = []
     fake = types.SimpleNamespace(
         TN_BLOCKS_MAX=16, tn_blocks_count=_count, num_cus=lambda: 256, cu_budget_now=lambda: 0,
