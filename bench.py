@@ -328,7 +328,8 @@ def main():
             "config": {"workload": f"SPEGNet (Hiera-L trunk + CFI + EFE + PED) train step: fwd + CODLoss + bwd + clip + AdamW, "
                                    f"batch {args.batch}/GPU @{args.size}x{args.size}, random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
-                       "launch": "eager, bucketed all-reduce overlapped with backward" if args.no_graph else ("hipGraph" if (world == 1 and not args.rehearse_comm) else f"hipGraph segments (fwd+loss+bwd in {getattr(step, 'n_segments', 8)} pieces) with RCCL all-reduce (bf16 payload) of finished gradient ranges on a side stream | hipGraph optimizer"),
+                       # (step.capture turns False when the hipGraph capture failed on some rank and every rank agreed to run eagerly)
+                       "launch": "eager, bucketed all-reduce overlapped with backward" if (args.no_graph or not step.capture) else ("hipGraph" if (world == 1 and not args.rehearse_comm) else f"hipGraph segments (fwd+loss+bwd in {getattr(step, 'n_segments', 8)} pieces) with RCCL all-reduce (bf16 payload) of finished gradient ranges on a side stream | hipGraph optimizer"),
                        "final_loss": round(loss_val, 5), **({"rehearsal": "one-rank RCCL group, every collective of the N > 1 step issued"} if args.rehearse_comm else {})},
             "roofline": roof, "cpu_baseline": cpu,
         }

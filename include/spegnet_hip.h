@@ -35,7 +35,7 @@ enum { SPG_ACT_NONE = 0, SPG_ACT_GELU = 1, SPG_ACT_RELU = 2,
 
 /* ABI revision: bumped with every change of an exported signature.  Bindings must compare spg_version() with the SPG_ABI_VERSION they
  * were written against and refuse to run on a mismatch (spegnet_amd/_lib.py does).  300 = round 3. */
-#define SPG_ABI_VERSION 308
+#define SPG_ABI_VERSION 309
 int spg_version(void);
 const char* spg_last_error(void);
 
@@ -170,6 +170,9 @@ int spg_chan_prod_sum(int dtype, const void* a, const void* b, float* out, int B
                       unsigned* red_counters, spg_stream_t stream);
 int spg_add(int dtype, const void* a, const void* b, void* out, long n, spg_stream_t stream);
 int spg_cast_bf16(const float* f32, void* bf16, long n, int to_f32, spg_stream_t stream);
+/* The cast back (bf16 -> f32, n multiple of 8) that also writes nparts (1..4096) partial sums of squares of the values it wrote: the clip's
+ * norm of an all-reduced gradient range without a pass of its own (add the arrays with spg_sumsq_fold).  Deterministic per nparts. */
+int spg_cast_bf16_sq(float* f32, const void* bf16, long n, float* sq_part, int nparts, spg_stream_t stream);
 int spg_copy_channels(int dtype, const void* x, void* y, long M, int C, int ldx, int cx0, int ldy, int cy0,
                       int accumulate, spg_stream_t stream);
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPG_LIBRARY") or os.path.join(_HERE, "libspegnet_hip.so")
 
 SPG_F32, SPG_BF16 = 0, 1
-ABI_VERSION = 308   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
+ABI_VERSION = 309   # = SPG_ABI_VERSION of include/spegnet_hip.h that SIGNATURES below was written for
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 ACT_GELU_SAVE_GRAD, ACT_MUL_H = 3, 4   # bf16: C2 = gelu'(pre) saved by the forward GEMM | C = acc * gelu_h in the backward GEMM
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "spg_chan_prod_sum": "ippp" "ili" "plp" "p",
     "spg_add": "ippp" "lp",
     "spg_cast_bf16": "pp" "lip",
+    "spg_cast_bf16_sq": "pp" "lpip",
     "spg_copy_channels": "ipp" "liiiiiip",
     "spg_bn_stats": "ipp" "li" "plp" "p",
     "spg_bn_stats_finalize": "ipp" "ppppppp" "liff" "plp" "p",

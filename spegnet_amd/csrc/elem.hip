@@ -149,6 +149,25 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ f, 
   }
 }
 
+// bf16 -> f32 (n multiple of 8) AND the sum of squares of what was written, one partial per block (grid-stride walk, block_sum: a fixed
+// order).  The gradient all-reduce's cast-back pass touches every element of the summed gradient anyway: the clip's norm needs no pass of
+// its own (spg_sumsq_fold adds the partial arrays).
+__global__ __launch_bounds__(256) void cast_sq_kernel(float* __restrict__ f, const bf16_t* __restrict__ h, long n8, float* __restrict__ sq_part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float v[8];
+    unpack16<bf16_t>(ld16(h + i * 8), v);
+    float* dst = f + i * 8;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e] * v[e];
+  }
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) sq_part[blockIdx.x] = s;
+}
+
 // 2x2 max pool over a channel window of an NHWC tensor; first max wins ties (torch semantics)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
@@ -792,6 +811,12 @@ extern "C" int spg_cast_bf16(const float* f32, void* bf16, long n, int to_f32, s
   SPG_REQUIRE(n % 8 == 0, "cast: n=%ld must be a multiple of 8", n);
   hipLaunchKernelGGL(cast_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, f32, (bf16_t*)bf16, n / 8, to_f32);
   return check_launch("cast_bf16");
+}
+extern "C" int spg_cast_bf16_sq(float* f32, const void* bf16, long n, float* sq_part, int nparts, spg_stream_t stream) {
+  SPG_REQUIRE(n % 8 == 0 && n > 0, "cast_bf16_sq: n=%ld must be a positive multiple of 8", n);
+  SPG_REQUIRE(sq_part && nparts >= 1 && nparts <= 4096, "cast_bf16_sq: 1..4096 partials");
+  hipLaunchKernelGGL(cast_sq_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, f32, (const bf16_t*)bf16, n / 8, sq_part);
+  return check_launch("cast_bf16_sq");
 }
 extern "C" int spg_maxpool2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int ldc, int c0,
                                 spg_stream_t stream) {

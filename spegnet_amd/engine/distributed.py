@@ -88,6 +88,29 @@ class GradSync:
         self._next = 0
         self._works = []
         self._tmp = {}
+        self._sq = {}        # (s, e) -> partial sums of squares of the all-reduced range, written by the cast-back pass (bf16 wire)
+
+    def fold_for(self, ranges):
+        """(partial arrays, gradient views) for Arena.step(fold=...): the sums of squares of the all-reduced gradient ranges that the
+        bf16 wire's cast-back pass wrote while it touched every element anyway (reduce_range), so the clip's norm pass reads only what
+        these ranges do not cover.  None when a range went over the wire as fp32 (no cast, no partials).  Buffers persist per range:
+        a captured optimizer graph may hold their addresses."""
+        if not (self.active and self.compress and self.cuda) or os.environ.get("SPG_SYNC_FOLD", "1") == "0":     # (the switch: A/B runs)
+            return None
+        parts, views = [], []
+        for s, e in ranges:
+            if (e - s) % 8 != 0 or e <= s:
+                return None
+            parts.append(self._sq_buf(s, e))
+            views.append(self.g[s:e])
+        return (parts, views) if 0 < len(parts) <= 32 else None
+
+    def _sq_buf(self, s, e):
+        buf = self._sq.get((s, e))
+        if buf is None:
+            n = max(1, min(1024, (e - s) // (8 * 256 * 4)))
+            buf = self._sq[(s, e)] = torch.zeros(n, dtype=torch.float32, device=self.g.device)
+        return buf
 
     def reset(self):
         self._next = 0
@@ -117,7 +140,8 @@ class GradSync:
             st = torch.cuda.current_stream().cuda_stream
             _lib.call("spg_cast_bf16", view.data_ptr(), tmp.data_ptr(), e - s, 0, st)
             dist.all_reduce(tmp, group=self.group)
-            _lib.call("spg_cast_bf16", view.data_ptr(), tmp.data_ptr(), e - s, 1, st)
+            sq = self._sq_buf(s, e)
+            _lib.call("spg_cast_bf16_sq", view.data_ptr(), tmp.data_ptr(), e - s, sq.data_ptr(), sq.numel(), st)
         else:
             dist.all_reduce(view, group=self.group)
 

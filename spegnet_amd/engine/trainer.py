@@ -91,11 +91,14 @@ class TrainStep:
         eng.fold_sumsq = self.sync is None and self.fold_sumsq
         eng.store_wgrads = self.fold_sumsq
 
-    def _opt(self, scale: float):
+    def _opt(self, scale: float, reduced=None):
+        """reduced: the gradient ranges [(s, e)] this step all-reduced (their sums of squares come from the wire's cast-back pass)"""
         # AdamW writes the compute-dtype weight copies of the next forward itself (spg_adamw_pack): no separate re-pack pass
         eng = self.model._engine
         parts, cover = eng.take_sq()
         fold = (parts, cover) if eng.fold_sumsq else None
+        if fold is None and self.comm and reduced:
+            fold = self.sync.fold_for(reduced)
         keep = cover if (eng.fold_sumsq or eng.store_wgrads) else None
         eng.fold_sumsq = eng.store_wgrads = False
         self.arena.step(self.clip, grad_scale=scale, packer=eng, fold=fold, keep=keep)
@@ -103,7 +106,7 @@ class TrainStep:
     def _eager(self, images, masks, edges):
         losses = self._fwd_bwd(images, masks, edges)
         scale = self.sync.finish() if self.sync is not None else 1.0
-        self._opt(scale)
+        self._opt(scale, reduced=self.sync.buckets if self.sync is not None else None)
         return losses
 
     def _allreduce_flat(self):
@@ -113,7 +116,7 @@ class TrainStep:
         losses = self._fwd_bwd(images, masks, edges)
         if self.comm:
             self._allreduce_flat()
-        self._opt(1.0 / self.world)
+        self._opt(1.0 / self.world, reduced=[(0, self.arena.size)])
         return losses
 
     # ---- hand-written backward in segments (multi-GPU graph mode) ---------------------------------------------------
@@ -163,7 +166,7 @@ class TrainStep:
             eng.trunk_bwd_end()
             if self.comm:
                 self._allreduce_flat()
-            self._opt(1.0 / self.world)
+            self._opt(1.0 / self.world, reduced=[(0, self.arena.size)])
             return losses
 
         side = torch.cuda.Stream()
@@ -196,8 +199,16 @@ class TrainStep:
                     eng.trunk_bwd_end()
             self.segments.append(g)
         self.graph_b = torch.cuda.CUDAGraph()
+        ranges, start = [], 0                  # what _replay_segmented all-reduces, range by range
+        for (_, _, end) in plan:
+            ranges.append((start, end))
+            start = end
+        if self.comm:      # the partial-sum buffers and the fold's chunk table (a host-to-device upload) exist BEFORE the capture
+            pre = self.sync.fold_for(ranges)
+            if pre is not None:
+                ar._fold_plan(pre[1])
         with ops.cu_budget(0), torch.cuda.graph(self.graph_b, pool=pool, capture_error_mode=graph_capture_mode()):
-            self._opt(1.0 / self.world)
+            self._opt(1.0 / self.world, reduced=ranges)
         self._plan = plan
         self.graph = g0
 
