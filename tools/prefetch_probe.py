@@ -18,7 +18,8 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     mk = lambda n, k: (torch.randn(n, k, device=dev, generator=g) * k ** -0.5).to(dt)
     hintln = len(sys.argv) > 1 and sys.argv[1] == "hintln"      # ... and the LayerNorm parameters the kernel after it reads (cold fp32, 4.6 KB)
-    hint = hint or hintln
+    biaswarm = len(sys.argv) > 1 and sys.argv[1] == "biaswarm"  # hint + the four (cold, fp32) bias vectors read one kernel ahead
+    hint = hint or hintln or biaswarm
 
     def with_ln(n, k):
         """weight [n, k] bf16 followed in the SAME allocation by an fp32 gamma / beta pair: one hint range covers both"""
@@ -32,13 +33,19 @@ def main():
     for _ in range(NB):
         qb, qw, g1, b1 = with_ln(3 * C, C)          # norm1's parameters ride behind the qkv weight
         fb, fw, g2, b2 = with_ln(4 * C, C)          # norm2's behind fc1
-        blocks.append(dict(qkv=qw, proj=mk(C, C), fc1=fw, fc2=mk(C, 4 * C), g1=g1, b1=b1, g2=g2, b2=b2, qkv_buf=qb, fc1_buf=fb))
+        blocks.append(dict(qkv=qw, proj=mk(C, C), fc1=fw, fc2=mk(C, 4 * C), g1=g1, b1=b1, g2=g2, b2=b2, qkv_buf=qb, fc1_buf=fb,
+                           bq=torch.zeros(3 * C, device=dev), bp=torch.zeros(C, device=dev), b1f=torch.zeros(4 * C, device=dev), b2f=torch.zeros(C, device=dev),
+                           pad=torch.zeros(1 << 20, device=dev)))      # (4 MB between the blocks' biases: no two share a page)
     x0 = torch.randn(M, C, device=dev, generator=g).to(dt)
     sink = torch.zeros(1, device=dev)
 
     def warm(w):
         if touch:
             sink.add_(w.float().sum() * 0)       # (reads the whole matrix; two small torch kernels)
+
+    def warmb(b):
+        if biaswarm:
+            sink.add_(b.sum() * 0)
 
     def chain():
         x = x0
@@ -48,16 +55,18 @@ def main():
             H = (lambda t: t) if hint else (lambda t: None)
             warm(b["qkv"])
             ln, _, _ = ops.layernorm_fwd(x, b["g1"], b["b1"], 1e-6)
-            qkv = ops.gemm_nt(ln, b["qkv"], prefetch=H(b["proj"]))
+            warmb(b["bq"]); warmb(b["bp"]); warmb(b["b1f"]); warmb(b["b2f"])
+            ln, _, _ = ops.layernorm_fwd(x, b["g1"], b["b1"], 1e-6)      # (again: the bias reads above sit two kernels ahead of their first use)
+            qkv = ops.gemm_nt(ln, b["qkv"], bias=b["bq"], prefetch=H(b["proj"]))
             warm(b["proj"])
             a = qkv[:, :C].contiguous()                                  # (stands in for the attention kernel: a kernel between the two GEMMs)
-            x1 = ops.gemm_nt(a, b["proj"], residual=x, prefetch=H(b[kf]))
+            x1 = ops.gemm_nt(a, b["proj"], bias=b["bp"], residual=x, prefetch=H(b[kf]))
             warm(b["fc1"])
             ln2, _, _ = ops.layernorm_fwd(x1, b["g2"], b["b2"], 1e-6)
-            h = ops.gemm_nt(ln2, b["fc1"], act=ops.ACT_GELU, prefetch=H(b["fc2"]))
+            h = ops.gemm_nt(ln2, b["fc1"], bias=b["b1f"], act=ops.ACT_GELU, prefetch=H(b["fc2"]))
             warm(b["fc2"])
             hh = h * 1                                                    # (a kernel between fc1 and fc2 so the warm-up has something to hide behind)
-            x = ops.gemm_nt(hh, b["fc2"], residual=x1, prefetch=H(nxt) if nxt is not None else None)
+            x = ops.gemm_nt(hh, b["fc2"], bias=b["b2f"], residual=x1, prefetch=H(nxt) if nxt is not None else None)
         return x
 
     for _ in range(2):
