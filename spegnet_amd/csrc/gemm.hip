@@ -2624,6 +2624,11 @@ using namespace spg;
 extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, void* C2, const float* bias,
                            const void* residual, const void* gelu_h, int M, int N, int K, int ldx, int ldc, int act,
                            int conv3x3, int B, int H, int Wd, int Ci, int cu_budget, spg_stream_t stream) {
+  // the warm-up hint belongs to THIS call (whichever kernel it becomes: the families without the warm-up ignore it) and to no later one --
+  // taken before any argument check, so a call that fails cannot leave a pointer behind for a launch made after its buffer is gone
+  const void* const hint_ptr = t_hint_ptr;
+  const unsigned hint_bytes = t_hint_bytes;
+  t_hint_ptr = nullptr; t_hint_bytes = 0;
   const int vec = dtype == SPG_BF16 ? 8 : 4;
   SPG_REQUIRE(dtype == SPG_F32 || dtype == SPG_BF16, "gemm_nt: bad dtype %d", dtype);
   SPG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
@@ -2637,9 +2642,7 @@ extern "C" int spg_gemm_nt(int dtype, const void* X, const void* W, void* C, voi
   }
   NtEpi epi{bias, residual, gelu_h, C2, act};
   hipStream_t s = (hipStream_t)stream;
-  // the hint belongs to THIS launch (whichever kernel it becomes: the families without the warm-up ignore it) and to no later one
-  t_cur_pf = t_hint_ptr; t_cur_pf_bytes = t_hint_bytes;
-  t_hint_ptr = nullptr; t_hint_bytes = 0;
+  t_cur_pf = hint_ptr; t_cur_pf_bytes = hint_bytes;
   const int rc = dtype == SPG_BF16 ? launch_nt<bf16_t>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget)
                                    : launch_nt<float>(X, W, C, epi, M, N, K, ldx, ldc, conv3x3, g, s, cu_budget);
   t_cur_pf = nullptr; t_cur_pf_bytes = 0;
