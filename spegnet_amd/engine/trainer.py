@@ -50,7 +50,8 @@ class TrainStep:
         self.graph = self.graph_b = None
         self.segments = None
         self.comm_stream = None
-        self.n_segments = 8     # graph segments of the backward (the all-reduce of each finished range overlaps the next segment)
+        # graph segments of the backward (the all-reduce of each finished range overlaps the next segment); SPG_SEGMENTS: A/B runs
+        self.n_segments = int(os.environ.get("SPG_SEGMENTS", "8"))
         self.static = None
         self.losses = None
         self.world = sync.world if sync is not None else 1

@@ -461,6 +461,31 @@ def test_patch_im2col_is_exactly_unfold(ops, dt, B, H, W):
     assert not cols[:, 147:].any()
 
 
+@pytest.mark.parametrize("n,nparts", [(8, 1), (4096, 3), (1_000_000, 64), (54_525_952, 1024)])
+def test_cast_bf16_and_its_sums_of_squares(n, nparts):
+    """The gradient all-reduce's staging casts (engine/distributed.py): fp32 -> bf16 rounds to nearest even like torch, bf16 -> fp32 is exact,
+    and the cast-back variant's partial sums of squares add up to the norm of what it wrote (the clip's norm without a pass of its own)."""
+    from spegnet_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(n, device="cuda", generator=g) * 0.01
+    h = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("spg_cast_bf16", x.data_ptr(), h.data_ptr(), n, 0, st)
+    assert torch.equal(h, x.to(torch.bfloat16))
+    back = torch.full((n,), float("nan"), device="cuda")
+    _lib.call("spg_cast_bf16", back.data_ptr(), h.data_ptr(), n, 1, st)
+    assert torch.equal(back, h.float())
+    back2 = torch.full((n,), float("nan"), device="cuda")
+    parts = torch.full((nparts,), float("nan"), device="cuda")
+    _lib.call("spg_cast_bf16_sq", back2.data_ptr(), h.data_ptr(), n, parts.data_ptr(), nparts, st)
+    assert torch.equal(back2, back)
+    want = float(h.double().pow(2).sum())
+    assert abs(float(parts.double().sum()) - want) < 1e-5 * want
+    again = torch.empty_like(parts)
+    _lib.call("spg_cast_bf16_sq", back2.data_ptr(), h.data_ptr(), n, again.data_ptr(), nparts, st)
+    assert torch.equal(again, parts)          # a fixed order: bit-reproducible
+
+
 # ------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,C,relu", [(500, 64, True), (2304, 512, True), (4, 128, True), (1000, 16, False)])
