@@ -9,9 +9,6 @@ namespace spg {
 // LayerNorm: one wave per row, row cached in registers (<= MAXCH 16-byte chunks per lane).
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_MAXCH = 5;
-#ifndef SPG_LN_HOIST      // bit 0: layernorm_bwd requests dres with the row -- measured level (21.90 vs 21.88 ms per step, same box), off
-#define SPG_LN_HOIST 0
-#endif
 
 // RW = rows per wave: with many short rows (stages 1 and 2: 73728 x 144, 18432 x 288 at batch 8) one row per wave keeps only 288-576 bytes
 // in flight per wave -- a launch bound by memory latency at a third of the HBM rate.  A wave then takes RW consecutive rows, requests all of
@@ -88,9 +85,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   if (row0 >= M) return;
   const int nch = C / VEC;
   float xv[RW][NI][VEC], dv[RW][NI][VEC];
-#if SPG_LN_HOIST & 1
-  u32x4 dr[RW][NI];      // the residual gradient requested WITH the row (it is as cold as dy: loaded in the last loop it was one more trip to HBM)
-#endif
 #pragma unroll
   for (int r = 0; r < RW; ++r)
 #pragma unroll
@@ -99,9 +93,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       if (ch < nch && row0 + r < M) {
         unpack16<T>(ld16(x + (long)(row0 + r) * C + ch * VEC), xv[r][i]);
         unpack16<T>(ld16(dy + (long)(row0 + r) * C + ch * VEC), dv[r][i]);
-#if SPG_LN_HOIST & 1
-        if (dres) dr[r][i] = ld16(dres + (long)(row0 + r) * C + ch * VEC);
-#endif
       }
     }
 #pragma unroll
@@ -131,11 +122,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       const int ch = lane + 64 * i;
       if (ch < nch) {
         float o[VEC];
-#if SPG_LN_HOIST & 1
-        if (dres) unpack16<T>(dr[r][i], o);
-#else
-        if (dres) unpack16<T>(ld16(dres + (long)row * C + ch * VEC), o);
-#endif
+        if (dres) unpack16<T>(ld16(dres + (long)row * C + ch * VEC), o);   // (requested with the row instead: measured level, 21.90 vs 21.88 ms per step)
         else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) o[e] = 0.f;
