@@ -78,6 +78,35 @@ struct GatherSrc {
   int h, w, C, c0, s;     // c0: first output channel; s = output size / source size (2 or 4; the kernel is instantiated per s)
 };
 
+// the S x S outputs of source pixel (i, j), channel chunk ch, from its activated 3 x 3 neighbourhood (shared by the two kernels below: the
+// same expressions, so the same bits)
+template <typename T, int S>
+__device__ __forceinline__ void gather_emit(const GatherSrc& g, const float (&nb)[3][3][ST<T>::VEC], T* __restrict__ y, int b, int i, int j, int ch,
+                                            int H, int W, int ldy) {
+  constexpr int VEC = ST<T>::VEC;
+  float ly[S], lx[S];
+#pragma unroll
+  for (int o = 0; o < S; ++o) {
+    int t0, t1;
+    bil_src_h(i * S + o, g.h, H, t0, t1, ly[o]);
+    bil_src_h(j * S + o, g.w, W, t0, t1, lx[o]);
+  }
+#pragma unroll
+  for (int oy = 0; oy < S; ++oy) {
+    const int r0 = (2 * oy < S) ? 0 : 1;
+#pragma unroll
+    for (int ox = 0; ox < S; ++ox) {
+      const int q0 = (2 * ox < S) ? 0 : 1;
+      const float w00 = (1.f - ly[oy]) * (1.f - lx[ox]), w01 = (1.f - ly[oy]) * lx[ox], w10 = ly[oy] * (1.f - lx[ox]), w11 = ly[oy] * lx[ox];
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        o[e] = w00 * nb[r0][q0][e] + w01 * nb[r0][q0 + 1][e] + w10 * nb[r0 + 1][q0][e] + w11 * nb[r0 + 1][q0 + 1][e];
+      st16(y + (((long)b * H + (i * S + oy)) * W + (j * S + ox)) * ldy + g.c0 + ch * VEC, pack16<T>(o));
+    }
+  }
+}
+
 // Output pixel s*i + oy interpolates rows (i-1, i) of the source when oy < s/2 and rows (i, i+1) otherwise; with the neighbourhood
 // clamped at the borders this holds there too (the clamped row repeats the border pixel, and PyTorch's lambda -- 0 at the low border,
 // src - i0 at the high one -- is applied to two equal values exactly as here).  So tap selection is compile-time; only lambda is computed.
@@ -111,28 +140,7 @@ __device__ __forceinline__ void gather_one(const GatherSrc& g, T* __restrict__ y
       }
     }
   }
-  float ly[S], lx[S];
-#pragma unroll
-  for (int o = 0; o < S; ++o) {
-    int t0, t1;
-    bil_src_h(i * S + o, g.h, H, t0, t1, ly[o]);
-    bil_src_h(j * S + o, g.w, W, t0, t1, lx[o]);
-  }
-#pragma unroll
-  for (int oy = 0; oy < S; ++oy) {
-    constexpr int dummy = 0; (void)dummy;
-    const int r0 = (2 * oy < S) ? 0 : 1;
-#pragma unroll
-    for (int ox = 0; ox < S; ++ox) {
-      const int q0 = (2 * ox < S) ? 0 : 1;
-      const float w00 = (1.f - ly[oy]) * (1.f - lx[ox]), w01 = (1.f - ly[oy]) * lx[ox], w10 = ly[oy] * (1.f - lx[ox]), w11 = ly[oy] * lx[ox];
-      float o[VEC];
-#pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        o[e] = w00 * nb[r0][q0][e] + w01 * nb[r0][q0 + 1][e] + w10 * nb[r0 + 1][q0][e] + w11 * nb[r0 + 1][q0 + 1][e];
-      st16(y + (((long)b * H + (i * S + oy)) * W + (j * S + ox)) * ldy + g.c0 + ch * VEC, pack16<T>(o));
-    }
-  }
+  gather_emit<T, S>(g, nb, y, b, i, j, ch, H, W, ldy);
 }
 
 template <typename T, int SE>
@@ -143,6 +151,89 @@ __global__ __launch_bounds__(256) void ped_gather_kernel(GatherSrc a, GatherSrc 
     if (it < items_a) gather_one<T, 2>(a, y, it, H, W, ldy);
     else gather_one<T, SE>(e, y, it - items_a, H, W, ldy);
   }
+}
+
+// ---- LDS-tiled form.  The per-item kernel above loads a source pixel's 16-byte chunk NINE times (once per neighbour that interpolates
+// from it) and applies the BatchNorm + ReLU nine times: its load + arithmetic half alone took 56 of 74 us on the 96 -> 192 stage with the
+// stores compiled out, against 47 us for the stores with one load per item (tools/ped_probe.py).  Here a workgroup owns a 4 x 16-pixel
+// source tile of 64 channels: the 6 x 18 halo tile is loaded once (16-byte loads, 128 contiguous bytes per pixel), activated once and
+// kept in LDS as f32 (27 KiB); every thread then reads its 3 x 3 neighbourhood from LDS (conflict-free 16-byte reads) and emits its S x S
+// outputs with the expressions of gather_one -- the same bits.
+constexpr int PG_TH = 4, PG_TW = 16, PG_CCH = 8;
+constexpr int PG_HALO = (PG_TH + 2) * (PG_TW + 2);
+template <typename T, int S>
+__device__ __forceinline__ void gather_tile(const GatherSrc& g, T* __restrict__ y, long tile_id, int H, int W, int ldy, float* __restrict__ tile) {
+  constexpr int VEC = ST<T>::VEC;
+  static_assert(VEC == 8, "the tile layout is written for 8-element chunks (bf16)");
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const int nch = g.C / VEC, ncg = (nch + PG_CCH - 1) / PG_CCH;
+  const int tw = (g.w + PG_TW - 1) / PG_TW, th = (g.h + PG_TH - 1) / PG_TH;
+  const int cg = (int)(tile_id % ncg); long t = tile_id / ncg;
+  const int tj = (int)(t % tw); t /= tw;
+  const int ti = (int)(t % th);
+  const int b = (int)(t / th);
+  const int c = threadIdx.x & (PG_CCH - 1);                 // this thread's chunk inside the group, in both phases (256 % 8 == 0)
+  const int ch = cg * PG_CCH + c;
+  const bool ch_in = ch < nch;
+  const bool bn = g.ss != nullptr;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { sc[e] = (bn && ch_in) ? g.ss[ch * VEC + e] : 1.f; sh[e] = (bn && ch_in) ? g.ss[g.C + ch * VEC + e] : 0.f; }
+  // stage the halo tile: all of a thread's loads first, then activation + LDS writes
+  constexpr int NIT = (PG_HALO * PG_CCH + 255) / 256;       // 4
+  u32x4 raw[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int pix = (threadIdx.x >> 3) + k * 32;
+    raw[k] = u32x4{0u, 0u, 0u, 0u};
+    if (pix < PG_HALO && ch_in) {
+      const int py = pix / (PG_TW + 2), px = pix - py * (PG_TW + 2);
+      const int yy = min(max(ti * PG_TH + py - 1, 0), g.h - 1), xx = min(max(tj * PG_TW + px - 1, 0), g.w - 1);
+      raw[k] = ld16(x + (((long)b * g.h + yy) * g.w + xx) * g.C + ch * VEC);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int pix = (threadIdx.x >> 3) + k * 32;
+    if (pix < PG_HALO) {
+      float v[VEC];
+      unpack16<T>(raw[k], v);
+      if (bn) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+      }
+      float* d = tile + (pix * PG_CCH + c) * VEC;
+      *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < (PG_TH * PG_TW * PG_CCH) / 256; ++k) {          // 2 source pixels per thread
+    const int pix = (threadIdx.x >> 3) + k * 32;
+    const int pi = pix / PG_TW, pj = pix - pi * PG_TW;
+    const int i = ti * PG_TH + pi, j = tj * PG_TW + pj;
+    if (i < g.h && j < g.w && ch_in) {
+      float nb[3][3][VEC];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float* sp = tile + (((pi + dy) * (PG_TW + 2) + (pj + dx)) * PG_CCH + c) * VEC;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(sp), bb = *reinterpret_cast<const f32x4*>(sp + 4);
+          nb[dy][dx][0] = a[0]; nb[dy][dx][1] = a[1]; nb[dy][dx][2] = a[2]; nb[dy][dx][3] = a[3];
+          nb[dy][dx][4] = bb[0]; nb[dy][dx][5] = bb[1]; nb[dy][dx][6] = bb[2]; nb[dy][dx][7] = bb[3];
+        }
+      gather_emit<T, S>(g, nb, y, b, i, j, ch, H, W, ldy);
+    }
+  }
+}
+template <typename T, int SE>
+__global__ __launch_bounds__(256) void ped_gather_tiled_kernel(GatherSrc a, GatherSrc e, long tiles_a, T* __restrict__ y, int H, int W, int ldy) {
+  __shared__ __attribute__((aligned(16))) float tile[PG_HALO * PG_CCH * 8];
+  const long t = blockIdx.x;
+  if (t < tiles_a) gather_tile<T, 2>(a, y, t, H, W, ldy, tile);
+  else gather_tile<T, SE>(e, y, t - tiles_a, H, W, ldy, tile);
 }
 
 // adjoint (gather form): dx[b,i,j,c] (+)= sum over the output pixels whose taps include (i,j): exactly the 2S outputs
@@ -462,6 +553,16 @@ extern "C" int spg_ped_gather(int dtype, const void* x, const float* x_scale_shi
   const int grid = head_grid(ia + ie);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SPG_BF16) {
+#ifndef SPG_PED_TILED      // (tools/ A/B builds: 0 = the per-item kernel)
+#define SPG_PED_TILED 1
+#endif
+    auto tiles = [](int B_, int h, int w, int C) { return (long)B_ * cdiv(h, PG_TH) * cdiv(w, PG_TW) * cdiv(C / 8, PG_CCH); };
+    const long ta = tiles(B, hx, wx, Cx), te = Ce ? tiles(B, he, we, Ce) : 0;
+    if (SPG_PED_TILED && ta + te < 0x7fffffffL) {
+      if (se == 4) hipLaunchKernelGGL((ped_gather_tiled_kernel<bf16_t, 4>), dim3((unsigned)(ta + te)), dim3(256), 0, s, a, e, ta, (bf16_t*)y, H, W, Cx + Ce);
+      else hipLaunchKernelGGL((ped_gather_tiled_kernel<bf16_t, 2>), dim3((unsigned)(ta + te)), dim3(256), 0, s, a, e, ta, (bf16_t*)y, H, W, Cx + Ce);
+      return check_launch("ped_gather(tiled)");
+    }
     if (se == 4) hipLaunchKernelGGL((ped_gather_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, s, a, e, ia, ie, (bf16_t*)y, H, W, Cx + Ce);
     else hipLaunchKernelGGL((ped_gather_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, s, a, e, ia, ie, (bf16_t*)y, H, W, Cx + Ce);
   } else {

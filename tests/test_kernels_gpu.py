@@ -689,7 +689,8 @@ def test_cfi_fusion_without_concat(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("hx,Cx,he,Ce,bn", [(12, 64, 12, 16, True), (12, 32, 6, 16, False), (7, 16, 0, 0, True), (24, 256, 24, 64, True)])
+@pytest.mark.parametrize("hx,Cx,he,Ce,bn", [(12, 64, 12, 16, True), (12, 32, 6, 16, False), (7, 16, 0, 0, True), (24, 256, 24, 64, True),
+                                           (10, 128, 5, 64, True), (18, 72, 9, 8, False)])
 def test_ped_gather_fwd_bwd(ops, dt, hx, Cx, he, Ce, bn):
     """cat[up2(relu(bn(x))), up_s(edge)] in one launch == bn_apply + two upsample launches (which are pinned to F.interpolate above);
     the adjoint == the generic upsample_bwd (s = 2 and 4, channel offsets, accumulate)."""
