@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void bn_bwd_head_reduce_kernel(const T* __rest
     mu[e] = mi[c]; is[e] = mi[C + c]; sc[e] = ss[c]; sh[e] = ss[C + c]; wv[e] = hw[c];
   }
   if (active) {
-#pragma unroll 4
+#pragma unroll 4      // (8: 95.9 -> 93.2 us on the 384 x 384 x 64 stage, 59.6 -> 68.0 on 96 x 96 x 256: stays)
     for (long r = r0 + rl; r < r1; r += rpar) {
       float xv[VEC], dv[VEC];
       unpack16<T>(ld16(x + r * C + ch * VEC), xv);
