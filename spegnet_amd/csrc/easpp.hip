@@ -138,8 +138,7 @@ __global__ __launch_bounds__(256) void dwconv4_wgrad_kernel(const T* __restrict_
     for (long p = p0 + pl; p < p1; p += ppar) {
       const int X = (int)(p % W);
       const int Y = (int)((p / W) % H);
-      float dv[VEC];
-      unpack16<T>(ld16(dy + p * 4 * C + br * C + ch * VEC), dv);
+      const u32x4 rdy = ld16(dy + p * 4 * C + br * C + ch * VEC);
       u32x4 raw[9];     // (the nine taps in flight together, see dwconv4_kernel)
       bool ok[9];
 #pragma unroll
@@ -149,6 +148,9 @@ __global__ __launch_bounds__(256) void dwconv4_wgrad_kernel(const T* __restrict_
         const long q = ok[t] ? p + (long)(t / 3 - 1) * dil * W + (t % 3 - 1) * dil : p;
         raw[t] = ld16(x + q * C + ch * VEC);
       }
+      __builtin_amdgcn_sched_barrier(0);     // (the scheduler otherwise pairs each tap's conversion with its load: groups of two in the ISA)
+      float dv[VEC];
+      unpack16<T>(rdy, dv);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         float v[VEC];
@@ -423,22 +425,43 @@ __global__ __launch_bounds__(1024) void easpp_global_bwd_kernel(const float* __r
     const float wv = wf[cc];
     float dwsum = 0.f, s0 = 0.f, s1 = 0.f;
     const float mu = mi[ch], is = mi[C + ch];
-    for (int b = 0; b < B; ++b) {
-      const float sg = S[b * C + g];
-      dwsum += glob[b * C + ch] * sg;
-      const float dy = glob[b * C + ch] > 0.f ? wv * sg : 0.f;      // through the ReLU
-      sm[b * C + ch] = dy;
-      s0 += dy;
-      s1 += dy * (gl0[b * C + ch] - mu) * is;
+    for (int b0 = 0; b0 < B; b0 += 8) {        // eight images' operands requested together (they were one round trip per image), used in image order
+      float sgv[8], glv[8], g0v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u < B ? b0 + u : b0;
+        sgv[u] = S[b * C + g]; glv[u] = glob[b * C + ch]; g0v[u] = gl0[b * C + ch];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u;
+        if (b < B) {
+          const float sg = sgv[u];
+          dwsum += glv[u] * sg;
+          const float dy = glv[u] > 0.f ? wv * sg : 0.f;      // through the ReLU
+          sm[b * C + ch] = dy;
+          s0 += dy;
+          s1 += dy * (g0v[u] - mu) * is;
+        }
+      }
     }
     dwf[cc] += dwsum;
     dbeta[ch] += s0;
     dgamma[ch] += s1;
     const float gmm = gamma[ch];
-    for (int b = 0; b < B; ++b) {
-      const float dy = sm[b * C + ch];
-      // training: full BN backward over the B samples; eval: the affine map only
-      sm[b * C + ch] = training ? gmm * is * (dy - s0 / (float)B - (gl0[b * C + ch] - mu) * is * s1 / (float)B) : gmm * is * dy;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      float g0v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g0v[u] = gl0[(b0 + u < B ? b0 + u : b0) * C + ch];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u;
+        if (b < B) {
+          const float dy = sm[b * C + ch];
+          // training: full BN backward over the B samples; eval: the affine map only
+          sm[b * C + ch] = training ? gmm * is * (dy - s0 / (float)B - (g0v[u] - mu) * is * s1 / (float)B) : gmm * is * dy;
+        }
+      }
     }
   }
   __syncthreads();

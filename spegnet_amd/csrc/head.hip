@@ -273,19 +273,30 @@ __global__ __launch_bounds__(256) void ped_gather_bwd_kernel(const T* __restrict
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    // the candidates of KYB rows are requested together (all 16 of the x2 window, a row of 8 of the x4 window's 64), then added in the
+    // same order: load-convert-add per candidate was one round trip each in the ISA (35 load groups for the x4 instance)
+    constexpr int KYB = S == 2 ? 4 : 1;
 #pragma unroll
-    for (int ky = 0; ky < N; ++ky) {
-      const int Y = min(max(Y0 + ky, 0), H - 1);          // out-of-range candidates carry weight 0: clamp the address, keep the load
-      const T* row = dy + (((long)b * H + Y) * W) * ldy + c0 + ch * VEC;
+    for (int ky0 = 0; ky0 < N; ky0 += KYB) {
+      u32x4 raw[KYB][N];
 #pragma unroll
-      for (int kx = 0; kx < N; ++kx) {
-        const int X = min(max(X0 + kx, 0), W - 1);
-        float v[VEC];
-        unpack16<T>(ld16(row + (long)X * ldy), v);
-        const float wgt = wy[ky] * wx[kx];
+      for (int kk = 0; kk < KYB; ++kk) {
+        const int Y = min(max(Y0 + ky0 + kk, 0), H - 1);  // out-of-range candidates carry weight 0: clamp the address, keep the load
+        const T* row = dy + (((long)b * H + Y) * W) * ldy + c0 + ch * VEC;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] += wgt * v[e];
+        for (int kx = 0; kx < N; ++kx) raw[kk][kx] = ld16(row + (long)min(max(X0 + kx, 0), W - 1) * ldy);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < KYB; ++kk)
+#pragma unroll
+        for (int kx = 0; kx < N; ++kx) {
+          float v[VEC];
+          unpack16<T>(raw[kk][kx], v);
+          const float wgt = wy[ky0 + kk] * wx[kx];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] += wgt * v[e];
+        }
     }
     T* dst = dx + it * VEC;
     if (accumulate) {
@@ -335,25 +346,45 @@ __global__ __launch_bounds__(256) void bn_bwd_head_reduce_kernel(const T* __rest
     mu[e] = mi[c]; is[e] = mi[C + c]; sc[e] = ss[c]; sh[e] = ss[C + c]; wv[e] = hw[c];
   }
   if (active) {
-#pragma unroll 4      // (8: 95.9 -> 93.2 us on the 384 x 384 x 64 stage, 59.6 -> 68.0 on 96 x 96 x 256: stays)
-    for (long r = r0 + rl; r < r1; r += rpar) {
-      float xv[VEC], dv[VEC];
-      unpack16<T>(ld16(x + r * C + ch * VEC), xv);
-      if (dnext) unpack16<T>(ld16(dnext + r * C + ch * VEC), dv);
-      else {
+    // four rows per trip, their loads requested before the first is used (x, the incoming gradient and the head's scalar of each row: written
+    // row by row the compiler waited for every row's three loads in turn -- seen in the ISA as load groups of 3, 3, 3, 3; deeper: 8 rows 95.9
+    // -> 93.2 us on the 384 x 384 x 64 stage, 59.6 -> 68.0 on 96 x 96 x 256).  A row past the block's end re-reads the block's first row, weight 0.
+    const T* __restrict__ dsrc = dnext ? dnext : x;
+    for (long rb = r0 + rl; rb < r1; rb += 4 * rpar) {
+      u32x4 rx[4], rd[4];
+      float dpv[4];
+      bool in[4];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) dv[e] = 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const long r = rb + (long)u * rpar;
+        in[u] = r < r1;
+        const long rc = in[u] ? r : r0 + rl;
+        rx[u] = ld16(x + rc * C + ch * VEC);
+        rd[u] = ld16(dsrc + rc * C + ch * VEC);
+        dpv[u] = ST<T>::ld(dpred + rc);
       }
-      const float dp = ST<T>::ld(dpred + r);
-      if (chl == 0 && slab == 0) sb += dp;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float yv = xv[e] * sc[e] + sh[e];
-        const bool on = yv > 0.f;
-        const float d = on ? dv[e] + dp * wv[e] : 0.f;
-        s0[e] += d;
-        s1[e] += d * (xv[e] - mu[e]) * is[e];
-        s2[e] += on ? dp * yv : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        if (!in[u]) continue;
+        float xv[VEC], dv[VEC];
+        unpack16<T>(rx[u], xv);
+        if (dnext) unpack16<T>(rd[u], dv);
+        else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) dv[e] = 0.f;
+        }
+        const float dp = dpv[u];
+        if (chl == 0 && slab == 0) sb += dp;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float yv = xv[e] * sc[e] + sh[e];
+          const bool on = yv > 0.f;
+          const float d = on ? dv[e] + dp * wv[e] : 0.f;
+          s0[e] += d;
+          s1[e] += d * (xv[e] - mu[e]) * is[e];
+          s2[e] += on ? dp * yv : 0.f;
+        }
       }
     }
   }
