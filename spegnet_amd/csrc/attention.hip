@@ -268,6 +268,40 @@ __device__ __forceinline__ void stage_tile(const T* const* ptrs, int off, char* 
   }
 }
 
+// the same for NT tiles at once: every load of a thread is requested before the first LDS write (stage_tile's pointer-read -> load ->
+// write chain is one memory round trip per item: 3 per tile at head dim 72, and the tiles came one after the other -- 12 dependent round
+// trips in the one-pass small-window backward).  A null row reads a fixed valid address (`safe`) and is replaced by zeros.
+struct StageSrc { const void* const* ptrs; int off; char* img; };
+template <typename T, int HD, int NT>
+__device__ __forceinline__ void stage_tiles(const StageSrc (&src)[NT], const T* safe) {
+  constexpr int VEC = AC<T, HD>::VEC, NCH = AC<T, HD>::NCH, RS = AC<T, HD>::RS;
+  constexpr int NIT = (64 * NCH + AT - 1) / AT;
+  u32x4 v[NT][NIT];
+  bool nz[NT][NIT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int p = threadIdx.x + it * AT;
+      const int pc = p < 64 * NCH ? p : 0;
+      const int ch = pc % NCH, t = pc / NCH;
+      const T* s = reinterpret_cast<const T* const*>(src[k].ptrs)[t];
+      nz[k][it] = s != nullptr;
+      v[k][it] = ld16((s ? s + src[k].off : safe) + ch * VEC);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int p = threadIdx.x + it * AT;
+      if (p < 64 * NCH) {
+        const int ch = p % NCH, t = p / NCH;
+        *reinterpret_cast<u32x4*>(src[k].img + t * RS + ch * 16) = nz[k][it] ? v[k][it] : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+}
+
 // zero the parts of the images staging never writes (pad d columns / pad d rows)
 template <typename T, int HD>
 __device__ __forceinline__ void zero_images(char* base, int bytes) {
@@ -335,8 +369,10 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnP p) {
       kptr[tid] = kp; kb[tid] = b;
     }
     __syncthreads();
-    stage_tile<T, HD>(kptr, 0, kimg);
-    stage_tile<T, HD>(kptr, p.C, vimg);
+    {
+      const StageSrc kv[2] = {{reinterpret_cast<const void* const*>(kptr), 0, kimg}, {reinterpret_cast<const void* const*>(kptr), p.C, vimg}};
+      stage_tiles<T, HD, 2>(kv, qkv);
+    }
     __syncthreads();
     f32x4 sacc[4];
     mma_scores<T, HD>(kimg, qf, lane, sacc);
@@ -432,7 +468,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
       kptr[tid] = kp; kb[tid] = b;
     }
     __syncthreads();
-    stage_tile<T, HD>(kptr, 0, kimg);
+    stage_tile<T, HD>(kptr, 0, kimg);      // (not stage_tiles: 12 more VGPRs in this kernel, 128 -> 140)
     stage_tile<T, HD>(kptr, p.C, vimg);
     __syncthreads();
     f32x4 sacc[4], pacc[4];
@@ -513,7 +549,7 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(SUB ? 3 : 1,
       qptrs[tid] = a; doptrs[tid] = b; lse_s[tid] = ls; delta_s[tid] = dl;
     }
     __syncthreads();
-    stage_tile<T, HD>(qptrs, 0, qimg);
+    stage_tile<T, HD>(qptrs, 0, qimg);     // (not stage_tiles: this kernel sits at exactly 168 VGPRs = three waves per SIMD; the batched form takes 180)
     stage_tile<T, HD>(doptrs, 0, doimg);
     __syncthreads();
     f32x4 sacc[4], pacc[4];
@@ -604,10 +640,11 @@ __global__ __launch_bounds__(AT) void attn_bwd_small_kernel(AttnP p) {
     qptrs[i] = a; doptrs[i] = b; lse_s[i] = ls;
   }
   __syncthreads();
-  stage_tile<T, HD>(kptr, 0, kimg);
-  stage_tile<T, HD>(kptr, p.C, vimg);
-  stage_tile<T, HD>(qptrs, 0, qimg);
-  stage_tile<T, HD>(doptrs, 0, doimg);
+  {
+    const StageSrc all4[4] = {{reinterpret_cast<const void* const*>(kptr), 0, kimg}, {reinterpret_cast<const void* const*>(kptr), p.C, vimg},
+                              {reinterpret_cast<const void* const*>(qptrs), 0, qimg}, {reinterpret_cast<const void* const*>(doptrs), 0, doimg}};
+    stage_tiles<T, HD, 4>(all4, qkv);
+  }
   __syncthreads();
 
   // ---------------- query side (this lane's query: qi) ----------------
