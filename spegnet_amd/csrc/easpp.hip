@@ -192,14 +192,22 @@ __global__ __launch_bounds__(256) void easpp_fuse_bn_kernel(const T* __restrict_
     const int g = (int)(i % C);
     const long p = i / C;
     const long b = p / HW;
+    // (the five taps' operands requested together -- both sources with clamped indices, the one that applies chosen afterwards: a load in each
+    // arm of `if (cc < 4C)` was waited for inside its arm, five round trips per output)
+    float xv[5], sc[5], sh[5], gv[5], wv[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int cc = 5 * g + j;
+      const int cd = cc < C4 ? cc : 0, cg = cc < C4 ? 0 : cc - C4;
+      xv[j] = ST<T>::ld(dcat + p * C4 + cd); sc[j] = ss[cd]; sh[j] = ss[C4 + cd];
+      gv[j] = glob[b * C + cg]; wv[j] = w[g * 5 + j];
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int cc = 5 * g + j;
-      float v;
-      if (cc < C4) v = fmaxf(ST<T>::ld(dcat + p * C4 + cc) * ss[cc] + ss[C4 + cc], 0.f);
-      else v = glob[b * C + (cc - C4)];
-      s += w[g * 5 + j] * v;
+      const float v = cc < C4 ? fmaxf(xv[j] * sc[j] + sh[j], 0.f) : gv[j];
+      s += wv[j] * v;
     }
     ST<T>::st(y + i, s);
   }

@@ -9,6 +9,7 @@
 //   gradient (each low-res logit sums over the full-res pixels whose interpolation touches it), scaled by the upstream
 //   gradient read from device memory (no host sync).
 // All HBM-trivial (a few MB); the point is launch count and staying inside the hipGraph.
+#include <type_traits>
 #include "common.h"
 
 namespace spg {
@@ -34,6 +35,25 @@ __device__ __forceinline__ float bil_at(const T* __restrict__ p, int h, int w, i
   const float c = ST<T>::ld(p + (long)y1 * w + x0), d = ST<T>::ld(p + (long)y1 * w + x1);
   return (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
 }
+// bil_at in two halves: the four taps requested now, interpolated later (the reductions below request three pixels' operands per trip before
+// using any -- one pixel per trip was a memory round trip per pixel, nine in a row at 384 x 384)
+struct BilTaps { float a, b, c, d, ly, lx; };
+template <typename T, bool IDENT>
+__device__ __forceinline__ BilTaps bil_request(const T* __restrict__ p, int h, int w, int S, int Y, int X) {
+  BilTaps t;
+  if constexpr (IDENT) { t.a = ST<T>::ld(p + (long)Y * w + X); t.b = t.c = t.d = 0.f; t.ly = t.lx = 0.f; return t; }
+  int y0, y1, x0, x1;
+  bil_src_l(Y, h, S, y0, y1, t.ly);
+  bil_src_l(X, w, S, x0, x1, t.lx);
+  t.a = ST<T>::ld(p + (long)y0 * w + x0); t.b = ST<T>::ld(p + (long)y0 * w + x1);
+  t.c = ST<T>::ld(p + (long)y1 * w + x0); t.d = ST<T>::ld(p + (long)y1 * w + x1);
+  return t;
+}
+template <bool IDENT>
+__device__ __forceinline__ float bil_value(const BilTaps& t) {
+  if constexpr (IDENT) return t.a;
+  return (1.f - t.ly) * ((1.f - t.lx) * t.a + t.lx * t.b) + t.ly * ((1.f - t.lx) * t.c + t.lx * t.d);
+}
 __device__ __forceinline__ float pos_weight(float npos, float total) {
   return fminf(fmaxf((total - npos) / (npos + 1e-7f), 0.1f), 10.f);
 }
@@ -47,10 +67,24 @@ __global__ __launch_bounds__(256) void loss_wmap_kernel(const float* __restrict_
   __shared__ float red[4];
   const int b = blockIdx.z, ty0 = blockIdx.y * 32, tx0 = blockIdx.x * 32;
   const float* m = mask + (long)b * S * S;
-  for (int i = threadIdx.x; i < 62 * 62; i += 256) {
-    const int r = i / 62, c = i - r * 62;
-    const int y = ty0 + r - 15, x = tx0 + c - 15;
-    tile[r][c] = ((unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S) ? m[(long)y * S + x] : 0.f;
+  // (the 62 x 62 halo tile, five elements per thread and trip with their loads requested together: `cond ? load : 0` per element was one
+  // memory round trip for each of a thread's 16 elements)
+  for (int i0 = threadIdx.x; i0 < 62 * 62; i0 += 256 * 5) {
+    float v[5];
+    bool in[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i = i0 + u * 256;
+      const int r = i / 62, c = i - r * 62;
+      const int y = ty0 + r - 15, x = tx0 + c - 15;
+      in[u] = i < 62 * 62 && (unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S;
+      v[u] = m[in[u] ? (long)y * S + x : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i = i0 + u * 256;
+      if (i < 62 * 62) { const int r = i / 62, c = i - r * 62; tile[r][c] = in[u] ? v[u] : 0.f; }
+    }
   }
   __syncthreads();
   // 31-tap box sums as running sums: a thread owns 8 consecutive outputs of a row (31 + 2 x 7 LDS reads instead of 8 x 31), then 4
@@ -72,6 +106,12 @@ __global__ __launch_bounds__(256) void loss_wmap_kernel(const float* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < 31; ++d) s += hs[r0 + d][c];
+    float ev[4];                               // (the four edge-map values of this thread's outputs, requested together)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = ty0 + r0 + j, x = tx0 + c;
+      ev[j] = egt[(y < S && x < S) ? ((long)b * S + y) * S + x : (long)b * S * S];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = r0 + j;
@@ -88,7 +128,7 @@ __global__ __launch_bounds__(256) void loss_wmap_kernel(const float* __restrict_
         const float w = 1.f + bw * (lap + fabsf(s * (1.f / 961.f) - mv));
         wmap[((long)b * S + y) * S + x] = w;
         sm += mv; sw += w;
-        se += egt[((long)b * S + y) * S + x];
+        se += ev[j];
       }
     }
   }
@@ -118,16 +158,33 @@ __device__ __forceinline__ void seg_reduce_body(const T* __restrict__ pred, cons
   const float pw = pos_weight(stats[b * 4 + 0], (float)HW);
   const T* p = pred + (long)b * h * w;
   float A = 0.f, I = 0.f, U = 0.f;
-#pragma unroll 3   // (nine pixels per thread at 384 x 384 with 64 blocks per image: three pixels' loads in flight per trip)
-  for (long i = bx * 256L + threadIdx.x; i < HW; i += (long)gx * 256) {
-    const int Y = (int)(i / S), X = (int)(i - (long)Y * S);
-    const float z = bil_at<T>(p, h, w, S, Y, X);
-    const float m = mask[b * HW + i], wv = wmap[b * HW + i];
-    const float lw = 1.f + (pw - 1.f) * m;
-    const float bce = (1.f - m) * z + lw * (log1pf(__expf(-fabsf(z))) + fmaxf(-z, 0.f));
-    const float s = sigmoid_f(z);
-    A += wv * bce; I += s * m * wv; U += (s + m) * wv;
-  }
+  const long stride = (long)gx * 256;
+  auto walk = [&](auto ident_c) __attribute__((always_inline)) {
+    constexpr bool IDENT = decltype(ident_c)::value;
+    for (long i0 = bx * 256L + threadIdx.x; i0 < HW; i0 += 3 * stride) {
+      BilTaps tp[3];
+      float mv[3], wvv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const long i = i0 + u * stride < HW ? i0 + u * stride : i0;
+        const int Y = (int)(i / S), X = (int)(i - (long)Y * S);
+        tp[u] = bil_request<T, IDENT>(p, h, w, S, Y, X);
+        mv[u] = mask[b * HW + i]; wvv[u] = wmap[b * HW + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (i0 + u * stride < HW) {
+          const float z = bil_value<IDENT>(tp[u]);
+          const float m = mv[u], wv = wvv[u];
+          const float lw = 1.f + (pw - 1.f) * m;
+          const float bce = (1.f - m) * z + lw * (log1pf(__expf(-fabsf(z))) + fmaxf(-z, 0.f));
+          const float s = sigmoid_f(z);
+          A += wv * bce; I += s * m * wv; U += (s + m) * wv;
+        }
+      }
+    }
+  };
+  if (h == S && w == S) walk(std::true_type{}); else walk(std::false_type{});
   A = block_sum<256>(A, red); I = block_sum<256>(I, red); U = block_sum<256>(U, red);
   float* pp = part + ((long)b * gx + bx) * 4;
   if (threadIdx.x == 0) { st_part(pp, A); st_part(pp + 1, I); st_part(pp + 2, U); }
@@ -155,16 +212,33 @@ __device__ __forceinline__ void edge_reduce_body(const T* __restrict__ pred, con
   const float pw = pos_weight(stats[b * 4 + 2], (float)HW);
   const T* p = pred + (long)b * h * w;
   float Fs = 0.f, I = 0.f, P = 0.f;
-#pragma unroll 3
-  for (long i = bx * 256L + threadIdx.x; i < HW; i += (long)gx * 256) {
-    const int Y = (int)(i / S), X = (int)(i - (long)Y * S);
-    const float z = bil_at<T>(p, h, w, S, Y, X);
-    const float t = egt[b * HW + i];
-    const float s = sigmoid_f(z);
-    const float pt = t * s + (1.f - t) * (1.f - s);
-    Fs += -pw * alpha * __powf(1.f - pt, gamma) * __logf(fmaxf(pt, 1e-7f));
-    I += s * t; P += s;
-  }
+  const long stride = (long)gx * 256;
+  auto walk = [&](auto ident_c) __attribute__((always_inline)) {
+    constexpr bool IDENT = decltype(ident_c)::value;
+    for (long i0 = bx * 256L + threadIdx.x; i0 < HW; i0 += 3 * stride) {
+      BilTaps tp[3];
+      float tv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const long i = i0 + u * stride < HW ? i0 + u * stride : i0;
+        const int Y = (int)(i / S), X = (int)(i - (long)Y * S);
+        tp[u] = bil_request<T, IDENT>(p, h, w, S, Y, X);
+        tv[u] = egt[b * HW + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (i0 + u * stride < HW) {
+          const float z = bil_value<IDENT>(tp[u]);
+          const float t = tv[u];
+          const float s = sigmoid_f(z);
+          const float pt = t * s + (1.f - t) * (1.f - s);
+          Fs += -pw * alpha * __powf(1.f - pt, gamma) * __logf(fmaxf(pt, 1e-7f));
+          I += s * t; P += s;
+        }
+      }
+    }
+  };
+  if (h == S && w == S) walk(std::true_type{}); else walk(std::false_type{});
   Fs = block_sum<256>(Fs, red); I = block_sum<256>(I, red); P = block_sum<256>(P, red);
   float* pp = part + ((long)b * gx + bx) * 4;
   if (threadIdx.x == 0) { st_part(pp, Fs); st_part(pp + 1, I); st_part(pp + 2, P); }
