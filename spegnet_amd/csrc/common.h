@@ -75,6 +75,8 @@ template <typename T> __device__ __forceinline__ u32x4 ld16(const T* p) { return
 template <typename T> __device__ __forceinline__ void st16(T* p, const u32x4& c) { *reinterpret_cast<u32x4*>(p) = c; }
 
 // ---- wave / block reductions ------------------------------------------------------------------
+// (Six dependent ds_bpermute_b32 in the ISA.  A DPP form -- quad swaps, row rotations, four v_readlane -- was built and measured: LayerNorm
+// forward 6.0 -> 5.7 us, backward 6.1 -> 6.3, the step level at 21.1-21.2 ms: not worth a different summation order everywhere.)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
