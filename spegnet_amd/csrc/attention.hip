@@ -271,6 +271,12 @@ __device__ __forceinline__ void stage_tile(const T* const* ptrs, int off, char* 
 // the same for NT tiles at once: every load of a thread is requested before the first LDS write (stage_tile's pointer-read -> load ->
 // write chain is one memory round trip per item: 3 per tile at head dim 72, and the tiles came one after the other -- 12 dependent round
 // trips in the one-pass small-window backward).  A null row reads a fixed valid address (`safe`) and is replaced by zeros.
+#ifndef SPG_DQ_STAGE_TILES      // (tools/ A/B builds) the tiled dQ kernel: 52.7 -> 38.6 us per global block with the batched form, 12 more VGPRs notwithstanding
+#define SPG_DQ_STAGE_TILES 1
+#endif
+#ifndef SPG_DKV_STAGE_TILES
+#define SPG_DKV_STAGE_TILES 0
+#endif
 struct StageSrc { const void* const* ptrs; int off; char* img; };
 template <typename T, int HD, int NT>
 __device__ __forceinline__ void stage_tiles(const StageSrc (&src)[NT], const T* safe) {
@@ -468,8 +474,15 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnP p) {
       kptr[tid] = kp; kb[tid] = b;
     }
     __syncthreads();
-    stage_tile<T, HD>(kptr, 0, kimg);      // (not stage_tiles: 12 more VGPRs in this kernel, 128 -> 140)
+#if SPG_DQ_STAGE_TILES
+    {
+      const StageSrc kv[2] = {{reinterpret_cast<const void* const*>(kptr), 0, kimg}, {reinterpret_cast<const void* const*>(kptr), p.C, vimg}};
+      stage_tiles<T, HD, 2>(kv, qkv);
+    }
+#else
+    stage_tile<T, HD>(kptr, 0, kimg);
     stage_tile<T, HD>(kptr, p.C, vimg);
+#endif
     __syncthreads();
     f32x4 sacc[4], pacc[4];
     mma_scores<T, HD>(kimg, qf, lane, sacc);
@@ -549,8 +562,15 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(SUB ? 3 : 1,
       qptrs[tid] = a; doptrs[tid] = b; lse_s[tid] = ls; delta_s[tid] = dl;
     }
     __syncthreads();
-    stage_tile<T, HD>(qptrs, 0, qimg);     // (not stage_tiles: this kernel sits at exactly 168 VGPRs = three waves per SIMD; the batched form takes 180)
+#if SPG_DKV_STAGE_TILES
+    {
+      const StageSrc qd[2] = {{reinterpret_cast<const void* const*>(qptrs), 0, qimg}, {reinterpret_cast<const void* const*>(doptrs), 0, doimg}};
+      stage_tiles<T, HD, 2>(qd, qkv);
+    }
+#else
+    stage_tile<T, HD>(qptrs, 0, qimg);     // (not stage_tiles: this kernel sits at exactly 168 VGPRs = three waves per SIMD; the batched form takes 180: 52.2 -> 55.8 us)
     stage_tile<T, HD>(doptrs, 0, doimg);
+#endif
     __syncthreads();
     f32x4 sacc[4], pacc[4];
     mma_scores<T, HD>(qimg, kf, lane, sacc);   // S[i][key]
