@@ -13,14 +13,23 @@ constexpr int LN_MAXCH = 5;
 // RW = rows per wave: with many short rows (stages 1 and 2: 73728 x 144, 18432 x 288 at batch 8) one row per wave keeps only 288-576 bytes
 // in flight per wave -- a launch bound by memory latency at a third of the HBM rate.  A wave then takes RW consecutive rows, requests all of
 // them before the first reduction, and works through them one after the other (the arithmetic per row is unchanged: same bits).
-template <typename T, int NI = LN_MAXCH, int RW = 1>   // NI = 16-byte chunk slots per lane (ceil(C / (64 VEC))): sized per launch, not for the widest row
+// HALF: a row on 32 lanes, two rows per wave -- for rows of at most 32 chunks (stage 1: C = 144 is 18 chunks: 18 of 64 lanes busy with a
+// row per wave, 36 of 64 with two).  The row sums stay inside the half (xor distances < 32).
+template <int LPR> __device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T, int NI = LN_MAXCH, int RW = 1, bool HALF = false>   // NI = 16-byte chunk slots per lane (ceil(C / (64 VEC))): sized per launch, not for the widest row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                             int C, float eps) {
   constexpr int VEC = ST<T>::VEC;
-  const int lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  static_assert(!HALF || NI == 1, "two rows per wave: one chunk slot per lane");
+  constexpr int LPR = HALF ? 32 : 64;
+  const int lane = threadIdx.x & (LPR - 1);
+  const int row0 = (blockIdx.x * (256 / LPR) + (threadIdx.x / LPR)) * RW;
   if (row0 >= M) return;
   const int nch = C / VEC;
   // Every load of the wave is REQUESTED before the first one is used: written as `if (in range) unpack(load(..))` per chunk slot, each
@@ -33,13 +42,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   for (int r = 0; r < RW; ++r)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int ch = lane + 64 * i;
+      const int ch = lane + LPR * i;
       const bool ok = ch < nch && row0 + r < M;
       raw[r][i] = ld16(x + (long)(ok ? row0 + r : row0) * C + (ok ? ch : 0) * VEC);
     }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int ch = lane + 64 * i;
+    const int ch = lane + LPR * i;
     const int cc = (ch < nch ? ch : 0) * VEC;
 #pragma unroll
     for (int q4 = 0; q4 < VEC / 4; ++q4) {
@@ -60,27 +69,27 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int ch = lane + 64 * i;
+      const int ch = lane + LPR * i;
       if (ch < nch) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s += v[r][i][e];
       }
     }
-    const float mu = wave_sum(s) / C;
+    const float mu = row_sum<LPR>(s) / C;
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int ch = lane + 64 * i;
+      const int ch = lane + LPR * i;
       if (ch < nch) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { const float d = v[r][i][e] - mu; ss += d * d; }
       }
     }
-    const float rs = rsqrtf(wave_sum(ss) / C + eps);
+    const float rs = rsqrtf(row_sum<LPR>(ss) / C + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int ch = lane + 64 * i;
+      const int ch = lane + LPR * i;
       if (ch < nch) {
         float o[VEC];
 #pragma unroll
@@ -96,14 +105,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) (+dres).  One wave per row (RW rows, one after the other, all requested up front),
 // row held in registers (full thread-level parallelism hides HBM latency); the parameter gradients dgamma = sum_rows dy*xhat, dbeta =
 // sum_rows dy are column reductions done by colreduce_kernel<RED_LN> (a second, bandwidth-bound pass over dy and x).
-template <typename T, int NI = LN_MAXCH, int RW = 1>
+template <typename T, int NI = LN_MAXCH, int RW = 1, bool HALF = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
                                                             T* __restrict__ dx, int M, int C) {
   constexpr int VEC = ST<T>::VEC;
-  const int lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  static_assert(!HALF || NI == 1, "two rows per wave: one chunk slot per lane");
+  constexpr int LPR = HALF ? 32 : 64;
+  const int lane = threadIdx.x & (LPR - 1);
+  const int row0 = (blockIdx.x * (256 / LPR) + (threadIdx.x / LPR)) * RW;
   if (row0 >= M) return;
   const int nch = C / VEC;
   // all loads requested before the first use (see layernorm_fwd_kernel: the slot-by-slot form was SEVEN dependent round trips here -- x, dy
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const long rowc = row0 + r < M ? row0 + r : row0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int ch = lane + 64 * i;
+      const int ch = lane + LPR * i;
       const long off = rowc * C + (ch < nch ? ch : 0) * VEC;
       rx[r][i] = ld16(x + off);
       rdy[r][i] = ld16(dy + off);
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int ch = lane + 64 * i;
+    const int ch = lane + LPR * i;
     const int cc = (ch < nch ? ch : 0) * VEC;
 #pragma unroll
     for (int q4 = 0; q4 < VEC / 4; ++q4) gq[i][q4] = *reinterpret_cast<const f32x4*>(gamma + cc + 4 * q4);
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int ch = lane + 64 * i;
+      const int ch = lane + LPR * i;
       if (ch < nch) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -158,11 +169,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
       }
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
+    s1 = row_sum<LPR>(s1) / C;
+    s2 = row_sum<LPR>(s2) / C;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int ch = lane + 64 * i;
+      const int ch = lane + LPR * i;
       if (ch < nch) {
         float o[VEC];
         if (dres) unpack16<T>(rdr[r][i], o);
@@ -533,7 +544,13 @@ extern "C" int spg_layernorm_fwd(int dtype, const void* x, const float* gamma, c
 #define SPG_LN_RW_ROWS 32768     // rows from which a wave takes four rows of a one-slot (C <= 512 bf16) LayerNorm (tools/ A/B builds: a huge value = never)
 #endif
   if (dtype == SPG_BF16 && ni <= 1 && M >= SPG_LN_RW_ROWS) {      // many short rows (stage 1: 73728 x 144: 24.5 -> 22.2 us; 18432 x 288 gains nothing)
-    SPG_LNF_RW(bf16_t, 4);
+#ifndef SPG_LN_HALF      // (tools/ A/B builds: 0 = a row per wave whatever its length)
+#define SPG_LN_HALF 1
+#endif
+    if (SPG_LN_HALF && C / vec <= 32)     // ... and rows of at most 32 chunks two to a wave
+      hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 1, 4, true>), dim3(cdiv(M, 8 * 4)), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
+    else
+      SPG_LNF_RW(bf16_t, 4);
     return check_launch("layernorm_fwd");
   }
   if (dtype == SPG_BF16) { if (ni <= 1) SPG_LNF(bf16_t, 1); else if (ni == 2) SPG_LNF(bf16_t, 2); else if (ni == 3) SPG_LNF(bf16_t, 3); else SPG_LNF(bf16_t, LN_MAXCH); }
@@ -553,7 +570,9 @@ extern "C" int spg_layernorm_bwd(int dtype, const void* dy, const void* x, const
 #define SPG_LNB(T_, NI_) hipLaunchKernelGGL((layernorm_bwd_kernel<T_, NI_>), dim3(cdiv(M, 4)), dim3(256), 0, s, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (const T_*)dres, (T_*)dx, M, C)
   // (several rows per wave, as the forward does for many short rows: 73728 x 144 backward 35.3 us with four rows per wave, 26.2 with two,
   // 26.4 with one; 18432 x 288: 11.4 / 11.6 -- nothing to gain, the one-row kernel stays)
-  if (dtype == SPG_BF16) { if (ni <= 1) SPG_LNB(bf16_t, 1); else if (ni == 2) SPG_LNB(bf16_t, 2); else if (ni == 3) SPG_LNB(bf16_t, 3); else SPG_LNB(bf16_t, LN_MAXCH); }
+  if (dtype == SPG_BF16 && SPG_LN_HALF && C / vec <= 32 && M >= 8)      // short rows (stage 1): two to a wave
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 1, 1, true>), dim3(cdiv(M, 8)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
+  else if (dtype == SPG_BF16) { if (ni <= 1) SPG_LNB(bf16_t, 1); else if (ni == 2) SPG_LNB(bf16_t, 2); else if (ni == 3) SPG_LNB(bf16_t, 3); else SPG_LNB(bf16_t, LN_MAXCH); }
   else { if (ni <= 1) SPG_LNB(float, 1); else if (ni == 2) SPG_LNB(float, 2); else if (ni == 3) SPG_LNB(float, 3); else SPG_LNB(float, LN_MAXCH); }
 #undef SPG_LNB
   int rc = check_launch("layernorm_bwd");
