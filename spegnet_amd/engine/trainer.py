@@ -51,7 +51,11 @@ class TrainStep:
         self.segments = None
         self.comm_stream = None
         # graph segments of the backward (the all-reduce of each finished range overlaps the next segment); SPG_SEGMENTS: A/B runs
-        self.n_segments = int(os.environ.get("SPG_SEGMENTS", "8"))
+        # (six: eight blocks per segment -- under the 240-CU budget a segment's stage-3 weight gradients then pack into whole-block launches
+        # without a remainder for the tile kernel, and every seam between two graph launches costs ~0.1 ms: 1 / 2 / 4 / 6 / 8 / 16 segments
+        # = 21.3 / 21.8 / 22.0 / 22.4 / 22.65 / 22.8 ms against 20.8-21.2 for the single graph, tools/seg_probe.py; the last range -- the
+        # only exposed all-reduce -- stays small: blocks 0-7 are stages 1 and 2, 7 M parameters)
+        self.n_segments = int(os.environ.get("SPG_SEGMENTS", "6"))
         self.static = None
         self.losses = None
         self.world = sync.world if sync is not None else 1
@@ -159,15 +163,26 @@ class TrainStep:
         keep = [ar.p, ar.m, ar.v, ar.step_f] + list(model.buffers())
         snap = [t.clone() for t in keep]
 
+        # CU budget per segment (grid sizes are frozen at capture): the first segment and the optimizer run with no collective in
+        # flight -> all CUs; segments 2.. replay while the previous range is being all-reduced -> leave RCCL its CUs.  The warm-up runs
+        # under the SAME budgets: the weight-gradient launches -- and with them the set of gradient matrices that are stored whole and kept
+        # uncleared from step to step -- depend on the budget, and a warm-up that made other launches than the captured step leaves
+        # gradients behind that the captured backward adds to (Arena.step refuses that: the capture failed and every rank fell back to
+        # the eager step -- silently but for a log line, found by tools/seg_probe.py)
+        comm_cus = COMM_CU_BUDGET if (self.comm or self.force_segmented) else 0
+
         def run_all():
             (lo, hi, _), rest = plan[0], plan[1:]
-            losses = self._seg_first(*self.static, lo, hi)
-            for (l2, h2, _) in rest:
-                eng.trunk_bwd_blocks(l2, h2)
-            eng.trunk_bwd_end()
+            with ops.cu_budget(0):
+                losses = self._seg_first(*self.static, lo, hi)
+            with ops.cu_budget(comm_cus):
+                for (l2, h2, _) in rest:
+                    eng.trunk_bwd_blocks(l2, h2)
+                eng.trunk_bwd_end()
             if self.comm:
                 self._allreduce_flat()
-            self._opt(1.0 / self.world, reduced=[(0, self.arena.size)])
+            with ops.cu_budget(0):
+                self._opt(1.0 / self.world, reduced=[(0, self.arena.size)])
             return losses
 
         side = torch.cuda.Stream()
@@ -184,9 +199,6 @@ class TrainStep:
             self.sync.drop_staging()     # the warm-up reduced the arena in one piece: its staging buffer is never used again
         self.comm_stream = torch.cuda.Stream()
         self.segments = []
-        # CU budget per segment (grid sizes are frozen at capture): the first segment and the optimizer run with no collective in
-        # flight -> all CUs; segments 2.. replay while the previous range is being all-reduced -> leave RCCL its CUs
-        comm_cus = COMM_CU_BUDGET if (self.comm or self.force_segmented) else 0
         g0 = torch.cuda.CUDAGraph()
         with ops.cu_budget(0), torch.cuda.graph(g0, capture_error_mode=graph_capture_mode()):
             self.losses = self._seg_first(*self.static, plan[0][0], plan[0][1])

@@ -786,6 +786,40 @@ def test_config3_captured_batch64_forward_matches_oracle():
             assert rep["thr_diff"] <= 0.02 * rep["pixels"], rep
 
 
+def test_segmented_step_captures_with_whole_block_weight_gradients():
+    """The segmented (multi-GPU) capture at a size where the whole-block weight-gradient launches exist (Hiera-L, 1152 stage-3 rows): its
+    warm-up must make the SAME launches as the captured segments (the sets depend on each segment's CU budget, and the gradients they
+    cover are stored and kept uncleared from step to step) -- a mismatch makes Arena.step refuse the captured optimizer, the capture
+    fails and the N > 1 step silently runs eagerly (round 4: found with tools/seg_probe.py, not by the small-model tests).  Three steps:
+    the kept gradients are overwritten, not added to -- the gradient norms follow the single-graph step's."""
+    from spegnet_amd.engine.arena import Arena
+    from spegnet_amd.engine.trainer import TrainStep
+    from spegnet_amd.utils.loss_functions import CODLoss
+    batch = O.synthetic_batch(2, 384, seed=91)
+    dev = (batch[0].cuda(), torch.stack(batch[1]).cuda(), torch.stack(batch[2]).cuda())
+    norms = {}
+    for seg in (False, True):
+        m, sd, cfg = make_model("large", "bf16", seed=3, train=True)
+        arena = Arena(m)
+        m.mark_params_changed()
+        arena.set_hyper(1e-6, 0.0, 1.0)           # (tiny steps: the three steps see practically the same parameters)
+        step = TrainStep(m, CODLoss().cuda(), arena, grad_clip=1.0, capture=True, force_segmented=seg)
+        ns = []
+        for it in range(3):
+            step(*dev)
+            torch.cuda.synchronize()
+            ns.append(float(arena.gnorm_sq))
+        if seg:
+            assert step.capture and step.segments is not None and len(step.segments) >= 4, "the segmented capture fell back to eager launches"
+            assert len(arena._unzeroed) >= 40, "no gradient matrix was stored and kept: the whole-block launches did not run"
+        norms[seg] = ns
+    # step 1 runs on identical parameters; later steps only loosely (at random initialisation the bf16 network turns last-bit differences of
+    # the first update into percents of the next gradient) -- but a stale gradient added to the new one would about double the squared norm
+    assert abs(norms[False][0] - norms[True][0]) < 1e-3 * norms[False][0], norms
+    for a, b in zip(norms[False][1:], norms[True][1:]):
+        assert abs(a - b) < 0.1 * a, norms
+
+
 def test_segmented_graph_step_equals_eager_step():
     """The multi-GPU graph mode captures a hand-written backward in segments; on one rank it must update the parameters
     exactly like the autograd-driven eager step (up to float-atomic ordering)."""
