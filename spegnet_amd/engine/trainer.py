@@ -295,6 +295,8 @@ class TrainStep:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok) == 0:
                     logger.warning("hipGraph capture failed on at least one rank (%s): every rank runs the eager step", err)
+                    import warnings      # (a log line alone went unnoticed for hours once: the step then runs ~15 % slower, with the all-reduce exposed)
+                    warnings.warn(f"hipGraph capture of the multi-GPU train step failed ({err}); every rank runs the eager step", RuntimeWarning)
                     self.capture, self.graph, self.segments = False, None, None
                     return self._eager(images, masks, edges)
             elif err is not None:
